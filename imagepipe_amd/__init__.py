@@ -1,0 +1,551 @@
+"""imagepipe_amd -- MI355X-native raw->sRGB hot path behind imagepipe's Pipeline / ImageOp surface.
+
+This package is plumbing: it loads libimagepipe_amd.so (HIP kernels + C ABI, include/imagepipe_amd.h),
+uses torch only to own device memory / streams / process groups, and mirrors the reference's
+interface names (OpBuffer, OpGoFloat ... OpTransform, Pipeline, PipelineSettings) so tests read like
+the reference's.  All pixel work happens in the shared library on the GPU; nothing here computes
+pixels and nothing falls back to the CPU.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (IpkError, FusedParams, PipelineDesc, OUT_F32, OUT_U8, OUT_U16, SRC_U16, SRC_F32, SRC_RGB8, SRC_RGB16,
+                   OR_NORMAL, OR_HFLIP, OR_ROT180, OR_VFLIP, OR_TRANSPOSE, OR_ROT90, OR_TRANSVERSE, OR_ROT270, OR_UNKNOWN,
+                   ROT_NORMAL, ROT_90, ROT_180, ROT_270, IPK_NOOP)
+
+__all__ = ["init", "lib", "OpBuffer", "RawImage", "OtherImage", "PipelineSettings", "PipelineGlobals", "PipelineOps",
+           "Pipeline", "OpGoFloat", "OpDemosaic", "OpRotateCrop", "OpToLab", "OpBaseCurve", "OpFromLab", "OpGamma",
+           "OpTransform", "raw_to_srgb", "IpkError"]
+
+_initialized_device = None
+
+
+def lib():
+    return _lib.load()
+
+
+def init(device: Optional[int] = None):
+    """Binds the library to a GPU (torch's current device by default).  Raises without a GPU."""
+    global _initialized_device
+    L = lib()
+    if not torch.cuda.is_available():
+        raise IpkError("imagepipe_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    if device is None:
+        device = torch.cuda.current_device()
+    if _initialized_device != device:
+        torch.cuda.set_device(device)
+        torch.zeros(1, device="cuda")               # make sure torch's HIP context exists first
+        _lib.check(L.ipk_init(device), "ipk_init")
+        _initialized_device = device
+    return device
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: torch.Tensor):
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _farr(vals, n):
+    a = (C.c_float * n)()
+    v = np.asarray(vals, dtype=np.float32).ravel()
+    assert v.size == n, (v.size, n)
+    for i in range(n):
+        a[i] = v[i]
+    return a
+
+
+def _points(points):
+    p = np.asarray(points, dtype=np.float32).reshape(-1)
+    arr = (C.c_float * max(2, p.size))()
+    for i, v in enumerate(p):
+        arr[i] = v
+    return arr, p.size // 2
+
+
+# ---------------------------------------------------------------------------------------------
+# OpBuffer (src/buffer.rs:5-32): width, height, colors, monochrome, data (f32, row-major interleaved)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class OpBuffer:
+    width: int
+    height: int
+    colors: int
+    monochrome: bool
+    data: torch.Tensor                      # device, float32, width*height*colors elements
+
+    @staticmethod
+    def new(width, height, colors, monochrome=False):
+        return OpBuffer(width, height, colors, monochrome,
+                        torch.zeros(width * height * colors, dtype=torch.float32, device="cuda"))
+
+    @staticmethod
+    def from_numpy(a: np.ndarray, monochrome=False):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim == 2:
+            h, w = a.shape; c = 1
+        else:
+            h, w, c = a.shape
+        return OpBuffer(w, h, c, monochrome, torch.from_numpy(a.reshape(-1)).cuda())
+
+    def numpy(self):
+        a = self.data.cpu().numpy()
+        return a.reshape(self.height, self.width) if self.colors == 1 else a.reshape(self.height, self.width, self.colors)
+
+
+# ---------------------------------------------------------------------------------------------
+# Sources: the fields of rawloader::RawImage / image::DynamicImage the hot path reads
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class RawImage:
+    width: int
+    height: int
+    data: torch.Tensor                      # device uint16 (stored as int16 bits) or float32, width*height*cpp
+    cpp: int = 1
+    cfa: str = ""                           # uncropped CFA pattern; "" = not a CFA image
+    crops: Sequence[int] = (0, 0, 0, 0)     # top, right, bottom, left
+    blacklevels: Sequence[float] = (0, 0, 0, 0)
+    whitelevels: Sequence[float] = (65535, 65535, 65535, 65535)
+    wb_coeffs: Sequence[float] = (1.0, 1.0, 1.0, float("nan"))
+    cam_to_xyz_normalized: Optional[np.ndarray] = None      # [[f32;4];3]; default SRGB_D65_43
+    orientation: int = OR_NORMAL
+    is_float: bool = False
+
+    def cropped_cfa(self):
+        if not self.cfa:
+            return ""
+        out = C.create_string_buffer(200)
+        _lib.check(lib().ipk_cfa_shift(self.cfa.encode(), int(self.crops[3]), int(self.crops[0]), out), "ipk_cfa_shift")
+        return out.value.decode()
+
+
+@dataclass
+class OtherImage:
+    width: int
+    height: int
+    data: torch.Tensor                      # device uint8 or uint16(int16 bits), width*height*3
+    bits: int = 8
+
+
+def upload_u16(a: np.ndarray) -> torch.Tensor:
+    """uint16 numpy -> device tensor (torch has no uint16 arithmetic; the bits are kept in int16)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint16).view(np.int16).reshape(-1)).cuda()
+
+
+SRGB_D65_43 = np.array([[0.4124564, 0.3575761, 0.1804375, 0.0],
+                        [0.2126729, 0.7151522, 0.0721750, 0.0],
+                        [0.0193339, 0.1191920, 0.9503041, 0.0]], dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# PipelineSettings / PipelineGlobals (src/pipeline.rs:110-151)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PipelineSettings:
+    maxwidth: int = 0
+    maxheight: int = 0
+    demosaic_width: int = 0
+    demosaic_height: int = 0
+    linear: bool = False
+    use_fastpath: bool = True
+
+
+@dataclass
+class PipelineGlobals:
+    image: object
+    settings: PipelineSettings = field(default_factory=PipelineSettings)
+
+
+# ---------------------------------------------------------------------------------------------
+# The eight ops (src/ops/*.rs).  Each `run` is one C-ABI call on device buffers and follows the
+# reference's contract: returns either the *same* OpBuffer (no-op cases) or a fresh one.
+# ---------------------------------------------------------------------------------------------
+class ImageOp:
+    name = "?"
+
+    def run(self, pipeline: PipelineGlobals, buf: OpBuffer) -> OpBuffer:
+        raise NotImplementedError
+
+    def transform_forward(self, width, height):
+        return width, height
+
+    def transform_reverse(self, width, height):
+        return width, height
+
+    def reset(self):
+        pass
+
+
+class OpGoFloat(ImageOp):
+    """src/ops/gofloat.rs"""
+    name = "gofloat"
+
+    def __init__(self, img):
+        if isinstance(img, RawImage):
+            self.crop_top, self.crop_right, self.crop_bottom, self.crop_left = [int(c) for c in img.crops]
+            self.is_cfa = bool(img.cfa)
+            self.blacklevels = [float(v) for v in img.blacklevels]
+            self.whitelevels = [float(v) for v in img.whitelevels]
+        else:
+            self.crop_top = self.crop_right = self.crop_bottom = self.crop_left = 0
+            self.is_cfa = False
+            self.blacklevels = [0.0] * 4
+            self.whitelevels = [0.0] * 4
+
+    def size_image(self, owidth, oheight):
+        out = (C.c_size_t * 4)()
+        _lib.check(lib().ipk_size_image(self.crop_top, self.crop_right, self.crop_bottom, self.crop_left, owidth, oheight, out),
+                   "ipk_size_image")
+        return tuple(out)
+
+    def transform_forward(self, width, height):
+        _, _, w, h = self.size_image(width, height)
+        return w, h
+
+    def run(self, pipeline, _buf=None):
+        img = pipeline.image
+        L = lib()
+        x, y, w, h = self.size_image(img.width, img.height)
+        if isinstance(img, RawImage):
+            sfx = "f32" if img.is_float else "u16"
+            if img.cpp == 1 and not self.is_cfa:
+                out = OpBuffer.new(w, h, 4, True)
+                fn = getattr(L, "ipk_gofloat_mono_" + sfx)
+                _lib.check(fn(_ptr(img.data), img.width, x, y, w, h, self.blacklevels[0], self.whitelevels[0], _ptr(out.data), _stream()), fn.__name__)
+            elif img.cpp == 3:
+                out = OpBuffer.new(w, h, 4, False)
+                fn = getattr(L, "ipk_gofloat_rgb_" + sfx)
+                _lib.check(fn(_ptr(img.data), img.width, x, y, w, h, _farr(self.blacklevels, 4), _farr(self.whitelevels, 4), _ptr(out.data), _stream()), fn.__name__)
+            else:
+                out = OpBuffer.new(w, h, img.cpp, False)
+                fn = getattr(L, "ipk_gofloat_cfa_" + sfx)
+                _lib.check(fn(_ptr(img.data), img.width, x, y, w, h, self.blacklevels[0], self.whitelevels[0], _ptr(out.data), _stream()), fn.__name__)
+        else:
+            out = OpBuffer.new(w, h, 4, False)
+            fn = L.ipk_gofloat_other_u8 if img.bits == 8 else L.ipk_gofloat_other_u16
+            _lib.check(fn(_ptr(img.data), img.width, x, y, w, h, _ptr(out.data), _stream()), "ipk_gofloat_other")
+        return out
+
+
+class OpDemosaic(ImageOp):
+    """src/ops/demosaic.rs"""
+    name = "demosaic"
+
+    def __init__(self, img):
+        self.cfa = img.cropped_cfa() if isinstance(img, RawImage) else ""
+
+    def run(self, pipeline, buf):
+        nw, nh = pipeline.settings.demosaic_width, pipeline.settings.demosaic_height
+        out = torch.empty(max(buf.width * buf.height, nw * nh) * 4, dtype=torch.float32, device="cuda")
+        ow, oh = C.c_size_t(), C.c_size_t()
+        rc = _lib.check(lib().ipk_demosaic_run(_ptr(buf.data), buf.width, buf.height, buf.colors, self.cfa.encode(), nw, nh,
+                                               _ptr(out), C.byref(ow), C.byref(oh), _stream()), "ipk_demosaic_run")
+        if rc == IPK_NOOP:
+            return buf
+        return OpBuffer(ow.value, oh.value, 4, buf.monochrome, out[: ow.value * oh.value * 4])
+
+
+class OpRotateCrop(ImageOp):
+    """src/ops/rotatecrop.rs"""
+    name = "rotatecrop"
+
+    def __init__(self, _img=None):
+        self.crop_top = self.crop_right = self.crop_bottom = self.crop_left = self.rotation = 0.0
+        self.reset()
+
+    def reset(self):
+        self.input_ratio = 1.0
+        self.output_size = None
+
+    def _params(self):
+        return _farr([self.crop_top, self.crop_right, self.crop_bottom, self.crop_left, self.rotation], 5)
+
+    def calc_size(self, width, height, reverse):
+        ow, oh = C.c_size_t(), C.c_size_t()
+        _lib.check(lib().ipk_rotatecrop_calc_size(self._params(), self.input_ratio, width, height, int(reverse), C.byref(ow), C.byref(oh)),
+                   "ipk_rotatecrop_calc_size")
+        return ow.value, oh.value
+
+    def transform_forward(self, width, height):
+        if self.output_size is not None:
+            return self.output_size
+        # `width as f32 / height as f32` (rotatecrop.rs:71)
+        self.input_ratio = float(np.float32(width) / np.float32(height)) if height else float("inf")
+        return self.calc_size(width, height, False)
+
+    def transform_reverse(self, width, height):
+        self.output_size = (width, height)
+        return self.calc_size(width, height, True)
+
+    def run(self, pipeline, buf):
+        ow, oh = C.c_size_t(), C.c_size_t()
+        rc = _lib.check(lib().ipk_rotatecrop(_ptr(buf.data), buf.width, buf.height, buf.colors, self._params(), None,
+                                             C.byref(ow), C.byref(oh), _stream()), "ipk_rotatecrop")
+        if rc == IPK_NOOP:
+            return buf
+        out = OpBuffer.new(ow.value, oh.value, buf.colors, buf.monochrome)
+        _lib.check(lib().ipk_rotatecrop(_ptr(buf.data), buf.width, buf.height, buf.colors, self._params(), _ptr(out.data),
+                                        C.byref(ow), C.byref(oh), _stream()), "ipk_rotatecrop")
+        return out
+
+
+class OpToLab(ImageOp):
+    """src/ops/colorspaces.rs:5-113"""
+    name = "to_lab"
+
+    def __init__(self, img):
+        if isinstance(img, RawImage):
+            cm = SRGB_D65_43 if img.cam_to_xyz_normalized is None else np.asarray(img.cam_to_xyz_normalized, np.float32)
+            self.cam_to_xyz_normalized = cm.reshape(3, 4)
+            self.wb_coeffs = [float(v) for v in img.wb_coeffs]
+        else:
+            self.cam_to_xyz_normalized = SRGB_D65_43
+            self.wb_coeffs = [1.0, 1.0, 1.0, 0.0]
+
+    def run(self, pipeline, buf):
+        out = OpBuffer.new(buf.width, buf.height, 3, buf.monochrome)
+        _lib.check(lib().ipk_tolab(_ptr(buf.data), buf.width, buf.height, int(buf.monochrome), _farr(self.wb_coeffs, 4),
+                                   _farr(self.cam_to_xyz_normalized, 12), _ptr(out.data), _stream()), "ipk_tolab")
+        return out
+
+
+class OpBaseCurve(ImageOp):
+    """src/ops/curves.rs:6-50"""
+    name = "basecurve"
+
+    def __init__(self, img):
+        self.exposure = 0.0
+        self.points = [(0.50, 0.60)] if isinstance(img, RawImage) else []
+
+    def run(self, pipeline, buf):
+        pts, n = _points(self.points)
+        out = OpBuffer.new(buf.width, buf.height, 3, buf.monochrome)
+        rc = _lib.check(lib().ipk_basecurve(_ptr(buf.data), buf.width, buf.height, self.exposure, pts, n, _ptr(out.data), _stream()),
+                        "ipk_basecurve")
+        return buf if rc == IPK_NOOP else out
+
+
+class OpFromLab(ImageOp):
+    """src/ops/colorspaces.rs:115-138"""
+    name = "from_lab"
+
+    def __init__(self, _img=None):
+        pass
+
+    def run(self, pipeline, buf):
+        out = OpBuffer.new(buf.width, buf.height, 3, buf.monochrome)
+        _lib.check(lib().ipk_fromlab(_ptr(buf.data), buf.width, buf.height, _ptr(out.data), _stream()), "ipk_fromlab")
+        return out
+
+
+class OpGamma(ImageOp):
+    """src/ops/gamma.rs"""
+    name = "gamma"
+
+    def __init__(self, _img=None):
+        pass
+
+    def run(self, pipeline, buf):
+        out = OpBuffer.new(buf.width, buf.height, buf.colors, buf.monochrome)
+        rc = _lib.check(lib().ipk_gamma(_ptr(buf.data), buf.width, buf.height, buf.colors, int(pipeline.settings.linear),
+                                        _ptr(out.data), _stream()), "ipk_gamma")
+        return buf if rc == IPK_NOOP else out
+
+
+class OpTransform(ImageOp):
+    """src/ops/transform.rs:14-85"""
+    name = "transform"
+    _FROM_ORIENTATION = {
+        OR_NORMAL: (ROT_NORMAL, False, False), OR_UNKNOWN: (ROT_NORMAL, False, False),
+        OR_VFLIP: (ROT_NORMAL, False, True), OR_HFLIP: (ROT_NORMAL, True, False),
+        OR_ROT180: (ROT_180, False, False), OR_TRANSPOSE: (ROT_90, False, True),
+        OR_ROT90: (ROT_90, False, False), OR_ROT270: (ROT_270, False, False),
+        OR_TRANSVERSE: (ROT_270, True, False),
+    }
+
+    def __init__(self, img):
+        if isinstance(img, RawImage):
+            self.rotation, self.fliph, self.flipv = self._FROM_ORIENTATION[img.orientation]
+        else:
+            self.rotation, self.fliph, self.flipv = ROT_NORMAL, False, False
+
+    def transform_forward(self, width, height):
+        return (height, width) if self.rotation in (ROT_90, ROT_270) else (width, height)
+
+    transform_reverse = transform_forward
+
+    def run(self, pipeline, buf):
+        out = OpBuffer.new(buf.width, buf.height, 3, buf.monochrome)
+        ow, oh = C.c_size_t(), C.c_size_t()
+        rc = _lib.check(lib().ipk_transform(_ptr(buf.data), buf.width, buf.height, self.rotation, int(self.fliph), int(self.flipv),
+                                            _ptr(out.data), C.byref(ow), C.byref(oh), _stream()), "ipk_transform")
+        if rc == IPK_NOOP:
+            return buf
+        out.width, out.height = ow.value, oh.value
+        return out
+
+
+class PipelineOps:
+    """src/pipeline.rs:153-179"""
+    ORDER = ["gofloat", "demosaic", "rotatecrop", "tolab", "basecurve", "fromlab", "gamma", "transform"]
+
+    def __init__(self, img):
+        self.gofloat = OpGoFloat(img)
+        self.demosaic = OpDemosaic(img)
+        self.rotatecrop = OpRotateCrop(img)
+        self.tolab = OpToLab(img)
+        self.basecurve = OpBaseCurve(img)
+        self.fromlab = OpFromLab(img)
+        self.gamma = OpGamma(img)
+        self.transform = OpTransform(img)
+
+    def all_ops(self):
+        return [getattr(self, n) for n in self.ORDER]
+
+
+class Pipeline:
+    """src/pipeline.rs:246-470 (cache == None; hashing/caching/serialisation are out of scope).
+
+    `run()` hands the whole op list to the C driver (ipk_pipeline_run), which uses the fused
+    raw->sRGB kernel when every op between gofloat and gamma allows it and the staged kernels
+    otherwise.  `run_ops()` walks the Python op objects one by one exactly like the reference's
+    loop (pipeline.rs:364-372) and exists so tests can compare the two."""
+
+    def __init__(self, img):
+        self.globals = PipelineGlobals(img)
+        self.ops = PipelineOps(img)
+        self.allow_fused = True
+        self.last_used_fused = None
+
+    @staticmethod
+    def new_from_source(img):
+        init()
+        return Pipeline(img)
+
+    # -- size negotiation (pipeline.rs:314-338) in Python over the op objects
+    def negotiate(self):
+        ops = self.ops.all_ops()
+        for op in ops:
+            op.reset()
+        w, h = self.globals.image.width, self.globals.image.height
+        for op in ops:
+            w, h = op.transform_forward(w, h)
+        s, nw, nh = C.c_float(), C.c_size_t(), C.c_size_t()
+        lib().ipk_calculate_scaling_total(w, h, self.globals.settings.maxwidth, self.globals.settings.maxheight,
+                                          C.byref(s), C.byref(nw), C.byref(nh))
+        w, h = nw.value, nh.value
+        final = (w, h)
+        for op in reversed(ops):
+            w, h = op.transform_reverse(w, h)
+        self.globals.settings.demosaic_width, self.globals.settings.demosaic_height = w, h
+        return (w, h), final
+
+    def run_ops(self) -> OpBuffer:
+        self.negotiate()
+        buf = None
+        for op in self.ops.all_ops():
+            buf = op.run(self.globals, buf)
+        return buf
+
+    # -- descriptor for the C driver
+    def desc(self) -> PipelineDesc:
+        img, ops, st = self.globals.image, self.ops, self.globals.settings
+        d = PipelineDesc()
+        if isinstance(img, RawImage):
+            d.src_type = SRC_F32 if img.is_float else SRC_U16
+            d.cpp = img.cpp
+        else:
+            d.src_type = SRC_RGB8 if img.bits == 8 else SRC_RGB16
+            d.cpp = 3
+        d.width, d.height = img.width, img.height
+        d.is_cfa = int(ops.gofloat.is_cfa)
+        d.cfa = ops.demosaic.cfa.encode()
+        d.crop_top, d.crop_right, d.crop_bottom, d.crop_left = ops.gofloat.crop_top, ops.gofloat.crop_right, ops.gofloat.crop_bottom, ops.gofloat.crop_left
+        d.blacklevels[:] = ops.gofloat.blacklevels
+        d.whitelevels[:] = ops.gofloat.whitelevels
+        rc = ops.rotatecrop
+        d.rotatecrop[:] = [rc.crop_top, rc.crop_right, rc.crop_bottom, rc.crop_left, rc.rotation]
+        d.cam_to_xyz_normalized[:] = [float(v) for v in np.asarray(ops.tolab.cam_to_xyz_normalized, np.float32).ravel()]
+        d.wb_coeffs[:] = ops.tolab.wb_coeffs
+        d.exposure = ops.basecurve.exposure
+        p = np.asarray(ops.basecurve.points, np.float32).ravel()
+        d.npoints = p.size // 2
+        for i, v in enumerate(p):
+            d.points[i] = v
+        d.rotation, d.fliph, d.flipv = ops.transform.rotation, int(ops.transform.fliph), int(ops.transform.flipv)
+        d.maxwidth, d.maxheight = st.maxwidth, st.maxheight
+        d.linear = int(st.linear)
+        d.allow_fused = int(self.allow_fused)
+        return d
+
+    def sizes(self):
+        d = self.desc()
+        a, b, c, e = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _lib.check(lib().ipk_pipeline_sizes(C.byref(d), C.byref(a), C.byref(b), C.byref(c), C.byref(e)), "ipk_pipeline_sizes")
+        return (a.value, b.value), (c.value, e.value)
+
+    def _run(self, out_type, out: Optional[torch.Tensor] = None):
+        d = self.desc()
+        _, (fw, fh) = self.sizes()
+        dt = {OUT_F32: torch.float32, OUT_U8: torch.uint8, OUT_U16: torch.int16}[out_type]
+        if out is None:
+            out = torch.empty(fw * fh * 3, dtype=dt, device="cuda")
+        used = C.c_int(0)
+        _lib.check(lib().ipk_pipeline_run(C.byref(d), _ptr(self.globals.image.data), _ptr(out), out_type, C.byref(used), _stream()),
+                   "ipk_pipeline_run")
+        self.last_used_fused = bool(used.value)
+        return out, fw, fh
+
+    def run(self, out: Optional[torch.Tensor] = None) -> OpBuffer:
+        data, w, h = self._run(OUT_F32, out)
+        return OpBuffer(w, h, 3, False, data)
+
+    def output_8bit(self):
+        """Pipeline::output_8bit slow path (pipeline.rs:404-421): returns (width, height, uint8 device tensor)."""
+        data, w, h = self._run(OUT_U8)
+        return w, h, data
+
+    def output_16bit(self):
+        """Pipeline::output_16bit slow path (pipeline.rs:451-468): uint16 bits in an int16 device tensor."""
+        data, w, h = self._run(OUT_U16)
+        return w, h, data
+
+
+def raw_to_srgb(src: torch.Tensor, *, width, height, owidth=None, x=0, y=0, is_float=True, black0=0.0, white0=1.0,
+                cfa="RGGB", wb_coeffs=(1.0, 1.0, 1.0, float("nan")), cam_to_xyz_normalized=None, exposure=0.0,
+                points=((0.5, 0.6),), linear=False, out_type=OUT_F32, out: Optional[torch.Tensor] = None, band=None):
+    """The fused kernel through the C ABI (ipk_raw_to_srgb); `band` = (src_row0, src_rows, out_row0, out_rows)."""
+    init()
+    p = FusedParams()
+    p.src_type = SRC_F32 if is_float else SRC_U16
+    p.owidth = owidth if owidth is not None else width
+    p.x, p.y, p.width, p.height = x, y, width, height
+    p.black0, p.white0 = black0, white0
+    p.cfa = cfa.encode()
+    p.wb_coeffs[:] = list(wb_coeffs)
+    cm = SRGB_D65_43 if cam_to_xyz_normalized is None else np.asarray(cam_to_xyz_normalized, np.float32)
+    p.cam_to_xyz_normalized[:] = [float(v) for v in cm.ravel()]
+    p.exposure = exposure
+    pts = np.asarray(points, np.float32).ravel()
+    p.npoints = pts.size // 2
+    for i, v in enumerate(pts):
+        p.points[i] = v
+    p.linear = int(linear)
+    p.out_type = out_type
+    rows = height
+    if band is not None:
+        p.band_src_row0, p.band_src_rows, p.band_out_row0, p.band_out_rows = band
+        rows = band[3]
+    dt = {OUT_F32: torch.float32, OUT_U8: torch.uint8, OUT_U16: torch.int16}[out_type]
+    if out is None:
+        out = torch.empty(rows * width * 3, dtype=dt, device="cuda")
+    _lib.check(lib().ipk_raw_to_srgb(C.byref(p), _ptr(src), _ptr(out), _stream()), "ipk_raw_to_srgb")
+    return out

@@ -1,0 +1,151 @@
+"""ctypes binding of libimagepipe_amd.so (the C ABI in include/imagepipe_amd.h).
+
+The library is the product; this module only loads it and declares the signatures.  If the shared
+object is missing the import fails loudly -- there is no Python or CPU implementation to fall back to.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libimagepipe_amd.so")
+
+IPK_OK, IPK_NOOP = 0, 1
+SRC_U16, SRC_F32, SRC_RGB8, SRC_RGB16 = 0, 1, 2, 3
+OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
+OR_NORMAL, OR_HFLIP, OR_ROT180, OR_VFLIP, OR_TRANSPOSE, OR_ROT90, OR_TRANSVERSE, OR_ROT270, OR_UNKNOWN = range(9)
+ROT_NORMAL, ROT_90, ROT_180, ROT_270 = range(4)
+
+_sz = C.c_size_t
+_vp = C.c_void_p
+_fp = C.POINTER(C.c_float)
+_szp = C.POINTER(C.c_size_t)
+_i64 = C.c_int64
+
+
+class FusedParams(C.Structure):
+    """ipk_fused_params"""
+    _fields_ = [
+        ("src_type", C.c_int), ("owidth", _sz),
+        ("x", _sz), ("y", _sz), ("width", _sz), ("height", _sz),
+        ("black0", C.c_float), ("white0", C.c_float),
+        ("cfa", C.c_char * 160),
+        ("wb_coeffs", C.c_float * 4), ("cam_to_xyz_normalized", C.c_float * 12),
+        ("exposure", C.c_float), ("npoints", C.c_int), ("points", C.c_float * 128),
+        ("linear", C.c_int), ("out_type", C.c_int),
+        ("band_src_row0", _sz), ("band_src_rows", _sz), ("band_out_row0", _sz), ("band_out_rows", _sz),
+    ]
+
+
+class PipelineDesc(C.Structure):
+    """ipk_pipeline_desc"""
+    _fields_ = [
+        ("src_type", C.c_int), ("width", _sz), ("height", _sz),
+        ("cpp", C.c_int), ("is_cfa", C.c_int), ("cfa", C.c_char * 160),
+        ("crop_top", _sz), ("crop_right", _sz), ("crop_bottom", _sz), ("crop_left", _sz),
+        ("blacklevels", C.c_float * 4), ("whitelevels", C.c_float * 4),
+        ("rotatecrop", C.c_float * 5),
+        ("cam_to_xyz_normalized", C.c_float * 12), ("wb_coeffs", C.c_float * 4),
+        ("exposure", C.c_float), ("npoints", C.c_int), ("points", C.c_float * 128),
+        ("rotation", C.c_int), ("fliph", C.c_int), ("flipv", C.c_int),
+        ("maxwidth", _sz), ("maxheight", _sz),
+        ("linear", C.c_int), ("allow_fused", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes).  Every symbol include/imagepipe_amd.h declares is listed here;
+# tests/test_cabi_symbols.py cross-checks this table against the header text.
+_GO = [_sz, _sz, _sz, _sz, _sz]                       # owidth, x, y, width, height
+_CORNERS = [_i64] * 6
+SIGNATURES = {
+    "ipk_init": (C.c_int, [C.c_int]),
+    "ipk_shutdown": (None, []),
+    "ipk_is_initialized": (C.c_int, []),
+    "ipk_last_error": (C.c_char_p, []),
+    "ipk_device_cus": (C.c_int, []),
+    "ipk_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
+    "ipk_free": (C.c_int, [_vp]),
+    "ipk_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ipk_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ipk_stream_sync": (C.c_int, [_vp]),
+    "ipk_lut_table": (C.c_int, [C.c_int, _fp]),
+    "ipk_size_image": (C.c_int, [_sz] * 6 + [_szp]),
+    "ipk_calculate_scaling_total": (C.c_int, [_sz] * 4 + [_fp, _szp, _szp]),
+    "ipk_normalize_wbs": (C.c_int, [_fp, _fp]),
+    "ipk_spline_new": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, _fp]),
+    "ipk_rotatecrop_calc_size": (C.c_int, [_fp, C.c_float, _sz, _sz, C.c_int, _szp, _szp]),
+    "ipk_cfa_shift": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
+    "ipk_orientation_to_flips": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "ipk_orientation_from_flips": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ipk_transform_orientation": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ipk_gofloat_cfa_u16": (C.c_int, [_vp] + _GO + [C.c_float, C.c_float, _vp, _vp]),
+    "ipk_gofloat_cfa_f32": (C.c_int, [_vp] + _GO + [C.c_float, C.c_float, _vp, _vp]),
+    "ipk_gofloat_mono_u16": (C.c_int, [_vp] + _GO + [C.c_float, C.c_float, _vp, _vp]),
+    "ipk_gofloat_mono_f32": (C.c_int, [_vp] + _GO + [C.c_float, C.c_float, _vp, _vp]),
+    "ipk_gofloat_rgb_u16": (C.c_int, [_vp] + _GO + [_fp, _fp, _vp, _vp]),
+    "ipk_gofloat_rgb_f32": (C.c_int, [_vp] + _GO + [_fp, _fp, _vp, _vp]),
+    "ipk_gofloat_other_u8": (C.c_int, [_vp] + _GO + [_vp, _vp]),
+    "ipk_gofloat_other_u16": (C.c_int, [_vp] + _GO + [_vp, _vp]),
+    "ipk_demosaic_full": (C.c_int, [_vp, _sz, _sz, C.c_char_p, _vp, _vp]),
+    "ipk_demosaic_full_band": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_char_p, _vp, _vp]),
+    "ipk_transform_buffer_f32": (C.c_int, [_vp, _sz, _sz] + _CORNERS + [_sz, _sz, _sz, C.c_char_p, _vp, _vp]),
+    "ipk_transform_buffer_u8": (C.c_int, [_vp, _sz, _sz] + _CORNERS + [_sz, _sz, _sz, C.c_char_p, _vp, _vp]),
+    "ipk_transform_buffer_u16": (C.c_int, [_vp, _sz, _sz] + _CORNERS + [_sz, _sz, _sz, C.c_char_p, _vp, _vp]),
+    "ipk_scaled_demosaic": (C.c_int, [_vp, _sz, _sz, C.c_char_p, _sz, _sz, _vp, _vp]),
+    "ipk_scale_down_opbuf": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "ipk_demosaic_run": (C.c_int, [_vp, _sz, _sz, _sz, C.c_char_p, _sz, _sz, _vp, _szp, _szp, _vp]),
+    "ipk_rotatecrop": (C.c_int, [_vp, _sz, _sz, _sz, _fp, _vp, _szp, _szp, _vp]),
+    "ipk_tolab": (C.c_int, [_vp, _sz, _sz, C.c_int, _fp, _fp, _vp, _vp]),
+    "ipk_basecurve": (C.c_int, [_vp, _sz, _sz, C.c_float, _fp, C.c_int, _vp, _vp]),
+    "ipk_fromlab": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "ipk_gamma": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp]),
+    "ipk_rotate_buffer": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _szp, _szp, _vp]),
+    "ipk_transform": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_int, C.c_int, _vp, _szp, _szp, _vp]),
+    "ipk_output8bit": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "ipk_output16bit": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "ipk_raw_to_srgb": (C.c_int, [C.POINTER(FusedParams), _vp, _vp, _vp]),
+    "ipk_pipeline_sizes": (C.c_int, [C.POINTER(PipelineDesc), _szp, _szp, _szp, _szp]),
+    "ipk_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int), _vp]),
+    "ipk_host_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "ipk_host_gofloat_cfa_u16": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_float, C.c_float, _vp]),
+    "ipk_host_gofloat_cfa_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_float, C.c_float, _vp]),
+    "ipk_host_demosaic_full": (C.c_int, [_vp, _sz, _sz, C.c_char_p, _vp]),
+    "ipk_host_transform_buffer_f32": (C.c_int, [_vp, _sz, _sz] + _CORNERS + [_sz, _sz, _sz, C.c_char_p, _vp]),
+    "ipk_host_tolab": (C.c_int, [_vp, _sz, _sz, C.c_int, _fp, _fp, _vp]),
+    "ipk_host_basecurve": (C.c_int, [_vp, _sz, _sz, C.c_float, _fp, C.c_int, _vp]),
+    "ipk_host_fromlab": (C.c_int, [_vp, _sz, _sz, _vp]),
+    "ipk_host_gamma": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp]),
+    "ipk_host_rotate_buffer": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _szp, _szp]),
+    "ipk_host_output8bit": (C.c_int, [_vp, _sz, _vp]),
+    "ipk_host_output16bit": (C.c_int, [_vp, _sz, _vp]),
+    "ipk_host_raw_to_srgb": (C.c_int, [C.POINTER(FusedParams), _vp, _vp]),
+}
+
+_lib = None
+
+
+class IpkError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (never builds it, never substitutes anything for it)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "imagepipe_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C imagepipe_amd/csrc`. There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise IpkError("%s failed (%d): %s" % (what or "ipk call", rc, load().ipk_last_error().decode()))
+    return rc

@@ -1,0 +1,768 @@
+// ipk_api.cpp -- the C ABI (include/imagepipe_amd.h): context, host-side parameter preparation,
+// the Pipeline::run driver and the host-pointer wrappers.  No device code here; kernels are
+// reached through ipk_launch.hpp.  There is deliberately no CPU implementation of any pixel
+// loop in this file: without a GPU every compute entry point fails with IPK_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/imagepipe_amd.h"
+#include "ipk_host.hpp"
+#include "ipk_launch.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                               \
+  do { hipError_t e_ = (expr);                                                                     \
+       if (e_ != hipSuccess) return fail(IPK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct DevCfa { uint32_t *lookups = nullptr; uint8_t *cfa48 = nullptr; };
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  int num_cus = 0;
+  std::vector<float> lut_host[3];
+  void *lut_pairs[3] = {nullptr, nullptr, nullptr};      // device, 8192 x {v, dv}
+  float xyz_d65_33[9];
+  std::map<std::string, DevCfa> cfa_cache;
+  // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
+  struct Block { void *p; size_t bytes; bool busy; };
+  std::vector<Block> pool;
+  std::mutex mu;
+};
+Context g;
+
+void build_host_luts() {
+  if (!g.lut_host[0].empty()) return;
+  for (int i = 0; i < 3; ++i) g.lut_host[i] = ipk::build_lut(static_cast<ipk::LutId>(i));
+  const ipk::Mat33 inv = ipk::inverse(ipk::srgb_d65_33());
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g.xyz_d65_33[r * 3 + c] = inv.m[r][c];
+}
+
+int require_init() {
+  if (!g.ready) return fail(IPK_ERR_NOT_INIT, "ipk_init() has not succeeded (no MI355X/HIP device bound); there is no CPU fallback");
+  return IPK_OK;
+}
+#define REQUIRE_INIT() do { int rc_ = require_init(); if (rc_) return rc_; } while (0)
+
+hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
+
+bool dims_ok(size_t w, size_t h) { return w >= 1 && h >= 1 && w < (1ull << 31) && h < (1ull << 31); }
+
+// device-side tables for one CFA pattern string (uploaded once, cached)
+int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
+  if (!ipk::Cfa::parse(pat, cfa) || !cfa.valid()) return fail(IPK_ERR_INVALID, "invalid CFA pattern \"%s\"", pat ? pat : "(null)");
+  std::lock_guard<std::mutex> lk(g.mu);
+  auto it = g.cfa_cache.find(pat);
+  if (it != g.cfa_cache.end()) { dev = it->second; return IPK_OK; }
+  uint32_t lookups[48 * 48];
+  cfa.demosaic_lookups(lookups);
+  DevCfa d;
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&d.lookups), sizeof(lookups)));
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&d.cfa48), 48 * 48));
+  HIPCHK(hipMemcpy(d.lookups, lookups, sizeof(lookups), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.cfa48, &cfa.pattern[0][0], 48 * 48, hipMemcpyHostToDevice));
+  g.cfa_cache[pat] = d;
+  dev = d;
+  return IPK_OK;
+}
+
+// scratch pool: buffers are handed out and returned in stream order by a single caller thread
+int pool_get(size_t bytes, void **out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  int best = -1;
+  for (size_t i = 0; i < g.pool.size(); ++i)
+    if (!g.pool[i].busy && g.pool[i].bytes >= bytes && (best < 0 || g.pool[i].bytes < g.pool[best].bytes)) best = (int)i;
+  if (best >= 0) { g.pool[best].busy = true; *out = g.pool[best].p; return IPK_OK; }
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+  g.pool.push_back({p, bytes, true});
+  *out = p;
+  return IPK_OK;
+}
+void pool_put(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g.mu);
+  for (auto &b : g.pool) if (b.p == p) { b.busy = false; return; }
+}
+struct Scratch {                       // RAII: returns its buffers to the pool
+  std::vector<void *> bufs;
+  ~Scratch() { for (void *p : bufs) pool_put(p); }
+  int get(size_t bytes, void **out) { int rc = pool_get(bytes, out); if (!rc) bufs.push_back(*out); return rc; }
+  void release(void *p) { pool_put(p); bufs.erase(std::remove(bufs.begin(), bufs.end(), p), bufs.end()); }
+};
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+int ipk_init(int device) {
+  if (g.ready && g.device == device) return IPK_OK;
+  if (g.ready) ipk_shutdown();
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(IPK_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(IPK_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  g.num_cus = prop.multiProcessorCount;
+  build_host_luts();
+  for (int t = 0; t < 3; ++t) {
+    // {table[i], table[i+1]-table[i]}: the subtraction of lookup() (color_conversions.rs:112) hoisted
+    std::vector<float> pairs(2 * 8192);
+    for (int i = 0; i < 8192; ++i) { pairs[2 * i] = g.lut_host[t][i]; pairs[2 * i + 1] = g.lut_host[t][i + 1] - g.lut_host[t][i]; }
+    HIPCHK(hipMalloc(&g.lut_pairs[t], pairs.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(g.lut_pairs[t], pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  g.device = device;
+  g.ready = true;
+  return IPK_OK;
+}
+
+void ipk_shutdown(void) {
+  if (!g.ready) return;
+  (void)hipDeviceSynchronize();
+  for (int t = 0; t < 3; ++t) { if (g.lut_pairs[t]) (void)hipFree(g.lut_pairs[t]); g.lut_pairs[t] = nullptr; }
+  for (auto &kv : g.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); }
+  g.cfa_cache.clear();
+  for (auto &b : g.pool) (void)hipFree(b.p);
+  g.pool.clear();
+  g.ready = false; g.device = -1; g.num_cus = 0;
+}
+int ipk_is_initialized(void) { return g.ready ? 1 : 0; }
+const char *ipk_last_error(void) { return g_err; }
+int ipk_device_cus(void) { return g.num_cus; }
+
+int ipk_malloc(void **dptr, size_t bytes) { REQUIRE_INIT(); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return IPK_OK; }
+int ipk_free(void *dptr) { REQUIRE_INIT(); HIPCHK(hipFree(dptr)); return IPK_OK; }
+int ipk_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+  REQUIRE_INIT(); HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream))); return IPK_OK;
+}
+int ipk_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+  REQUIRE_INIT(); HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream))); return IPK_OK;
+}
+int ipk_stream_sync(void *stream) { REQUIRE_INIT(); HIPCHK(hipStreamSynchronize(S(stream))); return IPK_OK; }
+
+int ipk_lut_table(int which, float *out8193) {
+  if (which < 0 || which > 2 || !out8193) return fail(IPK_ERR_INVALID, "bad table id");
+  build_host_luts();
+  std::memcpy(out8193, g.lut_host[which].data(), ipk::kLutLen * sizeof(float));
+  return IPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side maths
+// ------------------------------------------------------------------------------------------
+int ipk_size_image(size_t crop_top, size_t crop_right, size_t crop_bottom, size_t crop_left,
+                   size_t owidth, size_t oheight, size_t *out4) {
+  ipk::Rect r;
+  if (!ipk::size_image(crop_top, crop_right, crop_bottom, crop_left, owidth, oheight, r))
+    return fail(IPK_ERR_INVALID, "image %zux%zu is smaller than 10x10", owidth, oheight);
+  out4[0] = r.x; out4[1] = r.y; out4[2] = r.width; out4[3] = r.height;
+  return IPK_OK;
+}
+int ipk_calculate_scaling_total(size_t width, size_t height, size_t maxwidth, size_t maxheight,
+                                float *scale, size_t *nwidth, size_t *nheight) {
+  const ipk::Scaling s = ipk::calculate_scaling_total(width, height, maxwidth, maxheight);
+  *scale = s.scale; *nwidth = s.width; *nheight = s.height;
+  return IPK_OK;
+}
+int ipk_normalize_wbs(const float *vals4, float *out4) { ipk::normalize_wbs(vals4, out4); return IPK_OK; }
+int ipk_spline_new(const float *pts, int npts, float *px, float *py, float *c1s, float *c2s, float *c3s) {
+  ipk::Spline s;
+  if (!s.build(pts, npts)) return fail(IPK_ERR_INVALID, "invalid curve (%d points)", npts);
+  std::memcpy(px, s.px, s.npoints * sizeof(float)); std::memcpy(py, s.py, s.npoints * sizeof(float));
+  std::memcpy(c1s, s.c1, s.npoints * sizeof(float));
+  std::memcpy(c2s, s.c2, s.nseg * sizeof(float)); std::memcpy(c3s, s.c3, s.nseg * sizeof(float));
+  return s.npoints;
+}
+int ipk_rotatecrop_calc_size(const float *p, float input_ratio, size_t width, size_t height, int reverse,
+                             size_t *nwidth, size_t *nheight) {
+  ipk::RotateCrop rc;
+  rc.crop_top = p[0]; rc.crop_right = p[1]; rc.crop_bottom = p[2]; rc.crop_left = p[3]; rc.rotation = p[4];
+  rc.input_ratio = input_ratio;
+  rc.calc_size(width, height, reverse != 0, *nwidth, *nheight);
+  return IPK_OK;
+}
+int ipk_cfa_shift(const char *pattern, int x, int y, char *out) {
+  ipk::Cfa c;
+  if (!ipk::Cfa::parse(pattern, c)) return fail(IPK_ERR_INVALID, "invalid CFA pattern");
+  const std::string s = c.shifted_name(x, y);
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return IPK_OK;
+}
+int ipk_orientation_to_flips(int orientation, int *f) {
+  bool t, x, y; ipk::orientation_to_flips(orientation, t, x, y); f[0] = t; f[1] = x; f[2] = y; return IPK_OK;
+}
+int ipk_orientation_from_flips(int transpose, int flip_x, int flip_y) { return ipk::orientation_from_flips(transpose, flip_x, flip_y); }
+int ipk_transform_orientation(int rotation, int fliph, int flipv) {
+  if (rotation < 0 || rotation > 3) return fail(IPK_ERR_INVALID, "bad rotation");
+  return ipk::transform_orientation(rotation, fliph != 0, flipv != 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage kernels (device pointers)
+// ------------------------------------------------------------------------------------------
+#define GOFLOAT_ARGS_OK() do { REQUIRE_INIT(); if (!src || !dst || !dims_ok(width, height) || !dims_ok(owidth, 1)) return fail(IPK_ERR_INVALID, "bad gofloat arguments"); } while (0)
+
+int ipk_gofloat_cfa_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                        float black0, float white0, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_cfa<uint16_t>(src, owidth, x, y, width, height, black0, white0, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_cfa_f32(const float *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                        float black0, float white0, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_cfa<float>(src, owidth, x, y, width, height, black0, white0, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_mono_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                         float black0, float white0, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_mono<uint16_t>(src, owidth, x, y, width, height, black0, white0, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_mono_f32(const float *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                         float black0, float white0, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_mono<float>(src, owidth, x, y, width, height, black0, white0, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_rgb_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                        const float *black4, const float *white4, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_rgb<uint16_t>(src, owidth, x, y, width, height, black4, white4, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_rgb_f32(const float *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                        const float *black4, const float *white4, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_rgb<float>(src, owidth, x, y, width, height, black4, white4, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_other_u8(const uint8_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_other_u8(src, owidth, x, y, width, height, g.lut_pairs[ipk::kLutGammaReverse], dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float *dst, void *stream) {
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_other_u16(src, owidth, x, y, width, height, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+
+int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, size_t src_row0, size_t src_rows,
+                           size_t out_row0, size_t out_rows, const char *cfa_pat, float *dst4, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst4 || !dims_ok(width, img_height) || out_rows == 0 || out_row0 + out_rows > img_height)
+    return fail(IPK_ERR_INVALID, "bad demosaic arguments");
+  // the band must carry every in-image tap row of its output rows
+  const size_t need0 = out_row0 > 0 ? out_row0 - 1 : 0;
+  const size_t need1 = std::min(img_height, out_row0 + out_rows + 1);
+  if (src_row0 > need0 || src_row0 + src_rows < need1) return fail(IPK_ERR_INVALID, "band rows [%zu,%zu) do not cover taps [%zu,%zu)", src_row0, src_row0 + src_rows, need0, need1);
+  ipk::Cfa cfa; DevCfa dev;
+  int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
+  ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+int ipk_demosaic_full(const float *src, size_t width, size_t height, const char *cfa, float *dst4, void *stream) {
+  return ipk_demosaic_full_band(src, width, height, 0, height, 0, height, cfa, dst4, stream);
+}
+
+#define TRANSFORM_BODY(T)                                                                                    \
+  REQUIRE_INIT();                                                                                            \
+  if (!src || !dst || !dims_ok(width, height) || !dims_ok(nwidth, nheight) || components < 1 || components > 4) \
+    return fail(IPK_ERR_INVALID, "bad transform_buffer arguments");                                          \
+  const uint8_t *cfa48 = nullptr;                                                                            \
+  if (cfa_pat) { ipk::Cfa cfa; DevCfa dev; int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc; cfa48 = dev.cfa48; } \
+  ipk::launch_transform_buffer<T>(src, width, height, tlx, tly, trx, try_, blx, bly, nwidth, nheight, components, cfa48, dst, S(stream)); \
+  HIPCHK(hipGetLastError());                                                                                 \
+  return IPK_OK;
+
+int ipk_transform_buffer_f32(const float *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
+                             int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components, const char *cfa_pat,
+                             float *dst, void *stream) { TRANSFORM_BODY(float) }
+int ipk_transform_buffer_u8(const uint8_t *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
+                            int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components, const char *cfa_pat,
+                            uint8_t *dst, void *stream) { TRANSFORM_BODY(uint8_t) }
+int ipk_transform_buffer_u16(const uint16_t *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
+                             int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components, const char *cfa_pat,
+                             uint16_t *dst, void *stream) { TRANSFORM_BODY(uint16_t) }
+
+// scale_down_buffer's corners (src/scaling.rs:35-48)
+int ipk_scaled_demosaic(const float *src, size_t width, size_t height, const char *cfa, size_t nwidth, size_t nheight, float *dst4, void *stream) {
+  if (!cfa) return fail(IPK_ERR_INVALID, "scaled_demosaic needs a CFA");
+  return ipk_transform_buffer_f32(src, width, height, 0, 0, (int64_t)width - 1, 0, 0, (int64_t)height - 1, nwidth, nheight, 4, cfa, dst4, stream);
+}
+int ipk_scale_down_opbuf(const float *src4, size_t width, size_t height, size_t nwidth, size_t nheight, float *dst4, void *stream) {
+  return ipk_transform_buffer_f32(src4, width, height, 0, 0, (int64_t)width - 1, 0, 0, (int64_t)height - 1, nwidth, nheight, 4, nullptr, dst4, stream);
+}
+
+int ipk_demosaic_run(const float *src, size_t width, size_t height, size_t colors, const char *cfa_pat,
+                     size_t demosaic_width, size_t demosaic_height, float *dst4, size_t *out_width, size_t *out_height, void *stream) {
+  REQUIRE_INIT();
+  if (colors != 1 && colors != 4) return fail(IPK_ERR_INVALID, "demosaic expects 1 or 4 colours");
+  const float scale = ipk::calculate_scaling_total(width, height, demosaic_width, demosaic_height).scale;
+  ipk::Cfa cfa;
+  if (!ipk::Cfa::parse(cfa_pat ? cfa_pat : "", cfa)) return fail(IPK_ERR_INVALID, "invalid CFA pattern");
+  const float minscale = ipk::demosaic_minscale(cfa.width);
+  if (scale <= 1.0f && colors == 4) { *out_width = width; *out_height = height; return IPK_NOOP; }        // demosaic.rs:41-43
+  if (colors == 4) {                                                                                       // :44-46
+    *out_width = demosaic_width; *out_height = demosaic_height;
+    return ipk_scale_down_opbuf(src, width, height, demosaic_width, demosaic_height, dst4, stream);
+  }
+  if (scale >= minscale) {                                                                                 // :47-50
+    *out_width = demosaic_width; *out_height = demosaic_height;
+    return ipk_scaled_demosaic(src, width, height, cfa_pat, demosaic_width, demosaic_height, dst4, stream);
+  }
+  if (scale > 1.0f) {                                                                                      // :54-56
+    Scratch sc; void *full = nullptr;
+    int rc = sc.get(width * height * 4 * sizeof(float), &full); if (rc) return rc;
+    rc = ipk_demosaic_full(src, width, height, cfa_pat, static_cast<float *>(full), stream); if (rc) return rc;
+    *out_width = demosaic_width; *out_height = demosaic_height;
+    return ipk_scale_down_opbuf(static_cast<float *>(full), width, height, demosaic_width, demosaic_height, dst4, stream);
+  }
+  *out_width = width; *out_height = height;                                                                // :57-59
+  return ipk_demosaic_full(src, width, height, cfa_pat, dst4, stream);
+}
+
+int ipk_rotatecrop(const float *src, size_t width, size_t height, size_t colors, const float *p, float *dst,
+                   size_t *out_width, size_t *out_height, void *stream) {
+  ipk::RotateCrop rc;
+  rc.crop_top = p[0]; rc.crop_right = p[1]; rc.crop_bottom = p[2]; rc.crop_left = p[3]; rc.rotation = p[4];
+  int64_t pts[6]; size_t nw, nh;
+  if (!rc.corners(width, height, pts, nw, nh)) { *out_width = width; *out_height = height; return IPK_NOOP; }
+  *out_width = nw; *out_height = nh;
+  if (!dst) return IPK_OK;
+  return ipk_transform_buffer_f32(src, width, height, pts[0], pts[1], pts[2], pts[3], pts[4], pts[5], nw, nh, colors, nullptr, dst, stream);
+}
+
+int ipk_tolab(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs,
+              const float *cam_to_xyz_normalized, float *dst3, void *stream) {
+  REQUIRE_INIT();
+  if (!src4 || !dst3 || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad tolab arguments");
+  float mul[4], cm[12];
+  if (monochrome) { ipk::srgb_d65_43(cm); mul[0] = mul[1] = mul[2] = mul[3] = 1.0f; }                     // colorspaces.rs:90-101
+  else { std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul); }
+  ipk::launch_tolab(src4, width * height, mul, cm, g.lut_pairs[ipk::kLutXyzLab], dst3, g.num_cus, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
+static int build_curve(float exposure, const float *points, int npoints, ipk::Spline &sp) {
+  if (npoints < 0 || npoints > 64) return fail(IPK_ERR_INVALID, "curve with %d points (max 64)", npoints);
+  float fp[128];
+  const float m = std::exp2(exposure);                                                                    // curves.rs:38-41
+  for (int i = 0; i < npoints; ++i) { fp[2 * i] = points[2 * i]; fp[2 * i + 1] = points[2 * i + 1] * m; }
+  if (!sp.build(fp, npoints)) return fail(IPK_ERR_INVALID, "degenerate curve");
+  return IPK_OK;
+}
+static bool curve_is_noop(float exposure, int npoints) { return npoints == 0 && std::fabs(exposure) < 0.001f; }   // curves.rs:34-36
+
+int ipk_basecurve(const float *src3, size_t width, size_t height, float exposure, const float *points, int npoints,
+                  float *dst3, void *stream) {
+  REQUIRE_INIT();
+  if (curve_is_noop(exposure, npoints)) return IPK_NOOP;
+  if (!src3 || !dst3 || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad basecurve arguments");
+  ipk::Spline sp; int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
+  ipk::launch_basecurve(src3, width * height, sp, dst3, g.num_cus, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+int ipk_fromlab(const float *src3, size_t width, size_t height, float *dst3, void *stream) {
+  REQUIRE_INIT();
+  if (!src3 || !dst3 || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad fromlab arguments");
+  ipk::launch_fromlab(src3, width * height, g.xyz_d65_33, dst3, g.num_cus, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+int ipk_gamma(const float *src, size_t width, size_t height, size_t colors, int linear, float *dst, void *stream) {
+  REQUIRE_INIT();
+  if (linear) return IPK_NOOP;                                                                             // gamma.rs:17-18
+  if (!src || !dst || !dims_ok(width, height) || colors < 1) return fail(IPK_ERR_INVALID, "bad gamma arguments");
+  ipk::launch_gamma(src, width * height * colors, g.lut_pairs[ipk::kLutGamma], dst, g.num_cus, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+int ipk_rotate_buffer(const float *src3, size_t bwidth, size_t bheight, int orientation, float *dst3,
+                      size_t *out_width, size_t *out_height, void *stream) {
+  REQUIRE_INIT();
+  if (!src3 || !dst3 || !dims_ok(bwidth, bheight)) return fail(IPK_ERR_INVALID, "bad rotate arguments");
+  bool transpose, flip_x, flip_y;
+  ipk::orientation_to_flips(orientation, transpose, flip_x, flip_y);
+  // transform.rs:102-128 in units of pixels
+  int64_t width = (int64_t)bwidth, height = (int64_t)bheight;
+  int64_t base = 0, x_step = 1, y_step = width;
+  if (flip_x) { x_step = -x_step; base += width - 1; }
+  if (flip_y) { y_step = -y_step; base += width * (height - 1); }
+  if (transpose) { std::swap(width, height); std::swap(x_step, y_step); }
+  *out_width = (size_t)width; *out_height = (size_t)height;
+  ipk::launch_rotate(src3, (size_t)width, (size_t)height, base, x_step, y_step, dst3, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+int ipk_transform(const float *src3, size_t width, size_t height, int rotation, int fliph, int flipv, float *dst3,
+                  size_t *out_width, size_t *out_height, void *stream) {
+  if (rotation < 0 || rotation > 3) return fail(IPK_ERR_INVALID, "bad rotation");
+  const int o = ipk::transform_orientation(rotation, fliph != 0, flipv != 0);
+  if (o == IPK_OR_NORMAL || o == IPK_OR_UNKNOWN) { *out_width = width; *out_height = height; return IPK_NOOP; }   // transform.rs:68-69
+  return ipk_rotate_buffer(src3, width, height, o, dst3, out_width, out_height, stream);
+}
+int ipk_output8bit(const float *src, size_t n, uint8_t *dst, void *stream) {
+  REQUIRE_INIT(); if (!src || !dst) return fail(IPK_ERR_INVALID, "null buffer");
+  ipk::launch_output8(src, n, dst, g.num_cus, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *stream) {
+  REQUIRE_INIT(); if (!src || !dst) return fail(IPK_ERR_INVALID, "null buffer");
+  ipk::launch_output16(src, n, dst, g.num_cus, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused raw -> sRGB
+// ------------------------------------------------------------------------------------------
+int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream) {
+  REQUIRE_INIT();
+  if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  if (p->src_type != IPK_SRC_U16 && p->src_type != IPK_SRC_F32) return fail(IPK_ERR_INVALID, "fused path takes u16 or f32 CFA data");
+  if (!dims_ok(p->width, p->height) || p->owidth < p->x + p->width) return fail(IPK_ERR_INVALID, "bad geometry");
+  if (p->out_type < 0 || p->out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  ipk::Cfa cfa;
+  if (!ipk::Cfa::parse(p->cfa, cfa) || !cfa.valid()) return fail(IPK_ERR_INVALID, "invalid CFA pattern");
+  int xoff, yoff;
+  if (!cfa.bayer_phase(xoff, yoff)) return fail(IPK_ERR_UNSUPPORTED, "CFA \"%s\" is not an RGGB-phase Bayer tile; run the staged ops", p->cfa);
+
+  ipk::FusedLaunch f;
+  const size_t esz = p->src_type == IPK_SRC_U16 ? 2 : 4;
+  const bool band = p->band_out_rows != 0;
+  f.row_off = band ? p->band_src_row0 : 0;
+  f.out_r0 = band ? p->band_out_row0 : 0;
+  f.out_r1 = band ? p->band_out_row0 + p->band_out_rows : p->height;
+  if (f.out_r1 > p->height || f.out_r0 >= f.out_r1) return fail(IPK_ERR_INVALID, "band rows outside the frame");
+  if (band) {
+    const size_t need0 = f.out_r0 > 0 ? f.out_r0 - 1 : 0, need1 = std::min(p->height, f.out_r1 + 1);
+    if (p->band_src_row0 > need0 || p->band_src_row0 + p->band_src_rows < need1)
+      return fail(IPK_ERR_INVALID, "band source rows do not cover the 1-row halo");
+  }
+  // whole frame: src is sensor element (0,0) -> skip the top crop; band: src already starts at sensor row y+band_src_row0
+  const char *base = static_cast<const char *>(src) + ((band ? 0 : p->y * p->owidth) + p->x) * esz;
+  f.src = base; f.dst = dst;
+  f.src_is_u16 = p->src_type == IPK_SRC_U16;
+  f.src_aligned4 = (reinterpret_cast<uintptr_t>(base) % 4 == 0) && (p->owidth % 2 == 0);
+  f.width = p->width; f.height = p->height; f.owidth = p->owidth;
+  f.black0 = p->black0; f.white0 = p->white0;
+  f.xoff = xoff; f.yoff = yoff;
+  float mul[4];
+  ipk::normalize_wbs(p->wb_coeffs, mul);                                                                   // colorspaces.rs:100
+  f.mul4 = mul; f.cm12 = p->cam_to_xyz_normalized; f.rgbm9 = g.xyz_d65_33;
+  ipk::Spline sp;
+  f.has_curve = !curve_is_noop(p->exposure, p->npoints);
+  if (f.has_curve) { int rc = build_curve(p->exposure, p->points, p->npoints, sp); if (rc) return rc; }
+  f.spline = &sp;
+  f.linear = p->linear;
+  f.out_type = p->out_type;
+  f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma];
+  f.num_cus = g.num_cus;
+  ipk::launch_fused_bayer(f, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pipeline::run (src/pipeline.rs:311-375) for one source, cache == None
+// ------------------------------------------------------------------------------------------
+int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h, size_t *final_w, size_t *final_h) {
+  if (!d) return fail(IPK_ERR_INVALID, "null descriptor");
+  if (d->rotation < 0 || d->rotation > 3) return fail(IPK_ERR_INVALID, "bad rotation");
+  ipk::RotateCrop rc;                                                     // reset() state (pipeline.rs:314-316)
+  rc.crop_top = d->rotatecrop[0]; rc.crop_right = d->rotatecrop[1]; rc.crop_bottom = d->rotatecrop[2];
+  rc.crop_left = d->rotatecrop[3]; rc.rotation = d->rotatecrop[4];
+  ipk::Rect r;
+  if (!ipk::size_image(d->crop_top, d->crop_right, d->crop_bottom, d->crop_left, d->width, d->height, r))
+    return fail(IPK_ERR_INVALID, "source smaller than 10x10");
+  size_t w = r.width, h = r.height;
+  rc.transform_forward(w, h, w, h);                                       // forward fold (pipeline.rs:318-324)
+  ipk::transform_forward(d->rotation, w, h, w, h);
+  const ipk::Scaling s = ipk::calculate_scaling_total(w, h, d->maxwidth, d->maxheight);   // :328-329
+  w = s.width; h = s.height;
+  *final_w = w; *final_h = h;
+  ipk::transform_forward(d->rotation, w, h, w, h);                        // reverse fold (:331-335)
+  rc.transform_reverse(w, h, w, h);
+  *demosaic_w = w; *demosaic_h = h;
+  return IPK_OK;
+}
+
+int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused, void *stream) {
+  REQUIRE_INIT();
+  if (!d || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  size_t dw, dh, fw, fh;
+  int rc = ipk_pipeline_sizes(d, &dw, &dh, &fw, &fh); if (rc) return rc;
+  // output_8bit forces linear=false (pipeline.rs:405), output_16bit linear=true (:452)
+  const int linear = out_type == IPK_OUT_U8 ? 0 : (out_type == IPK_OUT_U16 ? 1 : d->linear);
+  ipk::Rect r;
+  ipk::size_image(d->crop_top, d->crop_right, d->crop_bottom, d->crop_left, d->width, d->height, r);
+  const bool raw = d->src_type == IPK_SRC_U16 || d->src_type == IPK_SRC_F32;
+  const bool cfa_branch = raw && !(d->cpp == 1 && !d->is_cfa) && d->cpp != 3;          // gofloat.rs:95,109,121
+  const int orientation = ipk::transform_orientation(d->rotation, d->fliph != 0, d->flipv != 0);
+  const bool transform_noop = orientation == IPK_OR_NORMAL || orientation == IPK_OR_UNKNOWN;
+  ipk::RotateCrop rcop;
+  rcop.crop_top = d->rotatecrop[0]; rcop.crop_right = d->rotatecrop[1]; rcop.crop_bottom = d->rotatecrop[2];
+  rcop.crop_left = d->rotatecrop[3]; rcop.rotation = d->rotatecrop[4];
+
+  // ---- fused path: legal when every op between gofloat and gamma is point-wise or demosaic::full ----
+  if (used_fused) *used_fused = 0;
+  if (d->allow_fused && cfa_branch && d->cpp == 1 && rcop.noop() && transform_noop) {
+    const float scale = ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale;
+    ipk::Cfa cfa; int xo, yo;
+    if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && cfa.bayer_phase(xo, yo)) {
+      ipk_fused_params fp;
+      std::memset(&fp, 0, sizeof(fp));
+      fp.src_type = d->src_type; fp.owidth = d->width; fp.x = r.x; fp.y = r.y; fp.width = r.width; fp.height = r.height;
+      fp.black0 = d->blacklevels[0]; fp.white0 = d->whitelevels[0];
+      std::memcpy(fp.cfa, d->cfa, sizeof(fp.cfa));
+      std::memcpy(fp.wb_coeffs, d->wb_coeffs, sizeof(fp.wb_coeffs));
+      std::memcpy(fp.cam_to_xyz_normalized, d->cam_to_xyz_normalized, sizeof(fp.cam_to_xyz_normalized));
+      fp.exposure = d->exposure; fp.npoints = d->npoints; std::memcpy(fp.points, d->points, sizeof(fp.points));
+      fp.linear = linear; fp.out_type = out_type;
+      rc = ipk_raw_to_srgb(&fp, src, dst, stream);
+      if (rc == IPK_OK && used_fused) *used_fused = 1;
+      return rc;
+    }
+  }
+
+  // ---- staged path: the eight ops in the reference's order (pipeline.rs:155-164) ----
+  Scratch sc;
+  hipStream_t st = S(stream); (void)st;
+  size_t w = r.width, h = r.height, colors;
+  int monochrome = 0;
+  void *buf = nullptr;
+  // gofloat
+  if (raw) {
+    if (d->cpp == 1 && !d->is_cfa) {
+      colors = 4; monochrome = 1;
+      rc = sc.get(w * h * 4 * sizeof(float), &buf); if (rc) return rc;
+      rc = d->src_type == IPK_SRC_U16
+        ? ipk_gofloat_mono_u16(static_cast<const uint16_t *>(src), d->width, r.x, r.y, w, h, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(buf), stream)
+        : ipk_gofloat_mono_f32(static_cast<const float *>(src), d->width, r.x, r.y, w, h, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(buf), stream);
+    } else if (d->cpp == 3) {
+      colors = 4;
+      rc = sc.get(w * h * 4 * sizeof(float), &buf); if (rc) return rc;
+      rc = d->src_type == IPK_SRC_U16
+        ? ipk_gofloat_rgb_u16(static_cast<const uint16_t *>(src), d->width, r.x, r.y, w, h, d->blacklevels, d->whitelevels, static_cast<float *>(buf), stream)
+        : ipk_gofloat_rgb_f32(static_cast<const float *>(src), d->width, r.x, r.y, w, h, d->blacklevels, d->whitelevels, static_cast<float *>(buf), stream);
+    } else {
+      if (d->cpp != 1) return fail(IPK_ERR_UNSUPPORTED, "cpp=%d sources are not supported", d->cpp);
+      colors = 1;
+      rc = sc.get(w * h * sizeof(float), &buf); if (rc) return rc;
+      rc = d->src_type == IPK_SRC_U16
+        ? ipk_gofloat_cfa_u16(static_cast<const uint16_t *>(src), d->width, r.x, r.y, w, h, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(buf), stream)
+        : ipk_gofloat_cfa_f32(static_cast<const float *>(src), d->width, r.x, r.y, w, h, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(buf), stream);
+    }
+  } else {
+    colors = 4;
+    rc = sc.get(w * h * 4 * sizeof(float), &buf); if (rc) return rc;
+    rc = d->src_type == IPK_SRC_RGB8
+      ? ipk_gofloat_other_u8(static_cast<const uint8_t *>(src), d->width, r.x, r.y, w, h, static_cast<float *>(buf), stream)
+      : ipk_gofloat_other_u16(static_cast<const uint16_t *>(src), d->width, r.x, r.y, w, h, static_cast<float *>(buf), stream);
+  }
+  if (rc < 0) return rc;
+  // demosaic
+  {
+    void *o = nullptr; size_t ow, oh;
+    rc = sc.get(std::max(w * h, dw * dh) * 4 * sizeof(float), &o); if (rc) return rc;
+    rc = ipk_demosaic_run(static_cast<const float *>(buf), w, h, colors, d->cfa, dw, dh, static_cast<float *>(o), &ow, &oh, stream);
+    if (rc < 0) return rc;
+    if (rc == IPK_NOOP) sc.release(o); else { sc.release(buf); buf = o; w = ow; h = oh; colors = 4; }
+  }
+  // rotatecrop
+  {
+    size_t ow, oh;
+    rc = ipk_rotatecrop(static_cast<const float *>(buf), w, h, colors, d->rotatecrop, nullptr, &ow, &oh, stream);
+    if (rc < 0) return rc;
+    if (rc != IPK_NOOP) {
+      void *o = nullptr;
+      rc = sc.get(ow * oh * colors * sizeof(float), &o); if (rc) return rc;
+      rc = ipk_rotatecrop(static_cast<const float *>(buf), w, h, colors, d->rotatecrop, static_cast<float *>(o), &ow, &oh, stream);
+      if (rc < 0) return rc;
+      sc.release(buf); buf = o; w = ow; h = oh;
+    }
+  }
+  // tolab
+  {
+    void *o = nullptr;
+    rc = sc.get(w * h * 3 * sizeof(float), &o); if (rc) return rc;
+    rc = ipk_tolab(static_cast<const float *>(buf), w, h, monochrome, d->wb_coeffs, d->cam_to_xyz_normalized, static_cast<float *>(o), stream);
+    if (rc < 0) return rc;
+    sc.release(buf); buf = o; colors = 3;
+  }
+  const size_t n3 = w * h * 3 * sizeof(float);
+  // basecurve
+  {
+    void *o = nullptr;
+    rc = sc.get(n3, &o); if (rc) return rc;
+    rc = ipk_basecurve(static_cast<const float *>(buf), w, h, d->exposure, d->points, d->npoints, static_cast<float *>(o), stream);
+    if (rc < 0) return rc;
+    if (rc == IPK_NOOP) sc.release(o); else { sc.release(buf); buf = o; }
+  }
+  // the last f32 stage writes straight into dst when the caller wants f32
+  const bool gamma_runs = !linear;
+  const bool f32_out = out_type == IPK_OUT_F32;
+  // fromlab
+  {
+    void *o = nullptr;
+    const bool last = f32_out && !gamma_runs && transform_noop;
+    if (last) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }
+    rc = ipk_fromlab(static_cast<const float *>(buf), w, h, static_cast<float *>(o), stream);
+    if (rc < 0) return rc;
+    sc.release(buf); buf = o;
+  }
+  // gamma
+  if (gamma_runs) {
+    void *o = nullptr;
+    const bool last = f32_out && transform_noop;
+    if (last) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }
+    rc = ipk_gamma(static_cast<const float *>(buf), w, h, 3, 0, static_cast<float *>(o), stream);
+    if (rc < 0) return rc;
+    sc.release(buf); buf = o;
+  }
+  // transform
+  if (!transform_noop) {
+    void *o = nullptr; size_t ow, oh;
+    if (f32_out) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }
+    rc = ipk_rotate_buffer(static_cast<const float *>(buf), w, h, orientation, static_cast<float *>(o), &ow, &oh, stream);
+    if (rc < 0) return rc;
+    sc.release(buf); buf = o; w = ow; h = oh;
+  }
+  if (w != fw || h != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", w, h, fw, fh);
+  // quantise (pipeline.rs:408-414 / :455-461)
+  if (out_type == IPK_OUT_U8) rc = ipk_output8bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint8_t *>(dst), stream);
+  else if (out_type == IPK_OUT_U16) rc = ipk_output16bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint16_t *>(dst), stream);
+  else rc = IPK_OK;
+  return rc < 0 ? rc : IPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-pointer forms
+// ------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? IPK_OK : fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes); }
+  int upload(const void *h, size_t bytes) { int rc = alloc(bytes); if (rc) return rc; HIPCHK(hipMemcpy(p, h, bytes, hipMemcpyHostToDevice)); return IPK_OK; }
+  int download(void *h, size_t bytes) { HIPCHK(hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost)); return IPK_OK; }
+};
+size_t src_elem_size(int t) { return t == IPK_SRC_U16 ? 2 : t == IPK_SRC_F32 ? 4 : t == IPK_SRC_RGB8 ? 1 : 2; }
+size_t out_elem_size(int t) { return t == IPK_OUT_F32 ? 4 : t == IPK_OUT_U8 ? 1 : 2; }
+}  // namespace
+
+#define HOST_TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
+
+int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused) {
+  REQUIRE_INIT();
+  if (!d || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  size_t dw, dh, fw, fh;
+  HOST_TRY(ipk_pipeline_sizes(d, &dw, &dh, &fw, &fh));
+  const bool raw = d->src_type == IPK_SRC_U16 || d->src_type == IPK_SRC_F32;
+  const size_t in_bytes = d->width * d->height * (raw ? (size_t)d->cpp : 3) * src_elem_size(d->src_type);
+  const size_t out_bytes = fw * fh * 3 * out_elem_size(out_type);
+  DevBuf a, b;
+  HOST_TRY(a.upload(src, in_bytes));
+  HOST_TRY(b.alloc(out_bytes));
+  HOST_TRY(ipk_pipeline_run(d, a.p, b.p, out_type, used_fused, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return b.download(dst, out_bytes);
+}
+int ipk_host_gofloat_cfa_u16(const uint16_t *src, size_t owidth, size_t oheight, size_t x, size_t y, size_t width, size_t height,
+                             float black0, float white0, float *dst) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src, owidth * oheight * 2)); HOST_TRY(b.alloc(width * height * 4));
+  HOST_TRY(ipk_gofloat_cfa_u16(static_cast<const uint16_t *>(a.p), owidth, x, y, width, height, black0, white0, static_cast<float *>(b.p), nullptr));
+  return b.download(dst, width * height * 4);
+}
+int ipk_host_gofloat_cfa_f32(const float *src, size_t owidth, size_t oheight, size_t x, size_t y, size_t width, size_t height,
+                             float black0, float white0, float *dst) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src, owidth * oheight * 4)); HOST_TRY(b.alloc(width * height * 4));
+  HOST_TRY(ipk_gofloat_cfa_f32(static_cast<const float *>(a.p), owidth, x, y, width, height, black0, white0, static_cast<float *>(b.p), nullptr));
+  return b.download(dst, width * height * 4);
+}
+int ipk_host_demosaic_full(const float *src, size_t width, size_t height, const char *cfa, float *dst4) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src, width * height * 4)); HOST_TRY(b.alloc(width * height * 16));
+  HOST_TRY(ipk_demosaic_full(static_cast<const float *>(a.p), width, height, cfa, static_cast<float *>(b.p), nullptr));
+  return b.download(dst4, width * height * 16);
+}
+int ipk_host_transform_buffer_f32(const float *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
+                                  int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components, const char *cfa, float *dst) {
+  REQUIRE_INIT(); DevBuf a, b;
+  const size_t in_comps = cfa ? 1 : components;
+  HOST_TRY(a.upload(src, width * height * in_comps * 4)); HOST_TRY(b.alloc(nwidth * nheight * components * 4));
+  HOST_TRY(ipk_transform_buffer_f32(static_cast<const float *>(a.p), width, height, tlx, tly, trx, try_, blx, bly, nwidth, nheight, components, cfa,
+                                    static_cast<float *>(b.p), nullptr));
+  return b.download(dst, nwidth * nheight * components * 4);
+}
+int ipk_host_tolab(const float *src4, size_t width, size_t height, int monochrome, const float *wb, const float *cm, float *dst3) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src4, width * height * 16)); HOST_TRY(b.alloc(width * height * 12));
+  HOST_TRY(ipk_tolab(static_cast<const float *>(a.p), width, height, monochrome, wb, cm, static_cast<float *>(b.p), nullptr));
+  return b.download(dst3, width * height * 12);
+}
+int ipk_host_basecurve(const float *src3, size_t width, size_t height, float exposure, const float *points, int npoints, float *dst3) {
+  REQUIRE_INIT();
+  if (curve_is_noop(exposure, npoints)) return IPK_NOOP;
+  DevBuf a, b;
+  HOST_TRY(a.upload(src3, width * height * 12)); HOST_TRY(b.alloc(width * height * 12));
+  HOST_TRY(ipk_basecurve(static_cast<const float *>(a.p), width, height, exposure, points, npoints, static_cast<float *>(b.p), nullptr));
+  return b.download(dst3, width * height * 12);
+}
+int ipk_host_fromlab(const float *src3, size_t width, size_t height, float *dst3) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src3, width * height * 12)); HOST_TRY(b.alloc(width * height * 12));
+  HOST_TRY(ipk_fromlab(static_cast<const float *>(a.p), width, height, static_cast<float *>(b.p), nullptr));
+  return b.download(dst3, width * height * 12);
+}
+int ipk_host_gamma(const float *src, size_t width, size_t height, size_t colors, int linear, float *dst) {
+  REQUIRE_INIT();
+  if (linear) return IPK_NOOP;
+  DevBuf a, b;
+  const size_t bytes = width * height * colors * 4;
+  HOST_TRY(a.upload(src, bytes)); HOST_TRY(b.alloc(bytes));
+  HOST_TRY(ipk_gamma(static_cast<const float *>(a.p), width, height, colors, 0, static_cast<float *>(b.p), nullptr));
+  return b.download(dst, bytes);
+}
+int ipk_host_rotate_buffer(const float *src3, size_t width, size_t height, int orientation, float *dst3, size_t *ow, size_t *oh) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src3, width * height * 12)); HOST_TRY(b.alloc(width * height * 12));
+  HOST_TRY(ipk_rotate_buffer(static_cast<const float *>(a.p), width, height, orientation, static_cast<float *>(b.p), ow, oh, nullptr));
+  return b.download(dst3, width * height * 12);
+}
+int ipk_host_output8bit(const float *src, size_t n, uint8_t *dst) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src, n * 4)); HOST_TRY(b.alloc(n));
+  HOST_TRY(ipk_output8bit(static_cast<const float *>(a.p), n, static_cast<uint8_t *>(b.p), nullptr));
+  return b.download(dst, n);
+}
+int ipk_host_output16bit(const float *src, size_t n, uint16_t *dst) {
+  REQUIRE_INIT(); DevBuf a, b;
+  HOST_TRY(a.upload(src, n * 4)); HOST_TRY(b.alloc(n * 2));
+  HOST_TRY(ipk_output16bit(static_cast<const float *>(a.p), n, static_cast<uint16_t *>(b.p), nullptr));
+  return b.download(dst, n * 2);
+}
+int ipk_host_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst) {
+  REQUIRE_INIT();
+  if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  const size_t esz = p->src_type == IPK_SRC_U16 ? 2 : 4;
+  const bool band = p->band_out_rows != 0;
+  const size_t src_rows = band ? p->band_src_rows : p->y + p->height;
+  const size_t out_rows = band ? p->band_out_rows : p->height;
+  DevBuf a, b;
+  HOST_TRY(a.upload(src, src_rows * p->owidth * esz));
+  HOST_TRY(b.alloc(out_rows * p->width * 3 * out_elem_size(p->out_type)));
+  HOST_TRY(ipk_raw_to_srgb(p, a.p, b.p, nullptr));
+  return b.download(dst, out_rows * p->width * 3 * out_elem_size(p->out_type));
+}
+
+}  // extern "C"

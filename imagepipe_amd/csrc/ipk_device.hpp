@@ -1,0 +1,198 @@
+// ipk_device.hpp -- per-pixel device functions shared by the staged and fused gfx950 kernels.
+//
+// Bit-exactness contract (SURVEY.md section 7 "hard parts"): every function evaluates the same
+// IEEE binary32 operations in the same order as the reference's Rust.  The translation unit is
+// compiled with -ffp-contract=off (no FMA contraction), without fast-math, with IEEE division
+// (hipcc default) and f32 denormals enabled (gfx9 default).  Reference citations are file:line
+// in pedrocr/imagepipe 0.5.0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ipkd {
+
+// One TransformLookup entry as the kernels hold it in LDS: {table[i], table[i+1]-table[i]}.
+// The difference is the same f32 subtraction lookup() performs (src/color_conversions.rs:112),
+// hoisted to table-build time, so one 8-byte ds_read_b64 feeds the whole interpolation.
+typedef float2 LutPair;
+constexpr int kLutPairs = 8192;          // keys 0..=8191 (pos = val*8191, val in [0,1])
+constexpr float kLutMaxF = 8191.0f;
+
+// D65 white (src/color_conversions.rs:7)
+constexpr float kWhiteX = 0.95047f, kWhiteY = 1.000f, kWhiteZ = 1.08883f;
+// e and k of the CIE Lab transfer (src/color_conversions.rs:121-122, :181-182), f32 divisions
+constexpr float kLabE = 216.0f / 24389.0f;
+constexpr float kLabK = 24389.0f / 27.0f;
+
+// ---- Rust float semantics ------------------------------------------------------------------
+// f32::min/max ignore a NaN operand == IEEE minNum/maxNum == fminf/fmaxf (v_min_f32/v_max_f32).
+__device__ __forceinline__ float rs_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float rs_max(float a, float b) { return fmaxf(a, b); }
+// `f as usize` clamped to a 32-bit range (callers min() it with a dimension < 2^31 afterwards):
+// v_cvt_u32_f32 saturates, maps NaN and negatives to 0.
+__device__ __forceinline__ uint32_t f32_as_u32_sat(float f) { return __float2uint_rz(f); }
+
+// ---- TransformLookup::lookup table branch (src/color_conversions.rs:106-112) ---------------
+// Precondition: !(val < 0 || val > 1)  (NaN takes this branch too, as in the reference: key 0,
+// a = NaN -> NaN).
+__device__ __forceinline__ float lut_interp(const LutPair *__restrict__ tab, float val) {
+  const float pos = val * kLutMaxF;
+  const uint32_t key = f32_as_u32_sat(pos);
+  const float base = truncf(pos);
+  const float a = pos - base;
+  const LutPair p = tab[key];
+  return p.x + a * p.y;
+}
+
+// ---- cbrtf, bit-identical to glibc 2.35 sysdeps/ieee754/flt-32/s_cbrtf.c -------------------
+// Rust's f32::cbrt is the platform libm's cbrtf; XYZ_LAB_TRANSFORM calls it at run time for
+// ratios > 1 (src/color_conversions.rs:103-104,123).  glibc's routine is not correctly rounded, so
+// the kernel reproduces its arithmetic (frexp, a degree-2 polynomial and one Halley step in
+// double, ldexp) rather than calling a different cbrt.  tests/test_gpu_cbrt.py checks it against
+// the host libm over every f32 in (1, 2^64].  Called only with x > 1 (finite or +inf).
+__device__ __forceinline__ float cbrtf_glibc(float x) {
+  if (__builtin_isinf(x)) return x;
+  int xe;
+  const float xm = frexpf(x, &xe);                       // xm in [0.5, 1)
+  const double dxm = (double)xm;
+  const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * dxm) * dxm);
+  const float t2 = u * u * u;
+  const int rem = xe % 3;                                // xe >= 1 here
+  const double factor = rem == 0 ? 1.0 : (rem == 1 ? 1.2599210498948731647672 : 1.5874010519681994747517);
+  const float ym = (float)((double)u * ((double)t2 + 2.0 * dxm) / (2.0 * (double)t2 + dxm) * factor);
+  return ldexpf(ym, xe / 3);
+}
+
+// XYZ_LAB_TRANSFORM.lookup (src/color_conversions.rs:102-114 with the closure of :120-124)
+__device__ __forceinline__ float lab_lookup(const LutPair *__restrict__ lab, float v) {
+  if (v < 0.0f || v > 1.0f) {
+    if (v > kLabE) return cbrtf_glibc(v);                // only v > 1 reaches here
+    return (kLabK * v + 16.0f) / 116.0f;                 // v < 0
+  }
+  return lut_interp(lab, v);
+}
+
+// xyz_to_lab (src/color_conversions.rs:156-169)
+__device__ __forceinline__ void xyz_to_lab(const LutPair *__restrict__ lab, float x, float y, float z,
+                                           float &ol, float &oa, float &ob) {
+  const float xr = x / kWhiteX, yr = y / kWhiteY, zr = z / kWhiteZ;
+  const float fx = lab_lookup(lab, xr);
+  const float fy = lab_lookup(lab, yr);
+  const float fz = lab_lookup(lab, zr);
+  const float l = 116.0f * fy - 16.0f;
+  const float a = 500.0f * (fx - fy);
+  const float b = 200.0f * (fy - fz);
+  ol = l / 100.0f; oa = (a + 127.0f) / 255.0f; ob = (b + 127.0f) / 255.0f;
+}
+
+// lab_to_xyz (src/color_conversions.rs:172-191)
+__device__ __forceinline__ void lab_to_xyz(float l, float a, float b, float &ox, float &oy, float &oz) {
+  const float cl = l * 100.0f;
+  const float ca = (a * 255.0f) - 127.0f;
+  const float cb = (b * 255.0f) - 127.0f;
+  const float fy = (cl + 16.0f) / 116.0f;
+  const float fx = ca / 500.0f + fy;
+  const float fz = fy - (cb / 200.0f);
+  const float fx3 = fx * fx * fx;
+  const float xr = (fx3 > kLabE) ? fx3 : (116.0f * fx - 16.0f) / kLabK;
+  const float yr = (cl > kLabK * kLabE) ? fy * fy * fy : cl / kLabK;
+  const float fz3 = fz * fz * fz;
+  const float zr = (fz3 > kLabE) ? fz3 : (116.0f * fz - 16.0f) / kLabK;
+  ox = xr * kWhiteX; oy = yr * kWhiteY; oz = zr * kWhiteZ;
+}
+
+// camera_to_lab (src/color_conversions.rs:42-55); cm = [[f32;4];3] row-major
+struct ToLabParams { float mul[4]; float cm[12]; };
+__device__ __forceinline__ void camera_to_lab(const LutPair *__restrict__ lab, const ToLabParams &p,
+                                              float p0, float p1, float p2, float p3,
+                                              float &ol, float &oa, float &ob) {
+  const float r = rs_min(p0 * p.mul[0], 1.0f);
+  const float g = rs_min(p1 * p.mul[1], 1.0f);
+  const float b = rs_min(p2 * p.mul[2], 1.0f);
+  const float e = rs_min(p3 * p.mul[3], 1.0f);
+  const float x = r * p.cm[0] + g * p.cm[1] + b * p.cm[2] + e * p.cm[3];
+  const float y = r * p.cm[4] + g * p.cm[5] + b * p.cm[6] + e * p.cm[7];
+  const float z = r * p.cm[8] + g * p.cm[9] + b * p.cm[10] + e * p.cm[11];
+  xyz_to_lab(lab, x, y, z, ol, oa, ob);
+}
+
+// lab_to_rgb (src/color_conversions.rs:58-65); m = XYZ_D65_33 row-major
+struct Mat9 { float m[9]; };
+__device__ __forceinline__ void lab_to_rgb(const Mat9 &mm, float l, float a, float b, float &orr, float &og, float &ob) {
+  float x, y, z;
+  lab_to_xyz(l, a, b, x, y, z);
+  orr = x * mm.m[0] + y * mm.m[1] + z * mm.m[2];
+  og  = x * mm.m[3] + y * mm.m[4] + z * mm.m[5];
+  ob  = x * mm.m[6] + y * mm.m[7] + z * mm.m[8];
+}
+
+// OpGamma's per-sample step (src/ops/gamma.rs:22): apply_srgb_gamma(v.max(0).min(1)); the clamp makes
+// the out-of-table branch of lookup unreachable.
+__device__ __forceinline__ float gamma_sample(const LutPair *__restrict__ gam, float v) {
+  return lut_interp(gam, rs_min(rs_max(v, 0.0f), 1.0f));
+}
+
+// output8bit / output16bit (src/color_conversions.rs:323-330)
+__device__ __forceinline__ uint8_t output8bit(float v) {
+  return (uint8_t)f32_as_u32_sat(rs_min(rs_max(v * 256.0f, 0.0f), 255.0f));
+}
+__device__ __forceinline__ uint16_t output16bit(float v) {
+  return (uint16_t)f32_as_u32_sat(rs_min(rs_max(roundf(v * 65535.0f), 0.0f), 65535.0f));
+}
+// input8bit / input16bit (src/color_conversions.rs:313-320)
+__device__ __forceinline__ float input8bit(uint8_t v) { return (float)v / 255.0f; }
+__device__ __forceinline__ float input16bit(uint16_t v) { return (float)v / 65535.0f; }
+
+// ---- SplineFunc::interpolate (src/ops/curves.rs:126-157) -----------------------------------
+constexpr int kSplineMaxKnots = 66;
+struct SplineDev {
+  int npoints, nseg;
+  float px[kSplineMaxKnots], py[kSplineMaxKnots], c1[kSplineMaxKnots], c2[kSplineMaxKnots], c3[kSplineMaxKnots];
+};
+__device__ __forceinline__ float spline_poly(float y, float c1, float c2, float c3, float diff) {
+  // self.points[i].1 + self.c1s[i]*diff + self.c2s[i]*diff*diff + self.c3s[i]*diff*diff*diff  (:156)
+  return y + c1 * diff + c2 * diff * diff + c3 * diff * diff * diff;
+}
+// Literal restatement, any knot count.  `s` lives in the kernel-argument segment (uniform loads for
+// the ends, per-lane loads inside the search).
+__device__ __forceinline__ float spline_interpolate(const SplineDev &s, float val) {
+  const int np = s.npoints;
+  if (np == 2) {
+    // unrolled for the 2-knot curve (no user points): search range 0..=0
+    if (val >= s.px[1]) return s.py[1];
+    if (!(val > s.px[0])) return s.py[0];              // val <= first, or NaN (returns points[mid=0].1)
+    return spline_poly(s.py[0], s.c1[0], s.c2[0], s.c3[0], val - s.px[0]);
+  }
+  if (np == 3) {
+    // unrolled for the 3-knot curve (the default raw base curve, curves.rs:18): search range 0..=1,
+    // first probe mid=0 always moves low to 1 (val > px[0] here), second probe mid=1 decides.
+    if (val >= s.px[2]) return s.py[2];
+    if (!(val > s.px[0])) return s.py[0];              // val <= first, or NaN (points[mid=0].1)
+    const float x1 = s.px[1];
+    if (x1 < val) return spline_poly(s.py[1], s.c1[1], s.c2[1], s.c3[1], val - x1);
+    if (x1 > val) return spline_poly(s.py[0], s.c1[0], s.c2[0], s.c3[0], val - s.px[0]);
+    return s.py[1];
+  }
+  if (val >= s.px[np - 1]) return s.py[np - 1];
+  if (val <= s.px[0]) return s.py[0];
+  int low = 0, high = s.nseg - 1;
+  while (low <= high) {
+    const int mid = (low + high) / 2;
+    const float xhere = s.px[mid];
+    if (xhere < val) low = mid + 1;
+    else if (xhere > val) high = mid - 1;
+    else return s.py[mid];                               // also NaN
+  }
+  const int i = high > 0 ? high : 0;
+  return spline_poly(s.py[i], s.c1[i], s.c2[i], s.c3[i], val - s.px[i]);
+}
+
+// ---- LDS table staging ---------------------------------------------------------------------
+__device__ __forceinline__ void load_lut_pairs(LutPair *__restrict__ lds, const LutPair *__restrict__ g) {
+  // 8192 pairs = 4096 float4; all threads of the block cooperate, 16 B per lane per step
+  const float4 *src = reinterpret_cast<const float4 *>(g);
+  float4 *dst = reinterpret_cast<float4 *>(lds);
+  for (int i = threadIdx.x; i < kLutPairs / 2; i += blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace ipkd

@@ -1,0 +1,329 @@
+// ipk_host.hpp -- host-side (CPU, once-per-op) maths of the hot path: everything the reference
+// computes outside its per-pixel loops and that decides kernel parameters or buffer sizes.
+// Citations are file:line in the reference (pedrocr/imagepipe 0.5.0).
+//
+// Compiled with -ffp-contract=off: Rust evaluates f32 expressions left to right without FMA
+// contraction, and these values (spline coefficients, matrices, sizes) feed bit-exact kernels.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace ipk {
+
+// ---- Rust `as` casts ---------------------------------------------------------------------
+inline size_t f32_to_usize(float f) {            // saturating, NaN -> 0
+  if (!(f > 0.0f)) return 0;
+  if (f >= 18446744073709551616.0f) return std::numeric_limits<size_t>::max();
+  return static_cast<size_t>(f);
+}
+inline int64_t f32_to_isize(float f) {
+  if (f != f) return 0;
+  if (f >= 9223372036854775808.0f) return std::numeric_limits<int64_t>::max();
+  if (f <= -9223372036854775808.0f) return std::numeric_limits<int64_t>::min();
+  return static_cast<int64_t>(f);
+}
+
+// ---- colour constants (src/color_conversions.rs:1-39) -------------------------------------
+struct Mat33 { float m[3][3]; };
+inline Mat33 srgb_d65_33() {
+  return Mat33{{{0.4124564f, 0.3575761f, 0.1804375f},
+                {0.2126729f, 0.7151522f, 0.0721750f},
+                {0.0193339f, 0.1191920f, 0.9503041f}}};
+}
+// cofactor inverse in f32 (src/color_conversions.rs:20-39); XYZ_D65_33 = inverse(SRGB_D65_33)
+inline Mat33 inverse(const Mat33 &a) {
+  const auto &i = a.m;
+  const float invdet = 1.0f / (i[0][0] * (i[1][1] * i[2][2] - i[2][1] * i[1][2]) -
+                               i[0][1] * (i[1][0] * i[2][2] - i[1][2] * i[2][0]) +
+                               i[0][2] * (i[1][0] * i[2][1] - i[1][1] * i[2][0]));
+  Mat33 o;
+  o.m[0][0] =  (i[1][1] * i[2][2] - i[2][1] * i[1][2]) * invdet;
+  o.m[0][1] = -(i[0][1] * i[2][2] - i[0][2] * i[2][1]) * invdet;
+  o.m[0][2] =  (i[0][1] * i[1][2] - i[0][2] * i[1][1]) * invdet;
+  o.m[1][0] = -(i[1][0] * i[2][2] - i[1][2] * i[2][0]) * invdet;
+  o.m[1][1] =  (i[0][0] * i[2][2] - i[0][2] * i[2][0]) * invdet;
+  o.m[1][2] = -(i[0][0] * i[1][2] - i[1][0] * i[0][2]) * invdet;
+  o.m[2][0] =  (i[1][0] * i[2][1] - i[2][0] * i[1][1]) * invdet;
+  o.m[2][1] = -(i[0][0] * i[2][1] - i[2][0] * i[0][1]) * invdet;
+  o.m[2][2] =  (i[0][0] * i[1][1] - i[1][0] * i[0][1]) * invdet;
+  return o;
+}
+// SRGB_D65_43 (src/color_conversions.rs:12-16), [[f32;4];3] row-major
+inline void srgb_d65_43(float out[12]) {
+  const Mat33 s = srgb_d65_33();
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) out[r * 4 + c] = s.m[r][c]; out[r * 4 + 3] = 0.0f; }
+}
+
+// ---- TransformLookup tables (src/color_conversions.rs:80-141) ------------------------------
+constexpr int kLutMax = (1 << 13) - 1;   // 8191
+constexpr int kLutLen = kLutMax + 2;     // 8193
+enum LutId { kLutXyzLab = 0, kLutGammaReverse = 1, kLutGamma = 2 };
+
+inline float lab_transform(float v) {            // :120-124
+  const float e = 216.0f / 24389.0f, k = 24389.0f / 27.0f;
+  return v > e ? std::cbrt(v) : (k * v + 16.0f) / 116.0f;
+}
+inline float gamma_reverse_transform(float v) {  // :126-132
+  return v < 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+}
+inline float gamma_transform(float v) {          // :134-140
+  return v < 0.0031308f ? v * 12.92f : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+}
+inline std::vector<float> build_lut(LutId id) {  // TransformLookup::new :87-100
+  std::vector<float> t(kLutLen);
+  for (int i = 0; i <= kLutMax + 1; ++i) {
+    const float v = static_cast<float>(i) / static_cast<float>(kLutMax);
+    t[i] = id == kLutXyzLab ? lab_transform(v) : id == kLutGammaReverse ? gamma_reverse_transform(v) : gamma_transform(v);
+  }
+  return t;
+}
+
+// ---- rawloader CFA (absent dependency; restated -- see DESIGN.md "unpinned") ---------------
+struct Cfa {
+  int width = 0, height = 0;
+  uint8_t pattern[48][48] = {};
+  bool valid() const { return width > 0; }
+  int color_at(size_t row, size_t col) const { return pattern[(row + 48) % 48][(col + 48) % 48]; }
+  // CFA::new(patname)
+  static bool parse(const char *pat, Cfa &out) {
+    const size_t len = pat ? std::strlen(pat) : 0;
+    out = Cfa();
+    switch (len) {
+      case 0: return true;
+      case 4: out.width = 2; out.height = 2; break;
+      case 36: out.width = 6; out.height = 6; break;
+      case 16: out.width = 8; out.height = 2; break;
+      case 144: out.width = 12; out.height = 12; break;
+      default: return false;
+    }
+    for (size_t i = 0; i < len; ++i) {
+      uint8_t v;
+      switch (pat[i]) {
+        case 'R': v = 0; break; case 'G': v = 1; break; case 'B': v = 2; break; case 'E': v = 3; break;
+        case 'M': v = 1; break; case 'Y': v = 3; break;
+        default: return false;
+      }
+      out.pattern[i / out.width][i % out.width] = v;
+    }
+    for (int r = 0; r < 48; ++r)
+      for (int c = 0; c < 48; ++c) out.pattern[r][c] = out.pattern[r % out.height][c % out.width];
+    return true;
+  }
+  // CFA::shift(x, y) as used by cropped_cfa()
+  std::string shifted_name(int x, int y) const {
+    static const char names[4] = {'R', 'G', 'B', 'E'};
+    std::string s;
+    for (int r = 0; r < height; ++r)
+      for (int c = 0; c < width; ++c) s.push_back(names[color_at(size_t(r + y), size_t(c + x))]);
+    return s;
+  }
+  // The per-pixel tap colours of demosaic::full (src/ops/demosaic.rs:77-90), 3 bits per tap packed
+  // low-to-high in tap order (-1,-1),(-1,0),(-1,1),(0,-1),(0,0),(0,1),(1,-1),(1,0),(1,1); 4 = discard.
+  void demosaic_lookups(uint32_t out[48 * 48]) const {
+    static const int off[9][2] = {{-1,-1},{-1,0},{-1,1},{0,-1},{0,0},{0,1},{1,-1},{1,0},{1,1}};
+    for (size_t row = 0; row < 48; ++row)
+      for (size_t col = 0; col < 48; ++col) {
+        const int pix = color_at(row, col);
+        uint32_t w = 0;
+        for (int i = 0; i < 9; ++i) {
+          const int dy = off[i][0], dx = off[i][1];
+          const int o = color_at(size_t(48 + dy) + row, size_t(48 + dx) + col);
+          const uint32_t c = (o != pix || (dx == 0 && dy == 0)) ? uint32_t(o) : 4u;
+          w |= c << (3 * i);
+        }
+        out[row * 48 + col] = w;
+      }
+  }
+  // Is this one of the four phases of the RGGB Bayer tile?  color_at(r,c) == RGGB[(r+yoff)&1][(c+xoff)&1]
+  bool bayer_phase(int &xoff, int &yoff) const {
+    if (width != 2 || height != 2) return false;
+    static const int rggb[2][2] = {{0, 1}, {1, 2}};
+    for (yoff = 0; yoff < 2; ++yoff)
+      for (xoff = 0; xoff < 2; ++xoff) {
+        bool ok = true;
+        for (int r = 0; r < 2 && ok; ++r)
+          for (int c = 0; c < 2 && ok; ++c) ok = pattern[r][c] == rggb[(r + yoff) & 1][(c + xoff) & 1];
+        if (ok) return true;
+      }
+    return false;
+  }
+};
+
+// ---- OpGoFloat::size_image (src/ops/gofloat.rs:74-82) --------------------------------------
+struct Rect { size_t x, y, width, height; };
+inline bool size_image(size_t crop_top, size_t crop_right, size_t crop_bottom, size_t crop_left,
+                       size_t owidth, size_t oheight, Rect &r) {
+  if (owidth < 10 || oheight < 10) return false;          // usize underflow in the reference
+  r.x = std::min(crop_left, owidth - 10);
+  r.y = std::min(crop_top, oheight - 10);
+  r.width = owidth - std::min(crop_left + crop_right, owidth - 10);
+  r.height = oheight - std::min(crop_top + crop_bottom, oheight - 10);
+  return true;
+}
+
+// ---- scaling (src/scaling.rs:8-32) ---------------------------------------------------------
+struct Scaling { float scale; size_t width, height; };
+inline Scaling calculate_scaling_total(size_t width, size_t height, size_t maxwidth, size_t maxheight) {
+  if (maxwidth == 0 && maxheight == 0) return {1.0f, width, height};
+  const float xscale = maxwidth == 0 ? 1.0f : float(width) / float(maxwidth);
+  const float yscale = maxheight == 0 ? 1.0f : float(height) / float(maxheight);
+  if (yscale <= 1.0f && xscale <= 1.0f) return {1.0f, width, height};
+  if (yscale > xscale) return {yscale, f32_to_usize(float(width) / yscale), maxheight};
+  return {xscale, maxwidth, f32_to_usize(float(height) / xscale)};
+}
+inline float demosaic_minscale(int cfa_width) {            // src/ops/demosaic.rs:33-39
+  switch (cfa_width) { case 2: return 2.0f; case 6: return 3.0f; case 8: return 2.0f; case 12: return 12.0f; default: return 2.0f; }
+}
+
+// ---- normalize_wbs (src/ops/colorspaces.rs:12-27) ------------------------------------------
+inline void normalize_wbs(const float vals[4], float out[4]) {
+  const float unity = vals[1];
+  for (int i = 0; i < 4; ++i) out[i] = !std::isnormal(vals[i]) ? 1.0f : vals[i] / unity;
+}
+
+// ---- SplineFunc::new (src/ops/curves.rs:68-124) --------------------------------------------
+constexpr int kSplineMaxKnots = 66;
+struct Spline {
+  int npoints = 0, nseg = 0;                 // knots, segments (= c3s.len())
+  float px[kSplineMaxKnots], py[kSplineMaxKnots], c1[kSplineMaxKnots], c2[kSplineMaxKnots], c3[kSplineMaxKnots];
+  // p: n (x,y) pairs
+  bool build(const float *p, int n) {
+    if (n < 0 || n > kSplineMaxKnots - 2) return false;
+    int np = 0;
+    if (n == 0 || (p[0] > 0.0f && p[1] > 0.0f)) { px[np] = 0.0f; py[np] = 0.0f; ++np; }
+    for (int i = 0; i < n; ++i) { px[np] = p[2 * i]; py[np] = p[2 * i + 1]; ++np; }
+    if (n == 0 || (p[2 * (n - 1)] < 1.0f && p[2 * (n - 1) + 1] < 1.0f)) { px[np] = 1.0f; py[np] = 1.0f; ++np; }
+    if (np < 2) return false;                 // reference panics indexing slopes[0]
+    npoints = np;
+    const int nd = np - 1;
+    float dxs[kSplineMaxKnots], slopes[kSplineMaxKnots];
+    for (int i = 0; i < nd; ++i) {
+      const float dx = px[i + 1] - px[i], dy = py[i + 1] - py[i];
+      dxs[i] = dx; slopes[i] = dy / dx;
+    }
+    int k = 0;
+    c1[k++] = slopes[0];
+    for (int i = 0; i < nd - 1; ++i) {
+      const float m = slopes[i], next = slopes[i + 1];
+      if (m * next <= 0.0f) c1[k++] = 0.0f;
+      else {
+        const float dx = dxs[i], dxnext = dxs[i + 1], common = dx + dxnext;
+        c1[k++] = 3.0f * common / ((common + dxnext) / m + (common + dx) / next);
+      }
+    }
+    c1[k++] = slopes[nd - 1];
+    nseg = 0;
+    for (int i = 0; i < k - 1; ++i) {
+      const float a = c1[i], slope = slopes[i], invdx = 1.0f / dxs[i];
+      const float common = a + c1[i + 1] - slope - slope;
+      c2[nseg] = (slope - a - common) * invdx;
+      c3[nseg] = common * invdx * invdx;
+      ++nseg;
+    }
+    return true;
+  }
+};
+
+// ---- Orientation flips (rawloader; table pinned by src/ops/transform.rs:168-278) -----------
+inline void orientation_to_flips(int o, bool &transpose, bool &fx, bool &fy) {
+  static const bool t[9][3] = {{0,0,0},{0,1,0},{0,1,1},{0,0,1},{1,0,0},{1,0,1},{1,1,1},{1,1,0},{0,0,0}};
+  if (o < 0 || o > 8) o = 8;
+  transpose = t[o][0]; fx = t[o][1]; fy = t[o][2];
+}
+inline int orientation_from_flips(bool transpose, bool fx, bool fy) {
+  for (int o = 0; o < 8; ++o) { bool a, b, c; orientation_to_flips(o, a, b, c); if (a == transpose && b == fx && c == fy) return o; }
+  return 8;
+}
+// OpTransform::run's recomposition (src/ops/transform.rs:58-66)
+inline int transform_orientation(int rotation, bool fliph, bool flipv) {
+  static const int base[4] = {0 /*Normal*/, 5 /*Rotate90*/, 2 /*Rotate180*/, 7 /*Rotate270*/};
+  bool t, fx, fy; orientation_to_flips(base[rotation & 3], t, fx, fy);
+  return orientation_from_flips(t, fx != fliph, fy != flipv);
+}
+inline void transform_forward(int rotation, size_t w, size_t h, size_t &ow, size_t &oh) {   // :75-84
+  if (rotation == 1 || rotation == 3) { ow = h; oh = w; } else { ow = w; oh = h; }
+}
+
+// ---- OpRotateCrop sizing (src/ops/rotatecrop.rs:66-163) ------------------------------------
+struct RotateCrop {
+  float crop_top = 0, crop_right = 0, crop_bottom = 0, crop_left = 0, rotation = 0;
+  float input_ratio = 1.0f;
+  bool has_output = false; size_t out_w = 0, out_h = 0;
+  static constexpr float kEps = 1.0f / 1000000.0f;
+  static constexpr float kFracPi2 = 1.57079632679489661923132169163975144f;
+
+  void reset() { input_ratio = 1.0f; has_output = false; out_w = out_h = 0; }
+  bool noop() const {
+    return std::fabs(rotation) < kEps && std::fabs(crop_top) < kEps && std::fabs(crop_right) < kEps &&
+           std::fabs(crop_bottom) < kEps && std::fabs(crop_left) < kEps;
+  }
+  float angle() const { return kFracPi2 * (rotation > 1.0f ? 1.0f : rotation); }
+  void calc_size(size_t owidth, size_t oheight, bool reverse, size_t &rw, size_t &rh) const {
+    rw = owidth; rh = oheight;
+    if (noop()) return;
+    float width = float(owidth), height = float(oheight);
+    if (!(reverse || rotation < kEps)) {
+      const float sn = std::sin(angle()), cs = std::cos(angle());
+      const float w2 = width * cs + height * sn, h2 = width * sn + height * cs;
+      width = w2; height = h2;
+    }
+    float nwidth, nheight;
+    {
+      const float ratio = 1.0f - crop_left - crop_right;
+      nwidth = reverse ? std::round(width / ratio) : std::round(width * ratio);
+      if (ratio < kEps || nwidth < 1.0f) return;
+    }
+    {
+      const float ratio = 1.0f - crop_top - crop_bottom;
+      nheight = reverse ? std::round(height / ratio) : std::round(height * ratio);
+      if (ratio < kEps || nheight < 1.0f) return;
+    }
+    if (!(!reverse || rotation < kEps)) {
+      const float sn = std::sin(angle()), cs = std::cos(angle());
+      const float w2 = std::round(nheight / (sn + (cs / input_ratio)));
+      const float h2 = std::round(w2 / input_ratio);
+      nwidth = w2; nheight = h2;
+    }
+    rw = f32_to_usize(nwidth); rh = f32_to_usize(nheight);
+  }
+  void transform_forward(size_t w, size_t h, size_t &ow, size_t &oh) {
+    if (has_output) { ow = out_w; oh = out_h; }
+    else { input_ratio = float(w) / float(h); calc_size(w, h, false, ow, oh); }
+  }
+  void transform_reverse(size_t w, size_t h, size_t &ow, size_t &oh) {
+    has_output = true; out_w = w; out_h = h;
+    calc_size(w, h, true, ow, oh);
+  }
+  void rotate_point_reverse(float x, float y, float width, float height, float swidth, float sheight,
+                            int64_t &ox, int64_t &oy) const {                       // :97-109
+    if (rotation < kEps) { ox = f32_to_isize(x); oy = f32_to_isize(y); return; }
+    const float sn = std::sin(angle()), cs = std::cos(angle());
+    const float tx = x - (width / 2.0f), ty = y - (height / 2.0f);
+    const float nx = tx * cs + ty * sn + (swidth / 2.0f);
+    const float ny = -tx * sn + ty * cs + (sheight / 2.0f);
+    ox = f32_to_isize(nx); oy = f32_to_isize(ny);
+  }
+  // The three corner points OpRotateCrop::run hands to OpBuffer::transform (:39-64).
+  // Returns false when the op returns its input unchanged.
+  bool corners(size_t width, size_t height, int64_t pts[6], size_t &nw, size_t &nh) const {
+    if (noop()) return false;
+    const float swidth = float(width), sheight = float(height);
+    calc_size(width, height, false, nw, nh);
+    const float fnw = float(nw), fnh = float(nh);
+    const float x = std::floor(swidth * crop_left);
+    if (x < 0.0f || x > swidth) return false;
+    const float y = std::floor(sheight * crop_top);
+    if (y < 0.0f || y > sheight) return false;
+    rotate_point_reverse(x, y, fnw, fnh, swidth, sheight, pts[0], pts[1]);
+    rotate_point_reverse(x + fnw - 1.0f, y, fnw, fnh, swidth, sheight, pts[2], pts[3]);
+    rotate_point_reverse(x, y + fnh - 1.0f, fnw, fnh, swidth, sheight, pts[4], pts[5]);
+    return true;
+  }
+};
+
+}  // namespace ipk

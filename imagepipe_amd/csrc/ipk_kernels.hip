@@ -1,0 +1,723 @@
+// ipk_kernels.hip -- gfx950 kernels of the raw->sRGB hot path and their launchers.
+//
+// Staged kernels (one per reference op, so stage boundaries stay materialisable for the
+// reference's per-op cache, src/pipeline.rs:364-372) and the fused raw->sRGB kernel.
+// All of them are HBM-streaming kernels: coalesced row-major access, LDS only for the two
+// 13-bit lookup tables (and the 48x48 CFA colour table), no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ipk_device.hpp"
+#include "ipk_launch.hpp"
+
+using namespace ipkd;
+
+namespace ipk {
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+static inline dim3 grid_rows(size_t width, size_t height, int bx, int cols_per_thread = 1) {
+  size_t gx = (width + size_t(bx) * cols_per_thread - 1) / (size_t(bx) * cols_per_thread);
+  size_t gy = height < 65535 ? height : 65535;
+  return dim3((unsigned)gx, (unsigned)gy, 1);
+}
+static inline unsigned grid_1d(size_t n, int bx, unsigned cap) {
+  size_t g = (n + bx - 1) / bx;
+  if (g < 1) g = 1;
+  return (unsigned)(g < cap ? g : cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// OpGoFloat (src/ops/gofloat.rs:84-201)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_gofloat_cfa(const T *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
+                              float min0, float range0, float *__restrict__ dst) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= width) return;
+  for (uint32_t row = blockIdx.y; row < height; row += gridDim.y) {
+    const float v = (float)src[owidth * (row + y) + x + col];
+    dst[(size_t)row * width + col] = rs_min((v - min0) / range0, 1.0f);      // gofloat.rs:126 / :162
+  }
+}
+template <typename T>
+__global__ void k_gofloat_mono(const T *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
+                               float min0, float range0, float4 *__restrict__ dst) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= width) return;
+  for (uint32_t row = blockIdx.y; row < height; row += gridDim.y) {
+    const float v = rs_min(((float)src[owidth * (row + y) + x + col] - min0) / range0, 1.0f);   // gofloat.rs:100-104
+    dst[(size_t)row * width + col] = make_float4(v, v, v, 0.0f);
+  }
+}
+struct Levels4 { float mins[4]; float ranges[4]; };
+template <typename T>
+__global__ void k_gofloat_rgb(const T *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
+                              Levels4 lv, float4 *__restrict__ dst) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= width) return;
+  for (uint32_t row = blockIdx.y; row < height; row += gridDim.y) {
+    const T *i = src + (owidth * (row + y) + x + col) * 3;                   // gofloat.rs:113-118
+    float4 o;
+    o.x = rs_min(((float)i[0] - lv.mins[0]) / lv.ranges[0], 1.0f);
+    o.y = rs_min(((float)i[1] - lv.mins[1]) / lv.ranges[1], 1.0f);
+    o.z = rs_min(((float)i[2] - lv.mins[2]) / lv.ranges[2], 1.0f);
+    o.w = 0.0f;
+    dst[(size_t)row * width + col] = o;
+  }
+}
+// run_other, 8 bit: expand_srgb_gamma(input8bit(v)) -- only 256 distinct inputs, so the block first
+// evaluates the reference expression for each of them (the SRGB_GAMMA_REVERSE table is read from
+// global memory 256 times) and the pixels index that 1 KB LDS table.
+__global__ void k_gofloat_other_u8(const uint8_t *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
+                                   const LutPair *__restrict__ gamma_reverse, float4 *__restrict__ dst) {
+  __shared__ float s_expand[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_expand[i] = lut_interp(gamma_reverse, input8bit((uint8_t)i));
+  __syncthreads();
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= width) return;
+  for (uint32_t row = blockIdx.y; row < height; row += gridDim.y) {
+    const uint8_t *i = src + (owidth * (row + y) + x + col) * 3;             // gofloat.rs:181-186
+    dst[(size_t)row * width + col] = make_float4(s_expand[i[0]], s_expand[i[1]], s_expand[i[2]], 0.0f);
+  }
+}
+__global__ void k_gofloat_other_u16(const uint16_t *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
+                                    float4 *__restrict__ dst) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= width) return;
+  for (uint32_t row = blockIdx.y; row < height; row += gridDim.y) {
+    const uint16_t *i = src + (owidth * (row + y) + x + col) * 3;            // gofloat.rs:191-196
+    dst[(size_t)row * width + col] = make_float4(input16bit(i[0]), input16bit(i[1]), input16bit(i[2]), 0.0f);
+  }
+}
+
+template <typename T>
+void launch_gofloat_cfa(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float black0, float white0,
+                        float *dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_gofloat_cfa<T>, grid_rows(w, h, 256), dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h,
+                     black0, white0 - black0, dst);
+}
+template <typename T>
+void launch_gofloat_mono(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float black0, float white0,
+                         float *dst4, hipStream_t s) {
+  hipLaunchKernelGGL(k_gofloat_mono<T>, grid_rows(w, h, 256), dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h,
+                     black0, white0 - black0, reinterpret_cast<float4 *>(dst4));
+}
+template <typename T>
+void launch_gofloat_rgb(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, const float *black4, const float *white4,
+                        float *dst4, hipStream_t s) {
+  Levels4 lv;
+  for (int i = 0; i < 4; ++i) { lv.mins[i] = black4[i]; lv.ranges[i] = white4[i] - black4[i]; }   // gofloat.rs:86-89
+  hipLaunchKernelGGL(k_gofloat_rgb<T>, grid_rows(w, h, 256), dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h,
+                     lv, reinterpret_cast<float4 *>(dst4));
+}
+template void launch_gofloat_cfa<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, float *, hipStream_t);
+template void launch_gofloat_cfa<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, float *, hipStream_t);
+template void launch_gofloat_mono<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, float *, hipStream_t);
+template void launch_gofloat_mono<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, float *, hipStream_t);
+template void launch_gofloat_rgb<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, const float *, const float *, float *, hipStream_t);
+template void launch_gofloat_rgb<float>(const float *, size_t, size_t, size_t, size_t, size_t, const float *, const float *, float *, hipStream_t);
+
+void launch_gofloat_other_u8(const uint8_t *src, size_t owidth, size_t x, size_t y, size_t w, size_t h,
+                             const void *gamma_reverse_pairs, float *dst4, hipStream_t s) {
+  hipLaunchKernelGGL(k_gofloat_other_u8, grid_rows(w, h, 256), dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h,
+                     reinterpret_cast<const LutPair *>(gamma_reverse_pairs), reinterpret_cast<float4 *>(dst4));
+}
+void launch_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float *dst4, hipStream_t s) {
+  hipLaunchKernelGGL(k_gofloat_other_u16, grid_rows(w, h, 256), dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h,
+                     reinterpret_cast<float4 *>(dst4));
+}
+
+// ------------------------------------------------------------------------------------------
+// demosaic::full, any CFA (src/ops/demosaic.rs:67-119)
+// `lookups` = the 48x48 table of nine 3-bit tap colours built on the host exactly as
+// demosaic.rs:77-90 does; staged in LDS (9 KB).
+// ------------------------------------------------------------------------------------------
+struct DemosaicAcc {
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;     // sums[0..3]; bucket 4 (discard) is never read
+  float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;     // counts
+  __device__ __forceinline__ void add(uint32_t color, float v) {   // demosaic.rs:105-106
+    if (color == 0) { s0 += v; n0 += 1.0f; }
+    else if (color == 1) { s1 += v; n1 += 1.0f; }
+    else if (color == 2) { s2 += v; n2 += 1.0f; }
+    else if (color == 3) { s3 += v; n3 += 1.0f; }
+  }
+  __device__ __forceinline__ float4 finish() const {               // demosaic.rs:110-114; untouched channels stay 0.0
+    return make_float4(n0 > 0.0f ? s0 / n0 : 0.0f, n1 > 0.0f ? s1 / n1 : 0.0f,
+                       n2 > 0.0f ? s2 / n2 : 0.0f, n3 > 0.0f ? s3 / n3 : 0.0f);
+  }
+};
+
+__global__ void k_demosaic_full(const float *__restrict__ src, uint32_t width, uint32_t img_height, uint32_t src_row0,
+                                uint32_t out_row0, uint32_t out_rows, const uint32_t *__restrict__ lookups,
+                                float4 *__restrict__ dst) {
+  __shared__ uint32_t s_lookups[48 * 48];
+  for (int i = threadIdx.x; i < 48 * 48; i += blockDim.x) s_lookups[i] = lookups[i];
+  __syncthreads();
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= width) return;
+  for (uint32_t orow = blockIdx.y; orow < out_rows; orow += gridDim.y) {
+    const uint32_t row = out_row0 + orow;                                   // image row
+    const uint32_t colors = s_lookups[(row % 48) * 48 + (col % 48)];        // demosaic.rs:95
+    DemosaicAcc acc;
+    #pragma unroll
+    for (int i = 0; i < 9; ++i) {                                           // tap order of demosaic.rs:70-74
+      const int dy = i / 3 - 1, dx = i % 3 - 1;
+      const int64_t r = (int64_t)row + dy, c = (int64_t)col + dx;
+      if (r >= 0 && r < (int64_t)img_height && c >= 0 && c < (int64_t)width)
+        acc.add((colors >> (3 * i)) & 7u, src[(size_t)(r - src_row0) * width + (size_t)c]);
+    }
+    dst[(size_t)orow * width + col] = acc.finish();
+  }
+}
+void launch_demosaic_full(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
+                          const uint32_t *lookups_dev, float *dst4, hipStream_t s) {
+  hipLaunchKernelGGL(k_demosaic_full, grid_rows(width, out_rows, 256), dim3(256), 0, s, src, (uint32_t)width, (uint32_t)img_height,
+                     (uint32_t)src_row0, (uint32_t)out_row0, (uint32_t)out_rows, lookups_dev, reinterpret_cast<float4 *>(dst4));
+}
+
+// ------------------------------------------------------------------------------------------
+// scaling::transform_buffer<T> (src/scaling.rs:51-130)
+// One thread per destination pixel; the window walk keeps the reference's y-outer / x-inner /
+// component-innermost accumulation order.
+// ------------------------------------------------------------------------------------------
+struct TransformArgs {
+  uint32_t width, height, nwidth, nheight, components;
+  float tlx, tly;                 // topleft as f32
+  float skip_x_x, skip_x_y, skip_y_x, skip_y_y;
+  int has_cfa;
+};
+template <typename T> struct PixCast;
+template <> struct PixCast<float>    { static __device__ __forceinline__ float to(float v) { return v; }    static __device__ __forceinline__ float from(float f) { return f; } };
+template <> struct PixCast<uint8_t>  { static __device__ __forceinline__ float to(uint8_t v) { return (float)v; }  static __device__ __forceinline__ uint8_t from(float f) { float c = rs_min(rs_max(f, 0.0f), 255.0f); return (uint8_t)f32_as_u32_sat(c); } };
+template <> struct PixCast<uint16_t> { static __device__ __forceinline__ float to(uint16_t v) { return (float)v; } static __device__ __forceinline__ uint16_t from(float f) { float c = rs_min(rs_max(f, 0.0f), 65535.0f); return (uint16_t)f32_as_u32_sat(c); } };
+
+template <typename T>
+__global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48, T *__restrict__ dst) {
+  __shared__ uint8_t s_cfa[48 * 48];
+  if (a.has_cfa) {
+    for (int i = threadIdx.x; i < 48 * 48; i += blockDim.x) s_cfa[i] = cfa48[i];
+    __syncthreads();
+  }
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= a.nwidth) return;
+  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+    // per-row values (scaling.rs:77-82)
+    const float from_x_r = a.tlx + a.skip_y_x * (float)row;
+    const float to_x_r = a.tlx + a.skip_y_x * (float)(row + 1);
+    const float from_y_r = a.tly + a.skip_y_y * (float)row;
+    const float to_y_r = a.tly + a.skip_y_y * (float)(row + 1);
+    const float center_x_r = a.tlx + (a.skip_y_x * (float)row) + (a.skip_y_x / 2.0f) - 0.5f;
+    const float center_y_r = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f;
+    // per-column window (scaling.rs:84-89)
+    const uint32_t from_x = min(a.width - 1, f32_as_u32_sat(floorf(from_x_r + (a.skip_x_x * (float)col))));
+    const uint32_t to_x = min(a.width - 1, f32_as_u32_sat(floorf(to_x_r + (a.skip_x_x * (float)(col + 1)))));
+    const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(from_y_r + (a.skip_x_y * (float)col))));
+    const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(to_y_r + (a.skip_x_y * (float)(col + 1)))));
+    const float center_x = center_x_r + (a.skip_x_x * (float)col) + (a.skip_x_x / 2.0f);
+    const float center_y = center_y_r + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
+
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    for (uint32_t y = from_y; y <= to_y; ++y) {
+      const float delta_y = ((float)y - center_y) / a.skip_y_y;
+      const float dy2 = delta_y * delta_y;
+      for (uint32_t x = from_x; x <= to_x; ++x) {
+        const float delta_x = ((float)x - center_x) / a.skip_x_x;
+        float factor = 1.0f - (delta_x * delta_x) - dy2;                    // scaling.rs:106
+        factor = (factor < 0.0f) ? 0.0f : factor;
+        if (a.has_cfa) {
+          const uint32_t c = s_cfa[(y % 48) * 48 + (x % 48)];               // cfa.color_at(y, x)
+          const float t = PixCast<T>::to(src[(size_t)y * a.width + x]) * factor;
+          if (c == 0) { s0 += t; n0 += factor; }
+          else if (c == 1) { s1 += t; n1 += factor; }
+          else if (c == 2) { s2 += t; n2 += factor; }
+          else { s3 += t; n3 += factor; }
+        } else {
+          const T *p = src + ((size_t)y * a.width + x) * a.components;
+          s0 += PixCast<T>::to(p[0]) * factor; n0 += factor;
+          if (a.components > 1) { s1 += PixCast<T>::to(p[1]) * factor; n1 += factor; }
+          if (a.components > 2) { s2 += PixCast<T>::to(p[2]) * factor; n2 += factor; }
+          if (a.components > 3) { s3 += PixCast<T>::to(p[3]) * factor; n3 += factor; }
+        }
+        if (x == 0xFFFFFFFFu) break;
+      }
+      if (y == 0xFFFFFFFFu) break;
+    }
+    // scaling.rs:122-126: untouched components keep the zero fill
+    T *o = dst + ((size_t)row * a.nwidth + col) * a.components;
+    o[0] = (n0 > 0.0f) ? PixCast<T>::from(s0 / n0) : PixCast<T>::from(0.0f);
+    if (a.components > 1) o[1] = (n1 > 0.0f) ? PixCast<T>::from(s1 / n1) : PixCast<T>::from(0.0f);
+    if (a.components > 2) o[2] = (n2 > 0.0f) ? PixCast<T>::from(s2 / n2) : PixCast<T>::from(0.0f);
+    if (a.components > 3) o[3] = (n3 > 0.0f) ? PixCast<T>::from(s3 / n3) : PixCast<T>::from(0.0f);
+  }
+}
+template <typename T>
+void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
+                             int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,
+                             const uint8_t *cfa48_dev, T *dst, hipStream_t s) {
+  TransformArgs a;
+  a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight;
+  a.components = (uint32_t)components;
+  a.tlx = (float)tlx; a.tly = (float)tly;
+  // scaling.rs:68-71
+  a.skip_x_x = ((float)trx - (float)tlx) / ((float)(nwidth - 1));
+  a.skip_x_y = ((float)try_ - (float)tly) / ((float)(nwidth - 1));
+  a.skip_y_x = ((float)blx - (float)tlx) / ((float)(nheight - 1));
+  a.skip_y_y = ((float)bly - (float)tly) / ((float)(nheight - 1));
+  a.has_cfa = cfa48_dev != nullptr;
+  hipLaunchKernelGGL(k_transform_buffer<T>, grid_rows(nwidth, nheight, 128), dim3(128), 0, s, src, a, cfa48_dev, dst);
+}
+template void launch_transform_buffer<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, float *, hipStream_t);
+template void launch_transform_buffer<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint8_t *, hipStream_t);
+template void launch_transform_buffer<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint16_t *, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Point-wise stage kernels: one thread per pixel, 12/16-byte per-lane accesses that are
+// contiguous across the wave.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+
+// OpToLab::run (src/ops/colorspaces.rs:103-111)
+__global__ __launch_bounds__(1024) void k_tolab(const float4 *__restrict__ src, size_t n, ToLabParams p,
+                                                const LutPair *__restrict__ lab_pairs, f3 *__restrict__ dst) {
+  __shared__ LutPair s_lab[kLutPairs];
+  load_lut_pairs(s_lab, lab_pairs);
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    f3 o;
+    camera_to_lab(s_lab, p, v.x, v.y, v.z, v.w, o.x, o.y, o.z);
+    dst[i] = o;
+  }
+}
+// OpBaseCurve::run (src/ops/curves.rs:44-48): channel 0 only, the rest is the clone
+__global__ void k_basecurve(const f3 *__restrict__ src, size_t n, SplineDev sp, f3 *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    f3 v = src[i];
+    v.x = spline_interpolate(sp, v.x);
+    dst[i] = v;
+  }
+}
+// OpFromLab::run (src/ops/colorspaces.rs:128-136)
+__global__ void k_fromlab(const f3 *__restrict__ src, size_t n, Mat9 m, f3 *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const f3 v = src[i];
+    f3 o;
+    lab_to_rgb(m, v.x, v.y, v.z, o.x, o.y, o.z);
+    dst[i] = o;
+  }
+}
+// OpGamma::run (src/ops/gamma.rs:20-24): every sample
+__global__ __launch_bounds__(1024) void k_gamma(const float *__restrict__ src, size_t n, const LutPair *__restrict__ gam_pairs,
+                                                float *__restrict__ dst) {
+  __shared__ LutPair s_gam[kLutPairs];
+  load_lut_pairs(s_gam, gam_pairs);
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = gamma_sample(s_gam, src[i]);
+}
+// rotate_buffer (src/ops/transform.rs:130-141): strided gather of 3-channel pixels
+__global__ void k_rotate(const f3 *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset, int64_t x_step,
+                         int64_t y_step, f3 *__restrict__ dst) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= owidth) return;
+  for (uint32_t row = blockIdx.y; row < oheight; row += gridDim.y) {
+    const int64_t offset = base_offset + y_step * (int64_t)row + x_step * (int64_t)col;   // in pixels
+    dst[(size_t)row * owidth + col] = src[offset];
+  }
+}
+// output8bit / output16bit loops (src/pipeline.rs:408-414, :455-461)
+__global__ void k_output8(const float *__restrict__ src, size_t n, uint8_t *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output8bit(src[i]);
+}
+__global__ void k_output16(const float *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output16bit(src[i]);
+}
+
+static ToLabParams make_tolab(const float *mul4, const float *cm12) {
+  ToLabParams p;
+  for (int i = 0; i < 4; ++i) p.mul[i] = mul4[i];
+  for (int i = 0; i < 12; ++i) p.cm[i] = cm12[i];
+  return p;
+}
+static SplineDev make_spline(const SplineHost &h) {
+  SplineDev d;
+  d.npoints = h.npoints; d.nseg = h.nseg;
+  for (int i = 0; i < kSplineMaxKnots; ++i) { d.px[i] = h.px[i]; d.py[i] = h.py[i]; d.c1[i] = h.c1[i]; d.c2[i] = h.c2[i]; d.c3[i] = h.c3[i]; }
+  return d;
+}
+
+void launch_tolab(const float *src4, size_t npix, const float *mul4, const float *cm12, const void *lab_pairs, float *dst3,
+                  int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_tolab, dim3(grid_1d(npix, 1024, (unsigned)num_cus * 2)), dim3(1024), 0, s,
+                     reinterpret_cast<const float4 *>(src4), npix, make_tolab(mul4, cm12),
+                     reinterpret_cast<const LutPair *>(lab_pairs), reinterpret_cast<f3 *>(dst3));
+}
+void launch_basecurve(const float *src3, size_t npix, const SplineHost &sp, float *dst3, int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_basecurve, dim3(grid_1d(npix, 256, (unsigned)num_cus * 16)), dim3(256), 0, s,
+                     reinterpret_cast<const f3 *>(src3), npix, make_spline(sp), reinterpret_cast<f3 *>(dst3));
+}
+void launch_fromlab(const float *src3, size_t npix, const float *m9, float *dst3, int num_cus, hipStream_t s) {
+  Mat9 m; for (int i = 0; i < 9; ++i) m.m[i] = m9[i];
+  hipLaunchKernelGGL(k_fromlab, dim3(grid_1d(npix, 256, (unsigned)num_cus * 16)), dim3(256), 0, s,
+                     reinterpret_cast<const f3 *>(src3), npix, m, reinterpret_cast<f3 *>(dst3));
+}
+void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst, int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_gamma, dim3(grid_1d(n, 1024, (unsigned)num_cus * 2)), dim3(1024), 0, s, src, n,
+                     reinterpret_cast<const LutPair *>(gam_pairs), dst);
+}
+void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
+                   float *dst3, hipStream_t s) {
+  hipLaunchKernelGGL(k_rotate, grid_rows(owidth, oheight, 256), dim3(256), 0, s, reinterpret_cast<const f3 *>(src3),
+                     (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px, reinterpret_cast<f3 *>(dst3));
+}
+void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_output8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+}
+void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_output16, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused raw -> sRGB for the four RGGB Bayer phases:
+//   OpGoFloat::run_raw (CFA branch) + demosaic::full + OpToLab + OpBaseCurve + OpFromLab + OpGamma
+//   [+ output8bit/output16bit], one pass: 4 (or 2) bytes in, 12 (or 3/6) bytes out per pixel.
+//
+// Structure (MI355X-first, not a restatement of the reference's row-parallel loops):
+//   * one 1024-thread workgroup per CU; both 13-bit tables live in LDS as {v, dv} pairs (128 KB);
+//   * no other LDS, no barriers after the table load: every WAVE owns a strip of up to 256 columns
+//     (4 consecutive pixels per lane => 16-byte loads, 48-byte stores, contiguous across the wave)
+//     and walks down a segment of rows, keeping a 3-row window of normalised samples in registers;
+//     horizontal neighbours come from the adjacent lane by DPP wave shifts, the two strip-edge
+//     columns from one 2-lane halo load per row;
+//   * each mosaic sample is therefore read from HBM once (plus 2 halo rows per segment and 2 halo
+//     columns per strip) and normalised once;
+//   * tasks (strip x row segment) are sized so that all waves of the grid get equal work.
+// ------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const void *src;            // element (row 0 of the slab, sensor column x) -- see row_off
+  void *dst;                  // first output row (image row out_r0)
+  uint32_t W, H;              // cropped image size
+  uint64_t owidth;            // source row pitch (elements)
+  uint32_t row_off;           // image row held by slab row 0
+  uint32_t out_r0, out_r1;    // output rows [out_r0, out_r1)
+  float min0, range0;         // blacklevels[0], whitelevels[0]-blacklevels[0]
+  int xoff, yoff;             // Bayer phase: color_at(r,c) = RGGB[(r+yoff)&1][(c+xoff)&1]
+  ToLabParams tolab;
+  Mat9 rgbm;                  // XYZ_D65_33
+  int has_curve, linear;
+  uint32_t n_strips, n_segs;  // task grid
+  uint32_t lc_base, lc_rem;   // lane-columns per strip: base (+1 for the first lc_rem strips)
+  const LutPair *lab_pairs, *gam_pairs;
+  SplineDev spline;
+};
+
+// one image row as a lane sees it: its 4 samples and the neighbours left/right of them
+struct RowWin { float l, v0, v1, v2, v3, r; };
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) us4 { uint16_t x, y, z, w; };
+struct __attribute__((packed, aligned(2))) us4u { uint16_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) u3w { uint32_t x, y, z; };
+
+template <typename T> struct RawRow { float v0, v1, v2, v3, h; };
+
+__device__ __forceinline__ float dpp_wave_shr1(float old, float v) {   // lane i <- lane i-1 ; lane 0 keeps `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float old, float v) {   // lane i <- lane i+1 ; lane 63 keeps `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// demosaic::full for one pixel with explicit tap validity: the frame-edge path (demosaic.rs:99-114).
+// pr/pc = parity of (row+yoff)/(col+xoff) in the RGGB tile; taps in the reference's order.
+__device__ __forceinline__ float4 demosaic_edge_px(const float t[9], uint32_t valid_mask, int pr, int pc) {
+  DemosaicAcc acc;
+  const int center = ((pr & 1) << 1 | (pc & 1));       // 0:R 1:G(r-row) 2:G(b-row) 3:B
+  const int center_color = center == 0 ? 0 : (center == 3 ? 2 : 1);
+  #pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int dy = i / 3 - 1, dx = i % 3 - 1;
+    const int tr = (pr + dy) & 1, tc = (pc + dx) & 1;
+    const int tcode = (tr << 1) | tc;
+    const int color = tcode == 0 ? 0 : (tcode == 3 ? 2 : 1);
+    const bool keep = (color != center_color) || i == 4;                    // demosaic.rs:87
+    if (((valid_mask >> i) & 1u) && keep) acc.add((uint32_t)color, t[i]);
+  }
+  return acc.finish();
+}
+
+// Interior pixel, all nine taps valid: the four tile roles written out.  Sums start from 0.0 and
+// add taps in the reference's order; /2 and /4 are exact as *0.5 / *0.25; count 1 is sum/1.0.
+template <int ROLE>   // 0: R site, 1: G on the R row, 2: G on the B row, 3: B site
+__device__ __forceinline__ float4 demosaic_inner_px(float nw, float n, float ne, float w, float c, float e, float sw, float s, float se) {
+  const float own = 0.0f + c;
+  const float cross = ((((0.0f + n) + w) + e) + s) * 0.25f;
+  const float diag = ((((0.0f + nw) + ne) + sw) + se) * 0.25f;
+  const float horiz = ((0.0f + w) + e) * 0.5f;
+  const float vert = ((0.0f + n) + s) * 0.5f;
+  if (ROLE == 0) return make_float4(own, cross, diag, 0.0f);
+  if (ROLE == 1) return make_float4(horiz, own, vert, 0.0f);
+  if (ROLE == 2) return make_float4(vert, own, horiz, 0.0f);
+  return make_float4(diag, cross, own, 0.0f);
+}
+
+struct PixOut { float r, g, b; };
+// OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma for one RGBE pixel
+__device__ __forceinline__ PixOut pointwise_px(const FusedArgs &a, const LutPair *__restrict__ s_lab, const LutPair *__restrict__ s_gam, float4 rgbe) {
+  float l, ca, cb;
+  camera_to_lab(s_lab, a.tolab, rgbe.x, rgbe.y, rgbe.z, rgbe.w, l, ca, cb);
+  if (a.has_curve) l = spline_interpolate(a.spline, l);
+  PixOut o;
+  lab_to_rgb(a.rgbm, l, ca, cb, o.r, o.g, o.b);
+  if (!a.linear) { o.r = gamma_sample(s_gam, o.r); o.g = gamma_sample(s_gam, o.g); o.b = gamma_sample(s_gam, o.b); }
+  return o;
+}
+
+template <typename SrcT, bool VEC>
+__device__ __forceinline__ void load_raw4(const SrcT *p, uint32_t nvalid, float &v0, float &v1, float &v2, float &v3);
+template <>
+__device__ __forceinline__ void load_raw4<float, true>(const float *p, uint32_t nvalid, float &v0, float &v1, float &v2, float &v3) {
+  if (nvalid == 4) { const f4u t = *reinterpret_cast<const f4u *>(p); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+  else { v0 = nvalid > 0 ? p[0] : 0.0f; v1 = nvalid > 1 ? p[1] : 0.0f; v2 = nvalid > 2 ? p[2] : 0.0f; v3 = 0.0f; }
+}
+template <>
+__device__ __forceinline__ void load_raw4<uint16_t, true>(const uint16_t *p, uint32_t nvalid, float &v0, float &v1, float &v2, float &v3) {
+  if (nvalid == 4) { const us4 t = *reinterpret_cast<const us4 *>(p); v0 = (float)t.x; v1 = (float)t.y; v2 = (float)t.z; v3 = (float)t.w; }
+  else { v0 = nvalid > 0 ? (float)p[0] : 0.0f; v1 = nvalid > 1 ? (float)p[1] : 0.0f; v2 = nvalid > 2 ? (float)p[2] : 0.0f; v3 = 0.0f; }
+}
+template <>
+__device__ __forceinline__ void load_raw4<uint16_t, false>(const uint16_t *p, uint32_t nvalid, float &v0, float &v1, float &v2, float &v3) {
+  if (nvalid == 4) { const us4u t = *reinterpret_cast<const us4u *>(p); v0 = (float)t.x; v1 = (float)t.y; v2 = (float)t.z; v3 = (float)t.w; }
+  else { v0 = nvalid > 0 ? (float)p[0] : 0.0f; v1 = nvalid > 1 ? (float)p[1] : 0.0f; v2 = nvalid > 2 ? (float)p[2] : 0.0f; v3 = 0.0f; }
+}
+
+template <int OUT> struct OutStore;
+template <> struct OutStore<0> {   // f32 RGB (Pipeline::run)
+  typedef float elem;
+  static __device__ __forceinline__ void store(void *dst, size_t pix, uint32_t nvalid, const PixOut o[4], bool) {
+    float *p = reinterpret_cast<float *>(dst) + pix * 3;
+    if (nvalid == 4) {
+      f4u a{o[0].r, o[0].g, o[0].b, o[1].r}, b{o[1].g, o[1].b, o[2].r, o[2].g}, c{o[2].b, o[3].r, o[3].g, o[3].b};
+      reinterpret_cast<f4u *>(p)[0] = a; reinterpret_cast<f4u *>(p)[1] = b; reinterpret_cast<f4u *>(p)[2] = c;
+    } else {
+      for (uint32_t j = 0; j < nvalid; ++j) { p[3 * j] = o[j].r; p[3 * j + 1] = o[j].g; p[3 * j + 2] = o[j].b; }
+    }
+  }
+};
+template <> struct OutStore<1> {   // u8 (output_8bit)
+  typedef uint8_t elem;
+  static __device__ __forceinline__ void store(void *dst, size_t pix, uint32_t nvalid, const PixOut o[4], bool aligned) {
+    uint8_t *p = reinterpret_cast<uint8_t *>(dst) + pix * 3;
+    uint8_t q[12];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) { q[3 * j] = output8bit(o[j].r); q[3 * j + 1] = output8bit(o[j].g); q[3 * j + 2] = output8bit(o[j].b); }
+    if (nvalid == 4 && aligned) {
+      u3w w;
+      w.x = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+      w.y = q[4] | (q[5] << 8) | (q[6] << 16) | ((uint32_t)q[7] << 24);
+      w.z = q[8] | (q[9] << 8) | (q[10] << 16) | ((uint32_t)q[11] << 24);
+      *reinterpret_cast<u3w *>(p) = w;
+    } else {
+      for (uint32_t j = 0; j < nvalid * 3; ++j) p[j] = q[j];
+    }
+  }
+};
+template <> struct OutStore<2> {   // u16 (output_16bit)
+  typedef uint16_t elem;
+  static __device__ __forceinline__ void store(void *dst, size_t pix, uint32_t nvalid, const PixOut o[4], bool aligned) {
+    uint16_t *p = reinterpret_cast<uint16_t *>(dst) + pix * 3;
+    uint16_t q[12];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) { q[3 * j] = output16bit(o[j].r); q[3 * j + 1] = output16bit(o[j].g); q[3 * j + 2] = output16bit(o[j].b); }
+    if (nvalid == 4 && aligned) {
+      uint32_t *pw = reinterpret_cast<uint32_t *>(p);
+      #pragma unroll
+      for (int j = 0; j < 6; ++j) pw[j] = q[2 * j] | ((uint32_t)q[2 * j + 1] << 16);
+    } else {
+      for (uint32_t j = 0; j < nvalid * 3; ++j) p[j] = q[j];
+    }
+  }
+};
+
+template <typename SrcT, bool VEC, int OUT>
+__global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
+  __shared__ LutPair s_lab[kLutPairs];
+  __shared__ LutPair s_gam[kLutPairs];
+  load_lut_pairs(s_lab, a.lab_pairs);
+  load_lut_pairs(s_gam, a.gam_pairs);
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (task >= a.n_strips * a.n_segs) return;             // whole wave leaves together
+  const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
+
+  // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each
+  const uint32_t lc0 = strip * a.lc_base + min(strip, a.lc_rem);
+  const uint32_t nl = a.lc_base + (strip < a.lc_rem ? 1u : 0u);
+  const uint32_t col0 = 4u * (lc0 + lane);
+  const bool lane_on = lane < nl;
+  const uint32_t nvalid = lane_on ? min(4u, a.W - min(a.W, col0)) : 0u;
+  // rows: this segment's output rows [r0, r1)
+  const uint32_t nrows = a.out_r1 - a.out_r0;
+  const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
+  const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
+  if (r0 >= r1) return;
+
+  // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl)
+  const bool is_first = lane == 0, is_last = lane + 1 == nl;
+  const int64_t halo_col = is_first ? (int64_t)4 * lc0 - 1 : (int64_t)4 * (lc0 + nl);
+  const bool halo_on = (is_first || is_last) && halo_col >= 0 && halo_col < (int64_t)a.W;
+  // a 1-lane strip needs both halos from one lane: the second one goes through `halo2`
+  const bool single = nl == 1;
+  const int64_t halo2_col = (int64_t)4 * (lc0 + nl);
+  const bool halo2_on = single && is_first && halo2_col < (int64_t)a.W;
+
+  const SrcT *src = reinterpret_cast<const SrcT *>(a.src);
+  const float min0 = a.min0, range0 = a.range0;
+
+  auto norm = [&](float v) -> float { return rs_min((v - min0) / range0, 1.0f); };       // gofloat.rs:126
+  // One image row is fetched in two steps so that the global loads of row r+2 are in flight while
+  // row r is being computed: issue_row() only loads, finish_row() normalises (OpGoFloat) and
+  // gathers the horizontal neighbours (DPP wave shifts + the strip's two halo columns).
+  struct RawRowT { float v0, v1, v2, v3, h, h2; };
+  auto issue_row = [&](uint32_t row) -> RawRowT {
+    const SrcT *rp = src + (uint64_t)(row - a.row_off) * a.owidth;
+    RawRowT t = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (nvalid) load_raw4<SrcT, VEC>(rp + col0, nvalid, t.v0, t.v1, t.v2, t.v3);
+    if (halo_on) t.h = (float)rp[halo_col];
+    if (halo2_on) t.h2 = (float)rp[halo2_col];
+    return t;
+  };
+  auto finish_row = [&](const RawRowT &t) -> RowWin {
+    RowWin w;
+    w.v0 = norm(t.v0); w.v1 = norm(t.v1); w.v2 = norm(t.v2); w.v3 = norm(t.v3);
+    const float h = norm(t.h);
+    const float h2 = single ? norm(t.h2) : 0.0f;
+    w.l = dpp_wave_shr1(h, w.v3);                        // lane 0 keeps its halo (left column)
+    const float rr = dpp_wave_shl1(h, w.v0);             // lane 63 keeps its halo
+    w.r = is_last ? (single ? h2 : h) : rr;
+    return w;
+  };
+
+  const bool store_aligned = (OUT == 0) ? true : ((OUT == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
+  const uint32_t Hm1 = a.H - 1, Wm1 = a.W - 1;
+
+  const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
+  if (r0 > 0) P = finish_row(issue_row(r0 - 1));
+  C = finish_row(issue_row(r0));
+  RawRowT raw_next = (r0 < Hm1) ? issue_row(r0 + 1) : zero_raw;
+  for (uint32_t r = r0; r < r1; ++r) {
+    if (r < Hm1) N = finish_row(raw_next);
+    if (r + 2 <= Hm1 && r + 1 < r1) raw_next = issue_row(r + 2);
+    const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
+    const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
+    const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
+    const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
+    float4 px[4];
+    // interior formulas; role = (row parity, column parity) in the RGGB tile.  col0 % 4 == 0, so the
+    // column parity of pixel j is (j + xoff) & 1: wave-uniform branches only.
+    if (pr == 0) {
+      if (a.xoff == 0) {
+        px[0] = demosaic_inner_px<0>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<1>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<0>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<1>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+      } else {
+        px[0] = demosaic_inner_px<1>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<0>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<1>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<0>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+      }
+    } else {
+      if (a.xoff == 0) {
+        px[0] = demosaic_inner_px<2>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<3>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<2>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<3>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+      } else {
+        px[0] = demosaic_inner_px<3>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<2>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<3>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<2>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+      }
+    }
+    // frame-edge pixels: taps outside the image are skipped, not mirrored (demosaic.rs:103-104)
+    const bool row_edge = (r == 0) || (r == Hm1);
+    const bool col_edge = nvalid && (col0 == 0 || col0 + 3 >= Wm1);
+    if (row_edge || col_edge) {
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t c = col0 + j;
+        if (c < a.W && (row_edge || c == 0 || c == Wm1)) {
+          const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
+          uint32_t m = 0x1FFu;
+          if (r == 0) m &= ~0x007u;
+          if (r == Hm1) m &= ~0x1C0u;
+          if (c == 0) m &= ~0x049u;
+          if (c == Wm1) m &= ~0x124u;
+          px[j] = demosaic_edge_px(t, m, pr, (int)((j + (uint32_t)a.xoff) & 1u));
+        }
+      }
+    }
+    PixOut o[4];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pointwise_px(a, s_lab, s_gam, px[j]);
+    if (nvalid) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
+    P = C; C = N;
+  }
+}
+
+template <typename SrcT, bool VEC, int OUT>
+static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT>), dim3(grid), dim3(1024), 0, s, a);
+}
+
+int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
+  FusedArgs a;
+  a.src = f.src; a.dst = f.dst; a.W = (uint32_t)f.width; a.H = (uint32_t)f.height; a.owidth = f.owidth;
+  a.row_off = (uint32_t)f.row_off; a.out_r0 = (uint32_t)f.out_r0; a.out_r1 = (uint32_t)f.out_r1;
+  a.min0 = f.black0; a.range0 = f.white0 - f.black0;                       // gofloat.rs:86-89
+  a.xoff = f.xoff; a.yoff = f.yoff;
+  a.tolab = make_tolab(f.mul4, f.cm12);
+  for (int i = 0; i < 9; ++i) a.rgbm.m[i] = f.rgbm9[i];
+  a.has_curve = f.has_curve; a.linear = f.linear;
+  if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
+  a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs);
+  a.gam_pairs = reinterpret_cast<const LutPair *>(f.gam_pairs);
+
+  // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
+  const uint32_t waves_per_block = 16;
+  const uint32_t grid = (uint32_t)(f.num_cus > 0 ? f.num_cus : 256);
+  const uint32_t total_waves = grid * waves_per_block;
+  const uint32_t w4 = (a.W + 3) / 4;
+  a.n_strips = (w4 + 63) / 64;
+  a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;
+  const uint32_t nrows = a.out_r1 - a.out_r0;
+  uint32_t segs = total_waves / a.n_strips;
+  if (segs < 1) segs = 1;
+  if (segs > nrows) segs = nrows;
+  a.n_segs = segs;
+  const uint32_t tasks = a.n_strips * a.n_segs;
+  const unsigned blocks = (tasks + waves_per_block - 1) / waves_per_block;
+
+  const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
+  if (!f.src_is_u16) {
+    if (f.out_type == 0) launch_fused_t<float, true, 0>(a, blocks, s);
+    else if (f.out_type == 1) launch_fused_t<float, true, 1>(a, blocks, s);
+    else launch_fused_t<float, true, 2>(a, blocks, s);
+  } else if (vec) {
+    if (f.out_type == 0) launch_fused_t<uint16_t, true, 0>(a, blocks, s);
+    else if (f.out_type == 1) launch_fused_t<uint16_t, true, 1>(a, blocks, s);
+    else launch_fused_t<uint16_t, true, 2>(a, blocks, s);
+  } else {
+    if (f.out_type == 0) launch_fused_t<uint16_t, false, 0>(a, blocks, s);
+    else if (f.out_type == 1) launch_fused_t<uint16_t, false, 1>(a, blocks, s);
+    else launch_fused_t<uint16_t, false, 2>(a, blocks, s);
+  }
+  return 0;
+}
+
+}  // namespace ipk

@@ -1,0 +1,60 @@
+// ipk_launch.hpp -- host-callable launchers of the gfx950 kernels (defined in ipk_kernels.hip).
+// Plain C++ declarations so the C-ABI layer (ipk_api.cpp) never sees device code.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+#include "ipk_host.hpp"
+
+namespace ipk {
+
+typedef Spline SplineHost;
+
+template <typename T>
+void launch_gofloat_cfa(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float black0, float white0,
+                        float *dst, hipStream_t s);
+template <typename T>
+void launch_gofloat_mono(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float black0, float white0,
+                         float *dst4, hipStream_t s);
+template <typename T>
+void launch_gofloat_rgb(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, const float *black4, const float *white4,
+                        float *dst4, hipStream_t s);
+void launch_gofloat_other_u8(const uint8_t *src, size_t owidth, size_t x, size_t y, size_t w, size_t h,
+                             const void *gamma_reverse_pairs, float *dst4, hipStream_t s);
+void launch_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float *dst4, hipStream_t s);
+
+void launch_demosaic_full(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
+                          const uint32_t *lookups_dev, float *dst4, hipStream_t s);
+
+template <typename T>
+void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
+                             int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,
+                             const uint8_t *cfa48_dev, T *dst, hipStream_t s);
+
+void launch_tolab(const float *src4, size_t npix, const float *mul4, const float *cm12, const void *lab_pairs, float *dst3,
+                  int num_cus, hipStream_t s);
+void launch_basecurve(const float *src3, size_t npix, const SplineHost &sp, float *dst3, int num_cus, hipStream_t s);
+void launch_fromlab(const float *src3, size_t npix, const float *m9, float *dst3, int num_cus, hipStream_t s);
+void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst, int num_cus, hipStream_t s);
+void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
+                   float *dst3, hipStream_t s);
+void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s);
+void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s);
+
+struct FusedLaunch {
+  const void *src; void *dst;
+  bool src_is_u16, src_aligned4;
+  size_t width, height, owidth;
+  size_t row_off, out_r0, out_r1;
+  float black0, white0;
+  int xoff, yoff;
+  const float *mul4, *cm12, *rgbm9;
+  int has_curve, linear;
+  const SplineHost *spline;
+  int out_type;                  // 0 f32, 1 u8, 2 u16
+  const void *lab_pairs, *gam_pairs;
+  int num_cus;
+};
+int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);
+
+}  // namespace ipk

@@ -1,0 +1,307 @@
+/*
+ * imagepipe_amd.h -- C ABI of the MI355X (gfx950) raw->sRGB hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one function of the reference
+ * (pedrocr/imagepipe 0.5.0) behind its own `ImageOp::run` / `Pipeline::run` surface.  Each
+ * declaration cites the reference interface (file:line, relative to the reference root) it
+ * stands in for.  INTEGRATION.md shows the Rust `extern "C"` block and the `impl ImageOp`
+ * wrappers a maintainer would add.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  An OpBuffer (src/buffer.rs:5-11) crosses the boundary as
+ *     (data, width, height, colors[, monochrome]): f32, row-major, channel-interleaved,
+ *     data[(row*width+col)*colors+c].
+ *   - `ipk_*` entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t, NULL =
+ *     default stream).  They return as soon as the work is enqueued; buffers stay in HBM between
+ *     stages.  Inputs are never modified (the reference's Arc<OpBuffer> inputs are immutable).
+ *   - `ipk_host_*` entry points take HOST pointers, are synchronous at return (Rayon-join
+ *     semantics of the reference ops) and do the H2D/D2H copies themselves.
+ *   - Return value: IPK_OK (0), IPK_NOOP (1, "the op returned its input Arc unchanged": the
+ *     output buffer was not written) or a negative ipk_status.  There is no CPU fallback: without a
+ *     GPU every compute entry point fails with IPK_ERR_NO_DEVICE.
+ *   - Results are bit-identical to the reference CPU path on the same host libm (the 13-bit
+ *     lookup tables are built with the host's cbrtf/powf exactly as TransformLookup::new does).
+ */
+#ifndef IMAGEPIPE_AMD_H
+#define IMAGEPIPE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPK_API __attribute__((visibility("default")))
+
+typedef enum {
+  IPK_OK = 0,
+  IPK_NOOP = 1,
+  IPK_ERR_NOT_INIT = -1,
+  IPK_ERR_INVALID = -2,
+  IPK_ERR_HIP = -3,
+  IPK_ERR_NO_DEVICE = -4,
+  IPK_ERR_UNSUPPORTED = -5,
+  IPK_ERR_NOMEM = -6
+} ipk_status;
+
+/* rawloader::Orientation (call sites src/ops/transform.rs:25-36,58-66,106) */
+typedef enum {
+  IPK_OR_NORMAL = 0, IPK_OR_HFLIP = 1, IPK_OR_ROT180 = 2, IPK_OR_VFLIP = 3, IPK_OR_TRANSPOSE = 4,
+  IPK_OR_ROT90 = 5, IPK_OR_TRANSVERSE = 6, IPK_OR_ROT270 = 7, IPK_OR_UNKNOWN = 8
+} ipk_orientation;
+
+/* imagepipe::Rotation (src/ops/transform.rs:7-12) */
+typedef enum { IPK_ROT_NORMAL = 0, IPK_ROT_90 = 1, IPK_ROT_180 = 2, IPK_ROT_270 = 3 } ipk_rotation;
+
+/* element type of a raw source: RawImageData::Integer / ::Float (src/ops/gofloat.rs:94,132) and
+ * the 8/16-bit raster of ImageSource::Other (src/ops/gofloat.rs:171-201) */
+typedef enum { IPK_SRC_U16 = 0, IPK_SRC_F32 = 1, IPK_SRC_RGB8 = 2, IPK_SRC_RGB16 = 3 } ipk_src_type;
+
+/* what Pipeline::run / output_8bit / output_16bit hand back (src/pipeline.rs:311,377,424) */
+typedef enum { IPK_OUT_F32 = 0, IPK_OUT_U8 = 1, IPK_OUT_U16 = 2 } ipk_out_type;
+
+/* ---------------------------------------------------------------------------------------- */
+/* Context                                                                                  */
+/* ---------------------------------------------------------------------------------------- */
+
+/* Selects the HIP device, builds the three 8193-entry TransformLookup tables on the host with
+ * libm (src/color_conversions.rs:87-100,119-141 -- the reference's lazy_static initialisers) and
+ * uploads them.  Idempotent.  Fails with IPK_ERR_NO_DEVICE when no GPU is visible. */
+IPK_API int ipk_init(int device);
+IPK_API void ipk_shutdown(void);
+IPK_API int ipk_is_initialized(void);
+/* Human-readable description of the last failure on this thread (never NULL). */
+IPK_API const char *ipk_last_error(void);
+/* Number of compute units of the selected device (0 before ipk_init). */
+IPK_API int ipk_device_cus(void);
+
+/* Device memory / stream helpers for callers that do not bring their own allocator. */
+IPK_API int ipk_malloc(void **dptr, size_t bytes);
+IPK_API int ipk_free(void *dptr);
+IPK_API int ipk_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+IPK_API int ipk_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+IPK_API int ipk_stream_sync(void *stream);
+
+/* Host copies of the lookup tables the device uses (8193 floats each), for fixture checks.
+ * which: 0 XYZ_LAB_TRANSFORM, 1 SRGB_GAMMA_REVERSE, 2 SRGB_GAMMA_TRANSFORM
+ * (src/color_conversions.rs:120,126,134).  Works without a GPU. */
+IPK_API int ipk_lut_table(int which, float *out8193);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Host-side size / parameter maths (no GPU needed)                                          */
+/* ---------------------------------------------------------------------------------------- */
+
+/* OpGoFloat::size_image (src/ops/gofloat.rs:74-82): out4 = x, y, width, height.
+ * IPK_ERR_INVALID when owidth or oheight < 10 (the reference underflows/panics). */
+IPK_API int ipk_size_image(size_t crop_top, size_t crop_right, size_t crop_bottom, size_t crop_left,
+                           size_t owidth, size_t oheight, size_t *out4);
+/* scaling::calculate_scaling_total (src/scaling.rs:8-23) */
+IPK_API int ipk_calculate_scaling_total(size_t width, size_t height, size_t maxwidth, size_t maxheight,
+                                        float *scale, size_t *nwidth, size_t *nheight);
+/* OpToLab's normalize_wbs (src/ops/colorspaces.rs:12-27) */
+IPK_API int ipk_normalize_wbs(const float *vals4, float *out4);
+/* SplineFunc::new (src/ops/curves.rs:68-124): pts = npts (x,y) pairs; arrays sized >= npts+2.
+ * Returns the knot count (>= 2) or a negative status. */
+IPK_API int ipk_spline_new(const float *pts, int npts, float *px, float *py, float *c1s, float *c2s, float *c3s);
+/* OpRotateCrop::calc_size (src/ops/rotatecrop.rs:111-163); params5 = crop_top, crop_right,
+ * crop_bottom, crop_left, rotation */
+IPK_API int ipk_rotatecrop_calc_size(const float *params5, float input_ratio, size_t width, size_t height,
+                                     int reverse, size_t *nwidth, size_t *nheight);
+/* rawloader CFA::shift as used by RawImage::cropped_cfa() (call site src/ops/demosaic.rs:13) */
+IPK_API int ipk_cfa_shift(const char *pattern, int x, int y, char *out /* >= strlen+1 */);
+/* Orientation::to_flips / from_flips (call sites src/ops/transform.rs:58-66,106);
+ * flips3 = transpose, flip_x, flip_y */
+IPK_API int ipk_orientation_to_flips(int orientation, int *flips3);
+IPK_API int ipk_orientation_from_flips(int transpose, int flip_x, int flip_y);
+/* The orientation OpTransform::run composes from (rotation, fliph, flipv) (src/ops/transform.rs:58-66) */
+IPK_API int ipk_transform_orientation(int rotation, int fliph, int flipv);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Stage kernels, device pointers (one per reference op)               */
+/* ---------------------------------------------------------------------------------------- */
+
+/* OpGoFloat::run_raw, CFA / cpp==1 branch (src/ops/gofloat.rs:122-130 u16, :158-166 f32):
+ * dst[row][col] = min((src[owidth*(row+y)+x+col] - black0) / (white0-black0), 1), 1 channel. */
+IPK_API int ipk_gofloat_cfa_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                float black0, float white0, float *dst, void *stream);
+IPK_API int ipk_gofloat_cfa_f32(const float *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                float black0, float white0, float *dst, void *stream);
+/* monochrome branch (src/ops/gofloat.rs:95-108, :133-144): 4-channel (v,v,v,0) */
+IPK_API int ipk_gofloat_mono_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                 float black0, float white0, float *dst4, void *stream);
+IPK_API int ipk_gofloat_mono_f32(const float *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                 float black0, float white0, float *dst4, void *stream);
+/* cpp==3 branch (src/ops/gofloat.rs:109-120, :145-156): per-channel levels, 4-channel out.
+ * black4/white4 are HOST arrays. */
+IPK_API int ipk_gofloat_rgb_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                const float *black4, const float *white4, float *dst4, void *stream);
+IPK_API int ipk_gofloat_rgb_f32(const float *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                const float *black4, const float *white4, float *dst4, void *stream);
+/* OpGoFloat::run_other (src/ops/gofloat.rs:171-201): RGB8 via expand_srgb_gamma(input8bit),
+ * RGB16 via input16bit; 4-channel out */
+IPK_API int ipk_gofloat_other_u8(const uint8_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                 float *dst4, void *stream);
+IPK_API int ipk_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                  float *dst4, void *stream);
+
+/* demosaic::full (src/ops/demosaic.rs:67-119).  `cfa` is the (cropped) pattern string OpDemosaic
+ * holds (src/ops/demosaic.rs:4-22).  1-channel in, 4-channel RGBE out. */
+IPK_API int ipk_demosaic_full(const float *src, size_t width, size_t height, const char *cfa, float *dst4, void *stream);
+/* Row-band form for frames sharded across GPUs: `src` holds image rows [src_row0, src_row0+src_rows)
+ * (the band plus its 1-row halos where they exist), output rows [out_row0, out_row0+out_rows) are
+ * written to dst4 (row 0 of dst4 = image row out_row0).  Taps outside [0,img_height) are skipped
+ * exactly as at the frame edge (src/ops/demosaic.rs:103-104). */
+IPK_API int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, size_t src_row0, size_t src_rows,
+                                   size_t out_row0, size_t out_rows, const char *cfa, float *dst4, void *stream);
+
+/* scaling::transform_buffer<T> (src/scaling.rs:51-130): corner points are (x,y) isize pairs;
+ * cfa NULL = None.  components <= 4. */
+IPK_API int ipk_transform_buffer_f32(const float *src, size_t width, size_t height,
+                                     int64_t tlx, int64_t tly, int64_t trx, int64_t try_, int64_t blx, int64_t bly,
+                                     size_t nwidth, size_t nheight, size_t components, const char *cfa, float *dst, void *stream);
+IPK_API int ipk_transform_buffer_u8(const uint8_t *src, size_t width, size_t height,
+                                    int64_t tlx, int64_t tly, int64_t trx, int64_t try_, int64_t blx, int64_t bly,
+                                    size_t nwidth, size_t nheight, size_t components, const char *cfa, uint8_t *dst, void *stream);
+IPK_API int ipk_transform_buffer_u16(const uint16_t *src, size_t width, size_t height,
+                                     int64_t tlx, int64_t tly, int64_t trx, int64_t try_, int64_t blx, int64_t bly,
+                                     size_t nwidth, size_t nheight, size_t components, const char *cfa, uint16_t *dst, void *stream);
+/* scaling::scaled_demosaic (src/scaling.rs:132-145) and scale_down_opbuf (:147-160) */
+IPK_API int ipk_scaled_demosaic(const float *src, size_t width, size_t height, const char *cfa,
+                                size_t nwidth, size_t nheight, float *dst4, void *stream);
+IPK_API int ipk_scale_down_opbuf(const float *src4, size_t width, size_t height,
+                                 size_t nwidth, size_t nheight, float *dst4, void *stream);
+/* OpDemosaic::run dispatch (src/ops/demosaic.rs:27-61).  colors = 1 or 4.  dst4 must hold
+ * max(width*height, demosaic_width*demosaic_height)*4 floats.  IPK_NOOP = pass-through.
+ * out_width / out_height receive the result size. */
+IPK_API int ipk_demosaic_run(const float *src, size_t width, size_t height, size_t colors, const char *cfa,
+                             size_t demosaic_width, size_t demosaic_height, float *dst4,
+                             size_t *out_width, size_t *out_height, void *stream);
+
+/* OpRotateCrop::run (src/ops/rotatecrop.rs:39-64).  Call with dst == NULL to query the output
+ * size; IPK_NOOP when the op is a no-op or rejects its crops (returns the input). */
+IPK_API int ipk_rotatecrop(const float *src, size_t width, size_t height, size_t colors, const float *params5,
+                           float *dst, size_t *out_width, size_t *out_height, void *stream);
+
+/* OpToLab::run (src/ops/colorspaces.rs:89-112) = camera_to_lab per pixel
+ * (src/color_conversions.rs:42-55,156-169).  wb_coeffs[4] and cam_to_xyz_normalized[12]
+ * ([[f32;4];3] row-major) are HOST arrays; normalize_wbs is applied here as in run(). 4ch -> 3ch. */
+IPK_API int ipk_tolab(const float *src4, size_t width, size_t height, int monochrome,
+                      const float *wb_coeffs, const float *cam_to_xyz_normalized, float *dst3, void *stream);
+/* OpBaseCurve::run (src/ops/curves.rs:33-49): points = npoints HOST (x,y) pairs.  IPK_NOOP when
+ * the op early-outs (no points and |exposure| < 0.001). */
+IPK_API int ipk_basecurve(const float *src3, size_t width, size_t height, float exposure,
+                          const float *points, int npoints, float *dst3, void *stream);
+/* OpFromLab::run (src/ops/colorspaces.rs:127-137) = lab_to_rgb with XYZ_D65_33
+ * (src/color_conversions.rs:58-65,172-191) */
+IPK_API int ipk_fromlab(const float *src3, size_t width, size_t height, float *dst3, void *stream);
+/* OpGamma::run (src/ops/gamma.rs:16-26); IPK_NOOP when linear */
+IPK_API int ipk_gamma(const float *src, size_t width, size_t height, size_t colors, int linear, float *dst, void *stream);
+/* rotate_buffer (src/ops/transform.rs:87-144), 3-channel */
+IPK_API int ipk_rotate_buffer(const float *src3, size_t width, size_t height, int orientation,
+                              float *dst3, size_t *out_width, size_t *out_height, void *stream);
+/* OpTransform::run (src/ops/transform.rs:56-73); IPK_NOOP for Normal/Unknown */
+IPK_API int ipk_transform(const float *src3, size_t width, size_t height, int rotation, int fliph, int flipv,
+                          float *dst3, size_t *out_width, size_t *out_height, void *stream);
+/* the quantise loops of Pipeline::output_8bit/16bit (src/pipeline.rs:408-414, :455-461;
+ * output8bit/output16bit src/color_conversions.rs:323-330) */
+IPK_API int ipk_output8bit(const float *src, size_t n, uint8_t *dst, void *stream);
+IPK_API int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *stream);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Fused raw -> sRGB (gofloat + demosaic::full + tolab + basecurve + fromlab + gamma [+ quantise]) */
+/* ---------------------------------------------------------------------------------------- */
+
+/* Everything the ops between OpGoFloat and OpGamma read, for a CFA raw source at full scale with
+ * a no-op rotatecrop (the default Pipeline::run on a RawImage). */
+typedef struct {
+  int src_type;                    /* IPK_SRC_U16 or IPK_SRC_F32 */
+  size_t owidth;                   /* RawImage.width: row pitch of src in elements */
+  size_t x, y, width, height;      /* OpGoFloat::size_image result */
+  float black0, white0;            /* blacklevels[0], whitelevels[0] (gofloat.rs:126) */
+  char cfa[160];                   /* cropped CFA pattern (OpDemosaic.cfa) */
+  float wb_coeffs[4];              /* OpToLab.wb_coeffs (normalised again inside, colorspaces.rs:100) */
+  float cam_to_xyz_normalized[12]; /* OpToLab.cam_to_xyz_normalized, [[f32;4];3] row-major */
+  float exposure;                  /* OpBaseCurve.exposure */
+  int npoints;                     /* OpBaseCurve.points */
+  float points[128];
+  int linear;                      /* PipelineSettings.linear: skip OpGamma */
+  int out_type;                    /* IPK_OUT_F32 (Pipeline::run), IPK_OUT_U8 / IPK_OUT_U16 (+ output8bit/16bit) */
+  /* row band (multi-GPU sharding of one frame); all zero = whole frame.  `src` then points at
+   * image row band_src_row0 (in cropped coordinates, i.e. row y+band_src_row0 of the sensor), and
+   * only output rows [band_out_row0, band_out_row0+band_out_rows) are produced into dst. */
+  size_t band_src_row0, band_src_rows, band_out_row0, band_out_rows;
+} ipk_fused_params;
+
+/* src: device pointer to the sensor data (element (0,0) of the uncropped frame, or of the band's
+ * first source row); dst: device pointer to width*rows*3 elements of out_type.
+ * Fails with IPK_ERR_UNSUPPORTED for CFA patterns that are not one of the four 2x2 Bayer phases
+ * (callers then run the staged ops). */
+IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Pipeline driver: Pipeline::run / output_8bit / output_16bit for one source                */
+/* (src/pipeline.rs:311-375, :377-422, :424-469), cache == None                              */
+/* ---------------------------------------------------------------------------------------- */
+
+/* The fields of ImageSource + PipelineOps + PipelineSettings the hot path reads. */
+typedef struct {
+  int src_type;                    /* ipk_src_type */
+  size_t width, height;            /* RawImage.width/height or raster dims */
+  int cpp;                         /* RawImage.cpp (1 or 3); ignored for RGB8/RGB16 */
+  int is_cfa;                      /* OpGoFloat.is_cfa */
+  char cfa[160];                   /* OpDemosaic.cfa = cropped_cfa() ("" for Other) */
+  size_t crop_top, crop_right, crop_bottom, crop_left;   /* OpGoFloat crops */
+  float blacklevels[4], whitelevels[4];
+  float rotatecrop[5];             /* OpRotateCrop: crop_top, crop_right, crop_bottom, crop_left, rotation */
+  float cam_to_xyz_normalized[12];
+  float wb_coeffs[4];
+  float exposure; int npoints; float points[128];        /* OpBaseCurve */
+  int rotation, fliph, flipv;      /* OpTransform */
+  size_t maxwidth, maxheight;      /* PipelineSettings */
+  int linear;
+  int allow_fused;                 /* 1: use ipk_raw_to_srgb when legal (cache==None); 0: always staged */
+} ipk_pipeline_desc;
+
+/* Size negotiation of Pipeline::run (src/pipeline.rs:314-338): demosaic_{w,h} as stored in the
+ * settings and the final output size.  No GPU needed. */
+IPK_API int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h,
+                               size_t *final_w, size_t *final_h);
+/* Runs the ops in the reference's fixed order (src/pipeline.rs:155-164,364-372) on a DEVICE source
+ * buffer and writes the result (final_w*final_h*3 elements of out_type) to the DEVICE buffer dst.
+ * out_type IPK_OUT_F32 = Pipeline::run with d->linear; IPK_OUT_U8 = output_8bit (forces
+ * linear=false, pipeline.rs:405); IPK_OUT_U16 = output_16bit (forces linear=true, :452).
+ * *used_fused (may be NULL) reports which path ran. */
+IPK_API int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type,
+                             int *used_fused, void *stream);
+/* Same with HOST source and destination buffers; synchronous. */
+IPK_API int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Host-pointer forms of the stage kernels: what a Rust `impl ImageOp::run` binds when it keeps   */
+/* its OpBuffers in host Vec<f32>s.  Same arguments as the device forms, minus the stream.       */
+/* ---------------------------------------------------------------------------------------- */
+IPK_API int ipk_host_gofloat_cfa_u16(const uint16_t *src, size_t owidth, size_t oheight, size_t x, size_t y, size_t width, size_t height,
+                                     float black0, float white0, float *dst);
+IPK_API int ipk_host_gofloat_cfa_f32(const float *src, size_t owidth, size_t oheight, size_t x, size_t y, size_t width, size_t height,
+                                     float black0, float white0, float *dst);
+IPK_API int ipk_host_demosaic_full(const float *src, size_t width, size_t height, const char *cfa, float *dst4);
+IPK_API int ipk_host_transform_buffer_f32(const float *src, size_t width, size_t height,
+                                          int64_t tlx, int64_t tly, int64_t trx, int64_t try_, int64_t blx, int64_t bly,
+                                          size_t nwidth, size_t nheight, size_t components, const char *cfa, float *dst);
+IPK_API int ipk_host_tolab(const float *src4, size_t width, size_t height, int monochrome,
+                           const float *wb_coeffs, const float *cam_to_xyz_normalized, float *dst3);
+IPK_API int ipk_host_basecurve(const float *src3, size_t width, size_t height, float exposure,
+                               const float *points, int npoints, float *dst3);
+IPK_API int ipk_host_fromlab(const float *src3, size_t width, size_t height, float *dst3);
+IPK_API int ipk_host_gamma(const float *src, size_t width, size_t height, size_t colors, int linear, float *dst);
+IPK_API int ipk_host_rotate_buffer(const float *src3, size_t width, size_t height, int orientation,
+                                   float *dst3, size_t *out_width, size_t *out_height);
+IPK_API int ipk_host_output8bit(const float *src, size_t n, uint8_t *dst);
+IPK_API int ipk_host_output16bit(const float *src, size_t n, uint16_t *dst);
+IPK_API int ipk_host_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGEPIPE_AMD_H */

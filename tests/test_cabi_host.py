@@ -1,0 +1,171 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/imagepipe_amd.h declares, its
+host-side maths (sizes, curves, tables, CFA, orientation) agrees with the oracle, and every compute entry point
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from imagepipe_amd import _lib
+    return _lib.load()
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "imagepipe_amd.h")).read()
+    return sorted(set(re.findall(r"IPK_API\s+[\w\s\*]+?\b(ipk_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    from imagepipe_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 60
+    for s in syms:
+        assert hasattr(L, s), "libimagepipe_amd.so does not export " + s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+
+
+def test_compute_entry_points_fail_loudly_without_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert L.ipk_init(0) == -4                                  # IPK_ERR_NO_DEVICE
+    assert b"no HIP device" in L.ipk_last_error()
+    assert L.ipk_is_initialized() == 0
+    buf = (C.c_float * 64)()
+    assert L.ipk_fromlab(buf, 4, 4, buf, None) == -1            # IPK_ERR_NOT_INIT
+    assert L.ipk_host_fromlab(buf, 4, 4, buf) == -1
+    assert L.ipk_host_gamma(buf, 4, 4, 3, 0, buf) == -1
+    assert b"no CPU fallback" in L.ipk_last_error()
+    import imagepipe_amd
+    with pytest.raises(imagepipe_amd.IpkError):
+        imagepipe_amd.init()
+
+
+def test_lut_tables_match_oracle_and_fixture(L, orc):
+    for which in range(3):
+        t = np.empty(8193, np.float32)
+        assert L.ipk_lut_table(which, t.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        assert np.array_equal(t.view(np.uint32), orc.lut_table(which).view(np.uint32))
+
+
+def test_size_image_and_scaling(L, orc):
+    rng = np.random.default_rng(1)
+    out = (C.c_size_t * 4)()
+    for _ in range(300):
+        ow, oh = int(rng.integers(10, 300)), int(rng.integers(10, 300))
+        cr = [int(v) for v in rng.integers(0, 200, 4)]
+        assert L.ipk_size_image(*cr, ow, oh, out) == 0
+        assert tuple(out) == orc.size_image(*cr, ow, oh)
+    assert L.ipk_size_image(0, 0, 0, 0, 9, 100, out) == -2
+    s, nw, nh = C.c_float(), C.c_size_t(), C.c_size_t()
+    for _ in range(2000):
+        w, h = int(rng.integers(1, 12000)), int(rng.integers(1, 12000))
+        mw, mh = int(rng.integers(0, 3) and rng.integers(1, 9000)), int(rng.integers(0, 3) and rng.integers(1, 9000))
+        L.ipk_calculate_scaling_total(w, h, mw, mh, C.byref(s), C.byref(nw), C.byref(nh))
+        es, ew, eh = orc.calculate_scaling_total(w, h, mw, mh)
+        assert (np.float32(s.value), nw.value, nh.value) == (np.float32(es), ew, eh)
+
+
+def test_normalize_wbs(L, orc):
+    for wb in [(2.0, 1.0, 1.5, np.nan), (0.0, 2.0, np.inf, 1e-40), (1.9, 0.93, 1.4, 0.0), (-1, -2, 3, 4), (1, 0, 1, 1)]:
+        a = (C.c_float * 4)(*wb); o = (C.c_float * 4)()
+        L.ipk_normalize_wbs(a, o)
+        assert np.array_equal(np.array(o[:], np.float32).view(np.uint32), orc.normalize_wbs(wb).view(np.uint32))
+
+
+def test_spline_new(L, orc):
+    for pts in [[], [(0.5, 0.6)], [(0.0, 0.2)], [(1.0, 0.8)], [(0.25, 0.2), (0.5, 0.6), (0.75, 0.8)], [(0.7, 0.2), (0.3, 0.9)],
+                [(0.1, 0.05), (0.2, 0.3), (0.3, 0.25), (0.6, 0.7), (0.9, 0.95)]]:
+        p = np.asarray(pts, np.float32).ravel()
+        n = p.size // 2
+        arr = (C.c_float * max(2, p.size))(*p)
+        outs = [(C.c_float * (n + 2))() for _ in range(5)]
+        k = L.ipk_spline_new(arr, n, *outs)
+        want = orc.spline_new(pts)
+        assert k == want[0].size
+        for got, w, m in zip(outs, want, [k, k, k, k - 1, k - 1]):
+            assert np.array_equal(np.array(got[:m], np.float32).view(np.uint32), w.view(np.uint32))
+
+
+def test_rotatecrop_calc_size(L, orc):
+    rng = np.random.default_rng(2)
+    ow, oh = C.c_size_t(), C.c_size_t()
+    for _ in range(3000):
+        p = [float(np.float32(v)) for v in (rng.uniform(0, 0.45, 4).tolist() + [rng.uniform(0, 1.1)])]
+        if rng.integers(0, 4) == 0:
+            p[4] = 0.0
+        w, h = int(rng.integers(1, 9000)), int(rng.integers(1, 9000))
+        ratio = float(np.float32(w) / np.float32(h))
+        for rev in (0, 1):
+            L.ipk_rotatecrop_calc_size((C.c_float * 5)(*p), ratio, w, h, rev, C.byref(ow), C.byref(oh))
+            assert (ow.value, oh.value) == orc.rotatecrop_calc_size(p, w, h, bool(rev), ratio)
+
+
+def test_cfa_shift_and_orientation(L, orc):
+    out = C.create_string_buffer(200)
+    xt = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+    for pat in ["RGGB", "GBRG", xt, "RGGBRGGBGRBGGRBG"]:
+        for x in range(7):
+            for y in range(7):
+                assert L.ipk_cfa_shift(pat.encode(), x, y, out) == 0
+                assert out.value.decode() == orc.cfa_shift(pat, x, y)
+    assert orc.cfa_shift("RGGB", 1, 0) == "GRBG" and orc.cfa_shift("RGGB", 0, 1) == "GBRG" and orc.cfa_shift("RGGB", 1, 1) == "BGGR"
+    assert L.ipk_cfa_shift(b"RGXB", 0, 0, out) == -2
+    f = (C.c_int * 3)()
+    for o in range(9):
+        L.ipk_orientation_to_flips(o, f)
+        assert tuple(bool(v) for v in f) == orc.orientation_to_flips(o)
+    for rot in range(4):
+        for fh in (0, 1):
+            for fv in (0, 1):
+                assert L.ipk_transform_orientation(rot, fh, fv) == orc.transform_orientation(rot, fh, fv)
+
+
+def _desc(**kw):
+    from imagepipe_amd._lib import PipelineDesc
+    d = PipelineDesc()
+    d.src_type = 2; d.width = 128; d.height = 64; d.cpp = 3
+    for k, v in kw.items():
+        if k == "rotatecrop":
+            d.rotatecrop[:] = v
+        else:
+            setattr(d, k, v)
+    return d
+
+
+@pytest.mark.parametrize("kw,size", [({}, (128, 64)), (dict(maxwidth=128), (128, 64)), (dict(maxwidth=256), (128, 64)),
+                                     (dict(maxwidth=64), (64, 32)), (dict(maxwidth=64, rotation=1), (64, 128)),
+                                     (dict(maxwidth=32, rotation=1), (32, 64)), (dict(maxwidth=256, rotation=1), (64, 128)),
+                                     (dict(maxwidth=64, crop_top=1, crop_bottom=1, crop_left=1, crop_right=1), (64, 31)),
+                                     (dict(maxwidth=64, rotatecrop=[0.1, 0.1, 0.1, 0.1, 0.0]), (64, 32))])
+def test_pipeline_sizes_maxsize_cases(L, kw, size):
+    """tests/maxsize_test.rs:31-90 through the product's own size negotiation"""
+    d = _desc(**kw)
+    a, b, c, e = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert L.ipk_pipeline_sizes(C.byref(d), C.byref(a), C.byref(b), C.byref(c), C.byref(e)) == 0
+    assert (c.value, e.value) == size
+
+
+def test_pipeline_sizes_random_vs_oracle(L, orc):
+    rng = np.random.default_rng(3)
+    a, b, c, e = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    for _ in range(1500):
+        w, h = int(rng.integers(10, 7000)), int(rng.integers(10, 5000))
+        kw = dict(width=w, height=h, maxwidth=int(rng.integers(0, 2) * rng.integers(1, 4000)), maxheight=int(rng.integers(0, 2) * rng.integers(1, 4000)),
+                  rotation=int(rng.integers(0, 4)), crop_top=int(rng.integers(0, 50)), crop_left=int(rng.integers(0, 50)),
+                  crop_right=int(rng.integers(0, 50)), crop_bottom=int(rng.integers(0, 50)))
+        rc = [float(np.float32(v)) for v in rng.uniform(0, 0.3, 4)] + [float(np.float32(rng.uniform(0, 1.0)))]
+        if rng.integers(0, 2):
+            rc = [0.0] * 5
+        d = _desc(rotatecrop=rc, **kw)
+        assert L.ipk_pipeline_sizes(C.byref(d), C.byref(a), C.byref(b), C.byref(c), C.byref(e)) == 0
+        od = orc.make_pipeline(np.zeros((h, w, 3), np.uint8), maxwidth=kw["maxwidth"], maxheight=kw["maxheight"], rotation=kw["rotation"],
+                               crops=(kw["crop_top"], kw["crop_right"], kw["crop_bottom"], kw["crop_left"]), rotatecrop=rc)
+        assert ((a.value, b.value), (c.value, e.value)) == orc.pipeline_sizes(od)

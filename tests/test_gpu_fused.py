@@ -1,0 +1,262 @@
+"""GPU parity of the fused raw->sRGB kernel and of the Pipeline driver (fused and staged) against the CPU oracle's
+Pipeline::run restatement, at sizes the oracle finishes in seconds; plus size-independent properties at the
+BASELINE.json frame sizes.  Bar: bit-exact (0 ULP; BASELINE.json allows 1 ULP f32)."""
+import numpy as np
+import pytest
+
+import util
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+CFAS = ["RGGB", "BGGR", "GRBG", "GBRG"]
+
+
+@pytest.fixture(scope="module")
+def ipa():
+    import imagepipe_amd
+    imagepipe_amd.init(0)
+    return imagepipe_amd
+
+
+def _raw(ipa, raw, cfa="RGGB", is_float=False, **kw):
+    import torch
+    h, w = raw.shape[:2]
+    data = torch.from_numpy(np.ascontiguousarray(raw, np.float32).ravel()).cuda() if is_float else ipa.upload_u16(raw)
+    kw.setdefault("blacklevels", [util.BLACK] * 4); kw.setdefault("whitelevels", [util.WHITE] * 4)
+    kw.setdefault("wb_coeffs", util.WB); kw.setdefault("cam_to_xyz_normalized", util.cam_matrix())
+    return ipa.RawImage(width=w, height=h, data=data, cfa=cfa, is_float=is_float, **kw)
+
+
+def _oracle_desc(orc, raw, cfa="RGGB", crops=(0, 0, 0, 0), **kw):
+    kw.setdefault("blacklevels", [util.BLACK] * 4); kw.setdefault("whitelevels", [util.WHITE] * 4)
+    kw.setdefault("wb_coeffs", util.WB); kw.setdefault("cam_to_xyz_normalized", util.cam_matrix())
+    return orc.make_pipeline(raw, cfa=orc.cfa_shift(cfa, crops[3], crops[0]) if cfa else "", crops=crops, **kw)
+
+
+@pytest.mark.parametrize("cfa", CFAS)
+@pytest.mark.parametrize("shape", [(10, 10), (11, 13), (64, 256), (97, 257), (130, 1030), (33, 2500)])
+def test_fused_u16_vs_oracle(ipa, orc, cfa, shape):
+    h, w = shape
+    raw = util.noise_u16(util.SEED + h * w, h, w)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa))
+    got = pipe.run()
+    assert pipe.last_used_fused and (got.width, got.height, got.colors) == (w, h, 3)
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa)), "fused u16 %s %dx%d" % (cfa, w, h))
+
+
+@pytest.mark.parametrize("shape", [(12, 16), (65, 259), (100, 1000)])
+def test_fused_f32_vs_oracle_with_specials(ipa, orc, shape):
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 31, h, w).astype(np.float32) + util.uniform_f32(util.SEED + 32, h * w).reshape(h, w)
+    raw.ravel()[7: 7 + util.SPECIALS.size] = util.SPECIALS * np.float32(16383.0)       # NaN, inf, negatives, denormals in the mosaic
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "GRBG", is_float=True))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "GRBG")), "fused f32 specials")
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_fused_256x256_config0(ipa, orc, kind):
+    """BASELINE.json configs[0]: 256x256 synthetic RGGB -> sRGB; the reference-shaped CPU path is the oracle."""
+    raw = (util.noise_u16 if kind == "noise" else util.smooth_u16)(util.SEED, 256, 256)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw))
+    assert_bits_equal(pipe.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw)), "config0 " + kind)
+    w, h, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(h, w, 3), orc.pipeline_output_8bit(_oracle_desc(orc, raw)))
+    w, h, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(h, w, 3), orc.pipeline_output_16bit(_oracle_desc(orc, raw)))
+
+
+@pytest.mark.parametrize("crops", [(0, 0, 0, 0), (1, 0, 0, 0), (0, 0, 0, 1), (3, 2, 5, 7), (2, 3, 4, 6)])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_fused_crops_shift_the_cfa(ipa, orc, crops, is_float):
+    """sensor crops: gofloat's offsets + cropped_cfa() phase; odd crops also exercise unaligned u16 rows"""
+    h, w = 70, 135
+    raw = util.noise_u16(util.SEED + 33, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "RGGB", is_float=is_float, crops=crops))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, src, "RGGB", crops=crops)), "fused crops %r" % (crops,))
+
+
+@pytest.mark.parametrize("points,exposure,linear", [([(0.5, 0.6)], 0.0, False), ([], 0.0, False), ([(0.5, 0.6)], 0.7, True),
+                                                    ([(0.2, 0.1), (0.4, 0.5), (0.6, 0.55), (0.8, 0.9)], -0.3, False), ([], 1.0, False)])
+def test_fused_curve_and_linear_variants(ipa, orc, points, exposure, linear):
+    h, w = 48, 300
+    raw = util.smooth_u16(util.SEED + 34, h, w)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw))
+    pipe.ops.basecurve.points = points; pipe.ops.basecurve.exposure = exposure
+    pipe.globals.settings.linear = linear
+    got = pipe.run()
+    assert pipe.last_used_fused
+    want = orc.pipeline_run(_oracle_desc(orc, raw, points=points, exposure=exposure, linear=linear))
+    assert_bits_equal(got.numpy(), want, "fused curve variant")
+
+
+def test_fused_equals_staged_equals_ops(ipa, orc):
+    """three routes to the same frame: fused kernel, the C driver's staged kernels, the Python op-by-op loop"""
+    h, w = 120, 516
+    raw = util.noise_u16(util.SEED + 35, h, w)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "BGGR"))
+    fused = pipe.run().numpy(); assert pipe.last_used_fused
+    pipe.allow_fused = False
+    staged = pipe.run().numpy(); assert not pipe.last_used_fused
+    ops = pipe.run_ops().numpy()
+    want = orc.pipeline_run(_oracle_desc(orc, raw, "BGGR"))
+    assert_bits_equal(fused, want, "fused"); assert_bits_equal(staged, want, "staged"); assert_bits_equal(ops, want, "op loop")
+
+
+def test_fused_row_bands_equal_whole_frame(ipa, orc):
+    """multi-GPU band form: each band (with its 1-row halos) reproduces its rows of the whole frame"""
+    import torch
+    h, w = 90, 260
+    raw = util.noise_u16(util.SEED + 36, h, w)
+    want = orc.pipeline_run(_oracle_desc(orc, raw, "GBRG"))
+    dev = ipa.upload_u16(raw)
+    for r0, r1 in [(0, 30), (30, 31), (31, 77), (77, 90)]:
+        s0, s1 = max(0, r0 - 1), min(h, r1 + 1)
+        band = dev[s0 * w: s1 * w].clone()
+        out = ipa.raw_to_srgb(band, width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="GBRG",
+                              wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix(), band=(s0, s1 - s0, r0, r1 - r0))
+        torch.cuda.synchronize()
+        assert_bits_equal(out.cpu().numpy().reshape(r1 - r0, w, 3), want[r0:r1], "band %d..%d" % (r0, r1))
+
+
+def test_fused_rejects_non_bayer(ipa):
+    import torch
+    src = torch.zeros(36 * 36, dtype=torch.float32, device="cuda")
+    with pytest.raises(ipa.IpkError):
+        ipa.raw_to_srgb(src, width=36, height=36, cfa="GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG")
+
+
+# ---------------------------------------------------------------------------------------------
+# staged driver on the paths the fused kernel does not take
+# ---------------------------------------------------------------------------------------------
+XTRANS = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+
+
+@pytest.mark.parametrize("case", [dict(cfa=XTRANS, shape=(72, 108)), dict(cfa=XTRANS, shape=(96, 144), maxwidth=36),
+                                  dict(cfa="RGGB", shape=(80, 120), maxwidth=40), dict(cfa="RGGB", shape=(80, 120), maxwidth=90),
+                                  dict(cfa="RGGB", shape=(80, 120), maxheight=33), dict(cfa="RGBE", shape=(40, 60)),
+                                  dict(cfa="RGGB", shape=(60, 90), rotation=1), dict(cfa="RGGB", shape=(60, 90), rotation=3, fliph=True, maxwidth=30),
+                                  dict(cfa="RGGB", shape=(60, 90), rotation=2, flipv=True),
+                                  dict(cfa="RGGB", shape=(100, 100), rotatecrop=(0.1, 0.05, 0.2, 0.0, 0.0)),
+                                  dict(cfa="RGGB", shape=(100, 120), rotatecrop=(0.0, 0.0, 0.0, 0.0, 0.3), maxwidth=64),
+                                  dict(cfa="GRBG", shape=(64, 64), crops=(1, 1, 1, 1), maxwidth=20)])
+def test_staged_pipeline_vs_oracle(ipa, orc, case):
+    case = dict(case)
+    h, w = case.pop("shape"); cfa = case.pop("cfa")
+    crops = case.pop("crops", (0, 0, 0, 0))
+    raw = util.noise_u16(util.SEED + 37, h, w)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa, crops=crops))
+    okw = {}
+    if "rotatecrop" in case:
+        rc = case.pop("rotatecrop")
+        pipe.ops.rotatecrop.crop_top, pipe.ops.rotatecrop.crop_right, pipe.ops.rotatecrop.crop_bottom, pipe.ops.rotatecrop.crop_left, pipe.ops.rotatecrop.rotation = rc
+        okw["rotatecrop"] = rc
+    for k in ("rotation", "fliph", "flipv"):
+        if k in case:
+            v = case.pop(k); setattr(pipe.ops.transform, k, v); okw[k] = v
+    for k in ("maxwidth", "maxheight"):
+        if k in case:
+            v = case.pop(k); setattr(pipe.globals.settings, k, v); okw[k] = v
+    desc = _oracle_desc(orc, raw, cfa, crops=crops, **okw)
+    assert pipe.sizes() == orc.pipeline_sizes(desc)
+    assert pipe.negotiate() == orc.pipeline_sizes(desc)
+    want = orc.pipeline_run(desc)
+    got = pipe.run()
+    assert not pipe.last_used_fused
+    assert (got.height, got.width) == want.shape[:2]
+    assert_bits_equal(got.numpy(), want, "staged driver")
+    assert_bits_equal(pipe.run_ops().numpy(), want, "op loop")
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/roundtrip_test.rs on the GPU: all 2^24 RGB8 colours through output_8bit (slow path)
+# ---------------------------------------------------------------------------------------------
+def test_roundtrip_8bit_slowpath_gpu(ipa):
+    import torch
+    a = np.arange(256, dtype=np.uint8)
+    r, g, b = np.meshgrid(a, a, a, indexing="ij")
+    img = np.stack([r.ravel(), g.ravel(), b.ravel()], axis=1).reshape(4096, 4096, 3)
+    pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(4096, 4096, torch.from_numpy(img.ravel()).cuda(), bits=8))
+    w, h, o8 = pipe.output_8bit()
+    assert (w, h) == (4096, 4096)
+    assert np.array_equal(o8.cpu().numpy().reshape(4096, 4096, 3), img)
+
+
+def test_roundtrip_16bit_slowpath_gpu(ipa):
+    """strided 16-bit colours (89/97/101) through output_16bit: identity (tests/roundtrip_test.rs:37-84)"""
+    r16 = np.arange(0, 65536, 89, dtype=np.uint32).astype(np.uint16)
+    g16 = np.arange(0, 65536, 97, dtype=np.uint32).astype(np.uint16)
+    b16 = np.arange(0, 65536, 101, dtype=np.uint32).astype(np.uint16)
+    g, b = np.meshgrid(g16, b16, indexing="ij")
+    plane = np.stack([g.ravel(), b.ravel()], axis=1)
+    per = 38                                                       # 38 r-planes of 676*649 triples ~ one 4096x4096 block
+    for i in range(0, r16.size, per):
+        rs = r16[i: i + per]
+        t = np.concatenate([np.concatenate([np.full((plane.shape[0], 1), r, np.uint16), plane], axis=1) for r in rs])
+        n = t.shape[0]
+        wdt = 4096; hgt = (n + wdt - 1) // wdt
+        img = np.zeros((hgt * wdt, 3), np.uint16); img[:n] = t
+        img = img.reshape(hgt, wdt, 3)
+        pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(wdt, hgt, ipa.upload_u16(img), bits=16))
+        w, h, o16 = pipe.output_16bit()
+        assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hgt, wdt, 3), img)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size frames: size-independent properties (the oracle is too slow to run per test at 100 MP)
+# ---------------------------------------------------------------------------------------------
+def _tile_frame(tile, reps_y, reps_x):
+    return np.tile(tile, (reps_y, reps_x))
+
+
+@pytest.mark.parametrize("H,W", [(4000, 6000), (10000, 10000)])
+def test_full_size_frame_is_periodic_like_its_input(ipa, orc, H, W):
+    """A frame built by tiling an even-sized tile is periodic, so the output interior must repeat the oracle's
+    output of a 3x3 tiling of that tile (every interior pixel sees the same 3x3 neighbourhood), at 24 MP and 100 MP."""
+    import torch
+    th, tw = 50, 40
+    tile = util.noise_u16(util.SEED + 38, th, tw)
+    frame = _tile_frame(tile, H // th, W // tw)
+    assert frame.shape == (H, W)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, frame))
+    out = pipe.run()
+    assert pipe.last_used_fused
+    got = out.data.view(H, W, 3)
+    small = orc.pipeline_run(_oracle_desc(orc, _tile_frame(tile, 3, 3)))
+    centre = torch.from_numpy(small[th:2 * th, tw:2 * tw].copy()).cuda()
+    # interior tiles: compare a spread of them bit-for-bit on the device
+    ys = sorted(set([1, 2, H // th // 2, H // th - 2]))
+    xs = sorted(set([1, 2, W // tw // 2, W // tw - 2]))
+    for ty in ys:
+        for tx in xs:
+            blk = got[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            assert torch.equal(blk.view(torch.int32), centre.view(torch.int32)), (ty, tx)
+    # every interior tile equals the first interior tile (whole-frame periodicity), checked in one shot
+    inner = got[th:H - th, tw:W - tw].reshape(H // th - 2, th, W // tw - 2, tw, 3)
+    ref = inner[0:1, :, 0:1]
+    assert bool((inner.view(torch.int32) == ref.view(torch.int32)).all())
+    # frame edges: the first/last tile rows and columns against the oracle's 3x3 result edges
+    edge = orc.pipeline_run(_oracle_desc(orc, _tile_frame(tile, 3, 3)))
+    assert torch.equal(got[:th, :tw].view(torch.int32), torch.from_numpy(edge[:th, :tw].copy()).cuda().view(torch.int32))
+    assert torch.equal(got[H - th:, W - tw:].view(torch.int32), torch.from_numpy(edge[2 * th:, 2 * tw:].copy()).cuda().view(torch.int32))
+    assert torch.equal(got[:th, W - tw:].view(torch.int32), torch.from_numpy(edge[:th, 2 * tw:].copy()).cuda().view(torch.int32))
+    assert torch.equal(got[H - th:, :tw].view(torch.int32), torch.from_numpy(edge[2 * th:, :tw].copy()).cuda().view(torch.int32))
+
+
+def test_full_size_strip_matches_oracle(ipa, orc):
+    """24 MP noise frame: three horizontal strips (top edge, middle, bottom edge) bit-identical to the oracle run on
+    just those rows plus their halo rows"""
+    import torch
+    H, W = 4000, 6000
+    frame = util.noise_u16(util.SEED + 39, H, W)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, frame))
+    got = pipe.run().data.view(H, W, 3)
+    for r0, r1 in [(0, 24), (1988, 2012), (3976, 4000)]:
+        s0, s1 = max(0, r0 - 2), min(H, r1 + 2)              # even offsets keep the CFA phase
+        sub = orc.pipeline_run(_oracle_desc(orc, frame[s0:s1]))
+        assert_bits_equal(got[r0:r1].cpu().numpy(), sub[r0 - s0: r1 - s0], "strip %d..%d" % (r0, r1))

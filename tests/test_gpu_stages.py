@@ -1,0 +1,422 @@
+"""GPU parity, stage by stage: every staged HIP kernel (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact f32 / integer outputs (BASELINE.json's stated tolerance is 1 ULP f32;
+these tests assert 0 ULP, any-NaN == any-NaN)."""
+import numpy as np
+import pytest
+
+import util
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ipa():
+    import imagepipe_amd
+    imagepipe_amd.init(0)
+    return imagepipe_amd
+
+
+def _globals(ipa, img=None, **settings):
+    g = ipa.PipelineGlobals(img)
+    for k, v in settings.items():
+        setattr(g.settings, k, v)
+    return g
+
+
+# ---------------------------------------------------------------------------------------------
+# gofloat
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("white", [1023.0, 4095.0, 16383.0])
+@pytest.mark.parametrize("crops", [(0, 0, 0, 0), (3, 5, 7, 2)])
+def test_gofloat_cfa_u16(ipa, orc, white, crops):
+    h, w = 37, 53
+    raw = util.noise_u16(util.SEED + 1, h, w, maxval=int(white) + 500)     # some values above white (clip) and below black (negative)
+    img = ipa.RawImage(w, h, ipa.upload_u16(raw), cfa="RGGB", crops=crops, blacklevels=[64.0] * 4, whitelevels=[white] * 4)
+    op = ipa.OpGoFloat(img)
+    out = op.run(_globals(ipa, img)).numpy()
+    x, y, ww, hh = orc.size_image(*crops, w, h)
+    assert (x, y, ww, hh) == op.size_image(w, h)
+    want = orc.gofloat_cfa(raw, x, y, ww, hh, 64.0, white)
+    assert (want < 0).any() and (want == 1.0).any()
+    assert_bits_equal(out, want, "gofloat cfa u16")
+
+
+def test_gofloat_cfa_f32(ipa, orc):
+    import torch
+    h, w = 31, 44
+    raw = np.concatenate([util.uniform_f32(util.SEED + 2, h * w - util.SPECIALS.size, -100.0, 20000.0), util.SPECIALS]).reshape(h, w)
+    img = ipa.RawImage(w, h, torch.from_numpy(raw.ravel()).cuda(), cfa="RGGB", crops=(1, 2, 3, 4), blacklevels=[512.0] * 4,
+                       whitelevels=[16383.0] * 4, is_float=True)
+    out = ipa.OpGoFloat(img).run(_globals(ipa, img)).numpy()
+    x, y, ww, hh = orc.size_image(1, 2, 3, 4, w, h)
+    assert_bits_equal(out, orc.gofloat_cfa(raw, x, y, ww, hh, 512.0, 16383.0), "gofloat cfa f32")
+
+
+def test_gofloat_mono_and_rgb(ipa, orc):
+    import torch
+    h, w = 23, 29
+    raw = util.noise_u16(util.SEED + 3, h, w, 4095)
+    img = ipa.RawImage(w, h, ipa.upload_u16(raw), cfa="", blacklevels=[64.0] * 4, whitelevels=[4000.0] * 4)
+    out = ipa.OpGoFloat(img).run(_globals(ipa, img))
+    assert out.monochrome and out.colors == 4
+    assert_bits_equal(out.numpy(), orc.gofloat_mono(raw, 0, 0, w, h, 64.0, 4000.0), "gofloat mono")
+    rgb = util.noise_u16(util.SEED + 4, h, w * 3, 4095).reshape(h, w, 3)
+    bl, wl = [64.0, 70.0, 80.0, 0.0], [4000.0, 3900.0, 4095.0, 0.0]
+    img = ipa.RawImage(w, h, ipa.upload_u16(rgb), cpp=3, cfa="", blacklevels=bl, whitelevels=wl)
+    assert_bits_equal(ipa.OpGoFloat(img).run(_globals(ipa, img)).numpy(), orc.gofloat_rgb(rgb, 0, 0, w, h, bl, wl), "gofloat rgb")
+    rgbf = rgb.astype(np.float32) + np.float32(0.25)
+    img = ipa.RawImage(w, h, torch.from_numpy(rgbf.ravel()).cuda(), cpp=3, cfa="", blacklevels=bl, whitelevels=wl, is_float=True)
+    assert_bits_equal(ipa.OpGoFloat(img).run(_globals(ipa, img)).numpy(), orc.gofloat_rgb(rgbf, 0, 0, w, h, bl, wl), "gofloat rgb f32")
+
+
+def test_gofloat_other(ipa, orc):
+    import torch
+    h, w = 16, 64
+    rgb8 = (util.splitmix64(util.SEED + 5, h * w * 3) & np.uint64(255)).astype(np.uint8).reshape(h, w, 3)
+    rgb8.ravel()[:256] = np.arange(256, dtype=np.uint8)
+    img = ipa.OtherImage(w, h, torch.from_numpy(rgb8.ravel()).cuda(), bits=8)
+    assert_bits_equal(ipa.OpGoFloat(img).run(_globals(ipa, img)).numpy(), orc.gofloat_other(rgb8, 0, 0, w, h), "gofloat other u8")
+    rgb16 = (util.splitmix64(util.SEED + 6, h * w * 3) & np.uint64(65535)).astype(np.uint16).reshape(h, w, 3)
+    img = ipa.OtherImage(w, h, ipa.upload_u16(rgb16), bits=16)
+    assert_bits_equal(ipa.OpGoFloat(img).run(_globals(ipa, img)).numpy(), orc.gofloat_other(rgb16, 0, 0, w, h), "gofloat other u16")
+
+
+# ---------------------------------------------------------------------------------------------
+# demosaic::full (parity unpinned by the reference's tests: oracle + hand-derived answers)
+# ---------------------------------------------------------------------------------------------
+XTRANS = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+CFAS = ["RGGB", "BGGR", "GRBG", "GBRG", "RGBE", "ERBG", XTRANS, "RGGBRGGBGRBGGRBG"]
+
+
+def _demosaic(ipa, cfa, buf, nw=0, nh=0):
+    op = ipa.OpDemosaic(None); op.cfa = cfa
+    return op.run(_globals(ipa, None, demosaic_width=nw, demosaic_height=nh), ipa.OpBuffer.from_numpy(buf))
+
+
+@pytest.mark.parametrize("cfa", CFAS)
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (10, 10), (49, 97), (64, 256)])
+def test_demosaic_full_vs_oracle(ipa, orc, cfa, shape):
+    h, w = shape
+    buf = util.uniform_f32(util.SEED + 7, h * w, -0.05, 1.0).reshape(h, w)
+    buf.ravel()[: min(buf.size, util.SPECIALS.size)] = util.SPECIALS[: min(buf.size, util.SPECIALS.size)]
+    out = _demosaic(ipa, cfa, buf)
+    assert (out.width, out.height, out.colors) == (w, h, 4)
+    assert_bits_equal(out.numpy(), orc.demosaic_full(cfa, buf), "demosaic full %s %dx%d" % (cfa[:4], w, h))
+
+
+@pytest.mark.parametrize("cfa", ["RGGB", "GBRG", XTRANS])
+def test_demosaic_constant_mosaic_gives_constant_rgb(ipa, cfa):
+    out = _demosaic(ipa, cfa, np.full((24, 36), 0.375, np.float32)).numpy()
+    assert np.all(out[..., :3] == np.float32(0.375)) and np.all(out[..., 3] == 0.0)
+
+
+def test_demosaic_impulse_known_answers(ipa):
+    """Hand-derived: a single 1.0 at an R, G or B site of an RGGB mosaic, interior, corner and edge.
+    Same-colour neighbours are discarded (demosaic.rs:87), out-of-image taps skipped (:103-104)."""
+    def run(r, c, h=8, w=8):
+        m = np.zeros((h, w), np.float32); m[r, c] = 1.0
+        return _demosaic(ipa, "RGGB", m).numpy()
+    o = run(4, 4)                       # R site, interior
+    assert o[4, 4].tolist() == [1.0, 0.0, 0.0, 0.0]
+    assert o[4, 3].tolist() == [0.5, 0.0, 0.0, 0.0] and o[3, 4].tolist() == [0.5, 0.0, 0.0, 0.0]   # G neighbours: R = (l+r)/2 or (u+d)/2
+    assert o[3, 3].tolist() == [0.25, 0.0, 0.0, 0.0]                                               # B neighbour: R = 4 corners / 4
+    assert o[4, 2].tolist() == [0.0, 0.0, 0.0, 0.0]                                                # next R site ignores same colour
+    o = run(0, 0)                       # R site in the corner: the B site (1,1) still has all four corners in the image
+    assert o[0, 0].tolist() == [1.0, 0.0, 0.0, 0.0] and o[1, 1].tolist() == [0.25, 0.0, 0.0, 0.0]
+    assert o[0, 1].tolist() == [0.5, 0.0, 0.0, 0.0] and o[1, 0].tolist() == [0.5, 0.0, 0.0, 0.0]
+    o = run(0, 1)                       # G site on the top edge; R site (0,0) averages 3 in-image G neighbours: (0,1),(1,0) and none above
+    assert o[0, 1][1] == 1.0 and o[0, 0][1] == np.float32(1.0) / np.float32(2.0)
+    assert o[1, 1][1] == 0.25 and o[0, 2][1] == np.float32(1.0) / np.float32(3.0)
+    o = run(7, 7)                       # B site in the bottom-right corner: R site (6,6) sees it among 4 in-image corners;
+    #                                     G (7,6) / (6,7) average their two in-image B neighbours
+    assert o[7, 7].tolist() == [0.0, 0.0, 1.0, 0.0] and o[6, 6][2] == 0.25 and o[7, 6][2] == 0.5 and o[6, 7][2] == 0.5
+
+
+def test_demosaic_band_equals_full(ipa, orc):
+    """Row-band form (multi-GPU sharding): bands with 1-row halos reproduce the whole-frame result."""
+    import ctypes as C
+    import torch
+    h, w = 50, 70
+    buf = util.uniform_f32(util.SEED + 8, h * w).reshape(h, w)
+    want = orc.demosaic_full(XTRANS, buf)
+    dev = torch.from_numpy(buf.ravel()).cuda()
+    for r0, r1 in [(0, 13), (13, 30), (30, 50)]:
+        s0, s1 = max(0, r0 - 1), min(h, r1 + 1)
+        band = dev[s0 * w: s1 * w].contiguous()
+        out = torch.empty((r1 - r0) * w * 4, dtype=torch.float32, device="cuda")
+        rc = ipa.lib().ipk_demosaic_full_band(C.c_void_p(band.data_ptr()), w, h, s0, s1 - s0, r0, r1 - r0, XTRANS.encode(),
+                                              C.c_void_p(out.data_ptr()), None)
+        assert rc == 0, ipa.lib().ipk_last_error()
+        torch.cuda.synchronize()
+        assert_bits_equal(out.cpu().numpy().reshape(r1 - r0, w, 4), want[r0:r1], "band %d..%d" % (r0, r1))
+
+
+# ---------------------------------------------------------------------------------------------
+# transform_buffer family
+# ---------------------------------------------------------------------------------------------
+def _transform(ipa, src, w, h, tl, tr, bl, nw, nh, comps, cfa=None):
+    import ctypes as C
+    import torch
+    dt = {np.dtype(np.float32): (torch.float32, "f32"), np.dtype(np.uint8): (torch.uint8, "u8"), np.dtype(np.uint16): (torch.int16, "u16")}[src.dtype]
+    dev = torch.from_numpy(src.view(np.int16).ravel() if src.dtype == np.uint16 else src.ravel()).cuda()
+    out = torch.empty(nw * nh * comps, dtype=dt[0], device="cuda")
+    fn = getattr(ipa.lib(), "ipk_transform_buffer_" + dt[1])
+    rc = fn(C.c_void_p(dev.data_ptr()), w, h, tl[0], tl[1], tr[0], tr[1], bl[0], bl[1], nw, nh, comps,
+            cfa.encode() if cfa else None, C.c_void_p(out.data_ptr()), None)
+    assert rc == 0, ipa.lib().ipk_last_error()
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    return (o.view(np.uint16) if src.dtype == np.uint16 else o).reshape(nh, nw, comps)
+
+
+@pytest.mark.parametrize("cfa,shape,nshape", [("RGGB", (64, 96), (16, 24)), ("RGGB", (61, 97), (20, 31)), (XTRANS, (72, 108), (18, 27)),
+                                               (XTRANS, (90, 90), (30, 30)), ("BGGR", (40, 40), (20, 20)), ("RGGB", (33, 47), (1, 1)),
+                                               ("RGGB", (33, 47), (5, 1)), ("RGGB", (33, 47), (1, 6))])
+def test_scaled_demosaic_vs_oracle(ipa, orc, cfa, shape, nshape):
+    h, w = shape; nh, nw = nshape
+    buf = util.uniform_f32(util.SEED + 9, h * w, -0.05, 1.0).reshape(h, w)
+    got = _transform(ipa, buf, w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, 4, cfa)
+    assert_bits_equal(got, orc.scaled_demosaic(cfa, buf, nw, nh), "scaled_demosaic")
+
+
+def test_scaled_demosaic_constant_planes(ipa):
+    """Hand-derived: a mosaic that is constant per colour scales to exactly those constants."""
+    h, w = 48, 64
+    m = np.zeros((h, w), np.float32)
+    m[0::2, 0::2] = 0.25; m[0::2, 1::2] = 0.5; m[1::2, 0::2] = 0.5; m[1::2, 1::2] = 0.75
+    got = _transform(ipa, m, w, h, (0, 0), (w - 1, 0), (0, h - 1), 16, 12, 4, "RGGB")
+    assert np.all(got[..., 0] == 0.25) and np.all(got[..., 1] == 0.5) and np.all(got[..., 2] == 0.75) and np.all(got[..., 3] == 0.0)
+
+
+@pytest.mark.parametrize("comps", [1, 3, 4])
+def test_scale_down_f32_vs_oracle(ipa, orc, comps):
+    h, w, nh, nw = 57, 83, 19, 29
+    buf = util.uniform_f32(util.SEED + 10, h * w * comps).reshape(h, w, comps)
+    got = _transform(ipa, buf, w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, comps)
+    assert_bits_equal(got, orc.transform_buffer(buf, w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, comps), "scale_down")
+
+
+def test_transform_buffer_rotated_corners(ipa, orc):
+    h, w = 60, 80
+    buf = util.uniform_f32(util.SEED + 11, h * w * 4).reshape(h, w, 4)
+    for tl, tr, bl, nw, nh in [((10, 5), (60, 20), (2, 40), 50, 35), ((70, 50), (10, 50), (70, 5), 30, 20), ((0, 0), (0, 0), (0, 0), 4, 4)]:
+        got = _transform(ipa, buf, w, h, tl, tr, bl, nw, nh, 4)
+        assert_bits_equal(got, orc.transform_buffer(buf, w, h, tl, tr, bl, nw, nh, 4), "rotated transform")
+
+
+def test_scaling_noop_u16(ipa):
+    """src/scaling.rs:189-203 on the GPU"""
+    data = (np.arange(150 * 150 * 3, dtype=np.uint32) & 0xFFFF).astype(np.uint16).reshape(150, 150, 3)
+    assert np.array_equal(_transform(ipa, data, 150, 150, (0, 0), (149, 0), (0, 149), 150, 150, 3), data)
+
+
+def test_scale_down_srgb_u8_u16_vs_oracle(ipa, orc):
+    h, w, nh, nw = 64, 96, 21, 32
+    img8 = (util.splitmix64(util.SEED + 12, h * w * 3) & np.uint64(255)).astype(np.uint8).reshape(h, w, 3)
+    assert np.array_equal(_transform(ipa, img8, w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, 3), orc.scale_down_srgb(img8, nw, nh))
+    img16 = (util.splitmix64(util.SEED + 13, h * w * 3) & np.uint64(65535)).astype(np.uint16).reshape(h, w, 3)
+    assert np.array_equal(_transform(ipa, img16, w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, 3), orc.scale_down_srgb(img16, nw, nh))
+
+
+@pytest.mark.parametrize("case", [("RGGB", (40, 60), (40, 60)), ("RGGB", (40, 60), (30, 45)), ("RGGB", (40, 60), (10, 15)),
+                                  (XTRANS, (60, 90), (25, 37)), (XTRANS, (60, 90), (15, 22))])
+def test_demosaic_run_dispatch(ipa, orc, case):
+    """OpDemosaic::run's four branches (demosaic.rs:41-60)"""
+    cfa, (h, w), (nh, nw) = case
+    buf = util.uniform_f32(util.SEED + 14, h * w).reshape(h, w)
+    branch, want = orc.demosaic_run(cfa, buf, nw, nh)
+    out = _demosaic(ipa, cfa, buf, nw, nh)
+    assert (out.height, out.width) == want.shape[:2]
+    assert_bits_equal(out.numpy(), want, "demosaic run branch %d" % branch)
+    # 4-colour input: pass-through or scale_down_opbuf
+    buf4 = util.uniform_f32(util.SEED + 15, h * w * 4).reshape(h, w, 4)
+    branch, want = orc.demosaic_run(cfa, buf4, nw, nh)
+    inb = ipa.OpBuffer.from_numpy(buf4)
+    op = ipa.OpDemosaic(None); op.cfa = cfa
+    out = op.run(_globals(ipa, None, demosaic_width=nw, demosaic_height=nh), inb)
+    if branch == 0:
+        assert out is inb
+    else:
+        assert_bits_equal(out.numpy(), want, "demosaic run 4ch")
+
+
+# ---------------------------------------------------------------------------------------------
+# rotatecrop (src/ops/rotatecrop.rs:170-270 restated on the GPU + oracle parity)
+# ---------------------------------------------------------------------------------------------
+def _rc(ipa, params, buf):
+    op = ipa.OpRotateCrop()
+    op.crop_top, op.crop_right, op.crop_bottom, op.crop_left, op.rotation = params
+    return op.run(_globals(ipa), ipa.OpBuffer.from_numpy(buf))
+
+
+@pytest.mark.parametrize("crops,size,first", [((0.1, 0, 0, 0), (100, 90), 3000), ((0, 0, 0.1, 0), (100, 90), 0), ((0.1, 0, 0.1, 0), (100, 80), 3000),
+                                               ((0, 0, 0, 0.1), (90, 100), 30), ((0, 0.1, 0, 0), (90, 100), 0), ((0, 0.1, 0, 0.1), (80, 100), 30),
+                                               ((0.1, 0.1, 0.1, 0.1), (80, 80), 3030)])
+def test_rotatecrop_reference_cases(ipa, orc, crops, size, first):
+    buf = np.arange(100 * 100 * 3, dtype=np.float32).reshape(100, 100, 3)
+    out = _rc(ipa, list(crops) + [0.0], buf)
+    assert (out.width, out.height) == size
+    got = out.numpy()
+    assert got.ravel()[0] == buf.ravel()[first]
+    assert_bits_equal(got, orc.rotatecrop_run(list(crops) + [0.0], buf), "rotatecrop crop")
+
+
+@pytest.mark.parametrize("rot,size", [(0.5, (141, 141)), (1.0, (100, 100)), (0.2, None), (0.77, None)])
+def test_rotatecrop_rotation(ipa, orc, rot, size):
+    buf = util.uniform_f32(util.SEED + 16, 100 * 100 * 4).reshape(100, 100, 4)
+    out = _rc(ipa, [0.05, 0.0, 0.1, 0.02, rot] if size is None else [0, 0, 0, 0, rot], buf)
+    want = orc.rotatecrop_run([0.05, 0.0, 0.1, 0.02, rot] if size is None else [0, 0, 0, 0, rot], buf)
+    if size:
+        assert (out.width, out.height) == size
+    assert_bits_equal(out.numpy(), want, "rotatecrop rotation")
+
+
+def test_rotatecrop_noop_returns_input(ipa):
+    inb = ipa.OpBuffer.from_numpy(np.zeros((12, 12, 4), np.float32))
+    assert ipa.OpRotateCrop().run(_globals(ipa), inb) is inb
+
+
+# ---------------------------------------------------------------------------------------------
+# point-wise stages
+# ---------------------------------------------------------------------------------------------
+def _rgbe_inputs(n, seed):
+    v = util.uniform_f32(seed, n * 4, -0.1, 1.3).reshape(-1, 4)
+    v[:, 3] = 0.0
+    sp = util.SPECIALS
+    k = sp.size
+    assert n >= 3 * k
+    v[:k, 0] = sp; v[k:2 * k, 1] = sp; v[2 * k:3 * k, 2] = sp
+    v[5, 3] = 0.7; v[6, 3] = np.nan
+    return v
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_tolab_vs_oracle(ipa, orc, mono):
+    h, w = 64, 96
+    buf = _rgbe_inputs(h * w, util.SEED + 20).reshape(h, w, 4)
+    op = ipa.OpToLab(None)
+    op.wb_coeffs = list(util.WB); op.cam_to_xyz_normalized = util.cam_matrix()
+    out = op.run(_globals(ipa), ipa.OpBuffer.from_numpy(buf, monochrome=mono))
+    want = orc.tolab(buf, util.WB, util.cam_matrix(), monochrome=mono)
+    assert np.isfinite(want).any() and (orc.lib() is not None)
+    assert_bits_equal(out.numpy(), want, "tolab mono=%s" % mono)
+
+
+def test_tolab_wb_edge_cases(ipa, orc):
+    buf = _rgbe_inputs(4096, util.SEED + 21).reshape(64, 64, 4)
+    for wb in [(0.0, 1.0, np.inf, 1e-40), (2.5, 2.0, 1.5, 0.5), (-1.0, 3.0, 2.0, np.nan)]:
+        op = ipa.OpToLab(None); op.wb_coeffs = list(wb); op.cam_to_xyz_normalized = util.cam_matrix()
+        assert_bits_equal(op.run(_globals(ipa), ipa.OpBuffer.from_numpy(buf)).numpy(), orc.tolab(buf, wb, util.cam_matrix()), "tolab wb %r" % (wb,))
+
+
+CURVES = [[(0.5, 0.6)], [], [(0.0, 0.2)], [(1.0, 0.8)], [(0.25, 0.2), (0.5, 0.6), (0.75, 0.8)],
+          [(0.1, 0.05), (0.2, 0.3), (0.3, 0.25), (0.6, 0.7), (0.9, 0.95)], [(0.5, 0.5), (0.5, 0.7)], [(0.7, 0.2), (0.3, 0.9)]]
+
+
+@pytest.mark.parametrize("points", CURVES)
+@pytest.mark.parametrize("exposure", [0.0, 0.5, -1.25])
+def test_basecurve_vs_oracle(ipa, orc, points, exposure):
+    h, w = 32, 64
+    buf = util.uniform_f32(util.SEED + 22, h * w * 3, -0.2, 1.2).reshape(h, w, 3)
+    flat = buf.reshape(-1, 3)
+    flat[: util.SPECIALS.size, 0] = util.SPECIALS
+    knots = np.array([p[0] for p in points] + [0.0, 1.0], np.float32)
+    flat[100: 100 + knots.size, 0] = knots                                  # exact knot hits
+    op = ipa.OpBaseCurve(None); op.points = points; op.exposure = exposure
+    inb = ipa.OpBuffer.from_numpy(buf)
+    out = op.run(_globals(ipa), inb)
+    want = orc.basecurve(buf, exposure, points)
+    if not points and abs(exposure) < 0.001:
+        assert out is inb
+    else:
+        assert_bits_equal(out.numpy(), want, "basecurve")
+
+
+def test_spline_reference_cases(ipa):
+    """src/ops/curves.rs:165-188 on the GPU kernel"""
+    def interp(points, vals):
+        op = ipa.OpBaseCurve(None); op.points = points; op.exposure = 0.01    # exposure 0.01 only to defeat the no-points early-out
+        buf = np.zeros((1, len(vals), 3), np.float32); buf[0, :, 0] = vals
+        return op.run(_globals(ipa), ipa.OpBuffer.from_numpy(buf)).numpy()[0, :, 0]
+    assert interp([], [0.0, 1.0, 1.5, -0.2]).tolist() == [0.0, 1.0, 1.0, 0.0]
+    assert interp([(0.0, 0.2)], [0.0])[0] == np.float32(0.2) * np.exp2(np.float32(0.01))
+    assert interp([(1.0, 0.8)], [1.0])[0] == np.float32(0.8) * np.exp2(np.float32(0.01))
+
+
+def test_fromlab_vs_oracle(ipa, orc):
+    h, w = 64, 96
+    buf = util.uniform_f32(util.SEED + 23, h * w * 3, -0.2, 1.2).reshape(h, w, 3)
+    buf.reshape(-1)[: util.SPECIALS.size] = util.SPECIALS
+    out = ipa.OpFromLab().run(_globals(ipa), ipa.OpBuffer.from_numpy(buf))
+    assert_bits_equal(out.numpy(), orc.fromlab(buf), "fromlab")
+
+
+def test_gamma_vs_oracle(ipa, orc):
+    h, w = 64, 96
+    buf = util.uniform_f32(util.SEED + 24, h * w * 3, -0.2, 1.2).reshape(h, w, 3)
+    buf.reshape(-1)[: util.SPECIALS.size] = util.SPECIALS
+    inb = ipa.OpBuffer.from_numpy(buf)
+    assert_bits_equal(ipa.OpGamma().run(_globals(ipa), inb).numpy(), orc.gamma(buf), "gamma")
+    assert ipa.OpGamma().run(_globals(ipa, None, linear=True), inb) is inb
+
+
+def test_gamma_every_table_cell(ipa, orc):
+    """all 8192 cells + their boundaries"""
+    k = np.arange(8192, dtype=np.float32)
+    vals = np.concatenate([k / np.float32(8191), (k + np.float32(0.5)) / np.float32(8191), np.nextafter(k / np.float32(8191), np.float32(2))])
+    vals = np.resize(vals, (64, 128, 3)).astype(np.float32)
+    assert_bits_equal(ipa.OpGamma().run(_globals(ipa), ipa.OpBuffer.from_numpy(vals)).numpy(), orc.gamma(vals), "gamma cells")
+
+
+def test_output_8_16bit_vs_oracle(ipa, orc):
+    import ctypes as C
+    import torch
+    v = np.concatenate([util.uniform_f32(util.SEED + 25, 100000, -0.1, 1.1), util.SPECIALS,
+                        np.arange(0, 65536, dtype=np.float32) / np.float32(65535), np.arange(0, 256, dtype=np.float32) / np.float32(255),
+                        (np.arange(0, 65536, dtype=np.float32) + np.float32(0.5)) / np.float32(65535)])
+    d = torch.from_numpy(v).cuda()
+    o8 = torch.empty(v.size, dtype=torch.uint8, device="cuda"); o16 = torch.empty(v.size, dtype=torch.int16, device="cuda")
+    assert ipa.lib().ipk_output8bit(C.c_void_p(d.data_ptr()), v.size, C.c_void_p(o8.data_ptr()), None) == 0
+    assert ipa.lib().ipk_output16bit(C.c_void_p(d.data_ptr()), v.size, C.c_void_p(o16.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(o8.cpu().numpy(), orc.output8bit(v))
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16), orc.output16bit(v))
+
+
+# ---------------------------------------------------------------------------------------------
+# transform / rotate_buffer (the nine goldens of src/ops/transform.rs:168-278 on the GPU)
+# ---------------------------------------------------------------------------------------------
+from test_oracle_reference_kats import F, ROTATE_GOLDENS, from_rgb_str_vec, orientation_id  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(ROTATE_GOLDENS))
+def test_rotate_goldens_gpu(ipa, orc, name):
+    import ctypes as C
+    import torch
+    src = from_rgb_str_vec(F)
+    d = torch.from_numpy(src.ravel()).cuda(); o = torch.empty(src.size, dtype=torch.float32, device="cuda")
+    ow, oh = C.c_size_t(), C.c_size_t()
+    rc = ipa.lib().ipk_rotate_buffer(C.c_void_p(d.data_ptr()), 8, 7, orientation_id(orc, name), C.c_void_p(o.data_ptr()), C.byref(ow), C.byref(oh), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = from_rgb_str_vec(ROTATE_GOLDENS[name])
+    assert (oh.value, ow.value) == want.shape[:2]
+    assert np.array_equal(o.cpu().numpy().reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("rot", [0, 1, 2, 3])
+@pytest.mark.parametrize("fh,fv", [(False, False), (True, False), (False, True), (True, True)])
+def test_transform_op_vs_oracle(ipa, orc, rot, fh, fv):
+    h, w = 37, 53
+    buf = util.uniform_f32(util.SEED + 26, h * w * 3).reshape(h, w, 3)
+    op = ipa.OpTransform(None); op.rotation, op.fliph, op.flipv = rot, fh, fv
+    inb = ipa.OpBuffer.from_numpy(buf)
+    out = op.run(_globals(ipa), inb)
+    o = orc.transform_orientation(rot, fh, fv)
+    if o in (orc.OR_NORMAL, orc.OR_UNKNOWN):
+        assert out is inb
+    else:
+        want = orc.rotate_buffer(buf, o)
+        assert (out.height, out.width) == want.shape[:2]
+        assert_bits_equal(out.numpy(), want, "transform")
