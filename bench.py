@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- megapixels/s of the full raw->sRGB pipe on a 100 MP f32 Bayer frame (BASELINE.json's metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One step = one pass of the hot path (Pipeline::run: gofloat + demosaic + tolab + basecurve + fromlab + gamma, fused)
+over one 10000x10000 synthetic RGGB f32 frame per GPU, input and output resident in HBM.  Frames are independent, so
+N GPUs each process their own frame with no data-path collective (weak scaling); value = all frames' pixels / max-rank time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+BYTES_PER_PX = 16.0            # algorithmic: 4 B mosaic sample in + 3 x 4 B RGB out
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=10000)
+    ap.add_argument("--height", type=int, default=10000)
+    ap.add_argument("--data", choices=["noise", "smooth"], default="noise")
+    ap.add_argument("--src", choices=["f32", "u16"], default="f32")
+    ap.add_argument("--out", choices=["f32", "u8", "u16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def synth_frame(torch, h, w, kind, seed):
+    """14-bit sensor values (black 512, white 16383) as f32, generated on the device."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    if kind == "noise":       # uniform in [0, 16383]: worst case for lookup-table locality
+        return torch.randint(0, 16384, (h, w), generator=g, device="cuda", dtype=torch.int32)
+    rr = torch.arange(h, device="cuda", dtype=torch.int32)[:, None]
+    cc = torch.arange(w, device="cuda", dtype=torch.int32)[None, :]
+    base = ((rr + cc) % 4096) * 4
+    n = torch.randint(0, 64, (h, w), generator=g, device="cuda", dtype=torch.int32)
+    return torch.clamp(base + n, max=16383)
+
+
+def main():
+    args = parse()
+    import torch
+    import imagepipe_amd as ipa
+    import util
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ipa.init(local_rank)
+
+    H, W = args.height, args.width
+    ints = synth_frame(torch, H, W, args.data, util.SEED + 2 + rank)
+    is_float = args.src == "f32"
+    src = ints.to(torch.float32).reshape(-1).contiguous() if is_float else ints.to(torch.int16).reshape(-1).contiguous()
+    del ints
+    out_type = {"f32": ipa.OUT_F32, "u8": ipa.OUT_U8, "u16": ipa.OUT_U16}[args.out]
+    out_dt = {"f32": torch.float32, "u8": torch.uint8, "u16": torch.int16}[args.out]
+    dst = torch.empty(H * W * 3, dtype=out_dt, device="cuda")
+    cm = util.cam_matrix()
+    plan = ipa.FusedPlan(width=W, height=H, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
+                         cam_to_xyz_normalized=cm, out_type=out_type)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.run(src, dst, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- correctness spot check against the CPU oracle (outside the timed region) ----
+    checked = None
+    if not args.no_check and rank == 0 and args.out == "f32":
+        import numpy as np
+        import oracle
+        step(); torch.cuda.synchronize()
+        rows = 12
+        top = src[: (rows + 2) * W].cpu().numpy().reshape(rows + 2, W)
+        desc = oracle.make_pipeline(top if is_float else top.view(np.uint16), cfa="RGGB", source_kind=1 if is_float else 0,
+                                    blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
+        want = oracle.pipeline_run(desc)[:rows]
+        util.assert_bits_equal(dst[: rows * W * 3].cpu().numpy().reshape(rows, W, 3), want, "bench spot check")
+        checked = "first %d rows bit-identical to the CPU oracle" % rows
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: avg kernel (+launch gap) per step
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    mp_total = world * args.steps * (H * W) / 1e6
+    value = mp_total / elapsed
+    in_b = 4.0 if is_float else 2.0
+    out_b = {"f32": 12.0, "u8": 3.0, "u16": 6.0}[args.out]
+    alg_bytes = (in_b + out_b) * H * W
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "megapixels/sec full raw->sRGB pipe, 100 MP f32 frame",
+        "value": round(value, 1), "unit": "MP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (%s, 14-bit RGGB sensor values, torch Philox seed 0x%X+rank)" % (args.data, util.SEED + 2),
+        "config": {"workload": "%dx%d (%.0f MP) synthetic RGGB Bayer %s mosaic -> fused gofloat+demosaic+tolab+basecurve+fromlab+gamma -> %s RGB, one frame per GPU per step"
+                               % (W, H, H * W / 1e6, args.src, args.out),
+                   "frame": [W, H], "src": args.src, "out": args.out, "frames_per_step": world, "sharding": "one independent frame per GPU, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "k_fused_bayer", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if checked:
+        result["parity_check"] = checked
+
+    # ---- CPU baseline: the oracle's reference-shaped pipeline (unfused, one task per row) on this host ----
+    if rank == 0 and not args.no_cpu_baseline:
+        import numpy as np
+        import oracle
+        ch, cw = 4000, 6000                                   # a 24 MP sample of the same synthetic workload
+        sample = util.noise_u16(util.SEED + 2, ch, cw).astype(np.float32) if args.data == "noise" else util.smooth_u16(util.SEED + 2, ch, cw).astype(np.float32)
+        desc = oracle.make_pipeline(sample, cfa="RGGB", source_kind=1, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                                    wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
+        oracle.pipeline_run(desc)                              # warm-up (tables, page faults)
+        n = 0; t0 = time.perf_counter()
+        while True:
+            oracle.pipeline_run(desc); n += 1
+            dt = time.perf_counter() - t0
+            if dt >= args.cpu_seconds or n >= 50:
+                break
+        result["cpu_baseline"] = {"value": round(n * ch * cw / 1e6 / dt, 1), "unit": "MP/s", "cores": oracle.max_threads(), "kind": "port",
+                                  "sample": "%d x 24 MP (6000x4000) frames of the same synthetic RGGB f32 workload through the C restatement of the "
+                                            "reference's unfused per-op pipeline (one OpenMP task per row); the Rust reference cannot be built here" % n}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ from ._lib import (IpkError, FusedParams, PipelineDesc, OUT_F32, OUT_U8, OUT_U16
 
 __all__ = ["init", "lib", "OpBuffer", "RawImage", "OtherImage", "PipelineSettings", "PipelineGlobals", "PipelineOps",
            "Pipeline", "OpGoFloat", "OpDemosaic", "OpRotateCrop", "OpToLab", "OpBaseCurve", "OpFromLab", "OpGamma",
-           "OpTransform", "raw_to_srgb", "IpkError"]
+           "OpTransform", "raw_to_srgb", "FusedPlan", "IpkError"]
 
 _initialized_device = None
 
@@ -519,33 +519,52 @@ class Pipeline:
         return w, h, data
 
 
-def raw_to_srgb(src: torch.Tensor, *, width, height, owidth=None, x=0, y=0, is_float=True, black0=0.0, white0=1.0,
-                cfa="RGGB", wb_coeffs=(1.0, 1.0, 1.0, float("nan")), cam_to_xyz_normalized=None, exposure=0.0,
-                points=((0.5, 0.6),), linear=False, out_type=OUT_F32, out: Optional[torch.Tensor] = None, band=None):
+class FusedPlan:
+    """A prepared ipk_fused_params: build once, launch many times (keeps the per-launch host cost to one C call)."""
+
+    def __init__(self, *, width, height, owidth=None, x=0, y=0, is_float=True, black0=0.0, white0=1.0,
+                 cfa="RGGB", wb_coeffs=(1.0, 1.0, 1.0, float("nan")), cam_to_xyz_normalized=None, exposure=0.0,
+                 points=((0.5, 0.6),), linear=False, out_type=OUT_F32, band=None):
+        init()
+        p = FusedParams()
+        p.src_type = SRC_F32 if is_float else SRC_U16
+        p.owidth = owidth if owidth is not None else width
+        p.x, p.y, p.width, p.height = x, y, width, height
+        p.black0, p.white0 = black0, white0
+        p.cfa = cfa.encode()
+        p.wb_coeffs[:] = list(wb_coeffs)
+        cm = SRGB_D65_43 if cam_to_xyz_normalized is None else np.asarray(cam_to_xyz_normalized, np.float32)
+        p.cam_to_xyz_normalized[:] = [float(v) for v in cm.ravel()]
+        p.exposure = exposure
+        pts = np.asarray(points, np.float32).ravel()
+        p.npoints = pts.size // 2
+        for i, v in enumerate(pts):
+            p.points[i] = v
+        p.linear = int(linear)
+        p.out_type = out_type
+        self.rows = height
+        if band is not None:
+            p.band_src_row0, p.band_src_rows, p.band_out_row0, p.band_out_rows = band
+            self.rows = band[3]
+        self.params = p
+        self.width = width
+        self.out_dtype = {OUT_F32: torch.float32, OUT_U8: torch.uint8, OUT_U16: torch.int16}[out_type]
+        self._fn = lib().ipk_raw_to_srgb
+        self._ref = C.byref(p)
+
+    def new_output(self):
+        return torch.empty(self.rows * self.width * 3, dtype=self.out_dtype, device="cuda")
+
+    def run(self, src: torch.Tensor, out: torch.Tensor, stream=None):
+        rc = self._fn(self._ref, src.data_ptr(), out.data_ptr(), stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        if rc < 0:
+            _lib.check(rc, "ipk_raw_to_srgb")
+        return out
+
+
+def raw_to_srgb(src: torch.Tensor, *, out: Optional[torch.Tensor] = None, **kw):
     """The fused kernel through the C ABI (ipk_raw_to_srgb); `band` = (src_row0, src_rows, out_row0, out_rows)."""
-    init()
-    p = FusedParams()
-    p.src_type = SRC_F32 if is_float else SRC_U16
-    p.owidth = owidth if owidth is not None else width
-    p.x, p.y, p.width, p.height = x, y, width, height
-    p.black0, p.white0 = black0, white0
-    p.cfa = cfa.encode()
-    p.wb_coeffs[:] = list(wb_coeffs)
-    cm = SRGB_D65_43 if cam_to_xyz_normalized is None else np.asarray(cam_to_xyz_normalized, np.float32)
-    p.cam_to_xyz_normalized[:] = [float(v) for v in cm.ravel()]
-    p.exposure = exposure
-    pts = np.asarray(points, np.float32).ravel()
-    p.npoints = pts.size // 2
-    for i, v in enumerate(pts):
-        p.points[i] = v
-    p.linear = int(linear)
-    p.out_type = out_type
-    rows = height
-    if band is not None:
-        p.band_src_row0, p.band_src_rows, p.band_out_row0, p.band_out_rows = band
-        rows = band[3]
-    dt = {OUT_F32: torch.float32, OUT_U8: torch.uint8, OUT_U16: torch.int16}[out_type]
+    plan = FusedPlan(**kw)
     if out is None:
-        out = torch.empty(rows * width * 3, dtype=dt, device="cuda")
-    _lib.check(lib().ipk_raw_to_srgb(C.byref(p), _ptr(src), _ptr(out), _stream()), "ipk_raw_to_srgb")
-    return out
+        out = plan.new_output()
+    return plan.run(src, out)
