@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -104,6 +105,47 @@ struct Scratch {                       // RAII: returns its buffers to the pool
   int get(size_t bytes, void **out) { int rc = pool_get(bytes, out); if (!rc) bufs.push_back(*out); return rc; }
   void release(void *p) { pool_put(p); bufs.erase(std::remove(bufs.begin(), bufs.end(), p), bufs.end()); }
 };
+
+
+// Can OpGoFloat's `(v - black) / range` run as the 4-instruction cdiv_fast in the fused kernel?
+// The kernel-side proof obligations (ipk_device.hpp): range positive and ordinary, the fast quotient equal to the
+// true one on the dividends this source can produce, and (u16 sources, which the kernel does not guard) every
+// nonzero dividend inside [2^-100, 2^100].  Anything else makes the kernel use true divisions.
+bool validate_cdiv_for_range_uncached(float black, float range, bool src_is_u16);
+bool validate_cdiv_for_range(float black, float range, bool src_is_u16) {
+  // one-entry memo: a pipeline is launched many times with the same levels
+  static thread_local struct { uint32_t b, r; int u16, ok; bool set; } memo = {0, 0, 0, 0, false};
+  uint32_t bb, rb; std::memcpy(&bb, &black, 4); std::memcpy(&rb, &range, 4);
+  if (memo.set && memo.b == bb && memo.r == rb && memo.u16 == (int)src_is_u16) return memo.ok != 0;
+  const bool ok = validate_cdiv_for_range_uncached(black, range, src_is_u16);
+  memo = {bb, rb, (int)src_is_u16, ok ? 1 : 0, true};
+  return ok;
+}
+bool validate_cdiv_for_range_uncached(float black, float range, bool src_is_u16) {
+  if (!(range >= 0x1p-60f && range <= 0x1p60f)) return false;             // also rejects NaN, <= 0
+  const float rc = 1.0f / range;
+  auto ok = [&](float d) {
+    if (d == 0.0f || d != d || std::isinf(d)) return true;                // v_div_fixup_f32 supplies these
+    const float ad = std::fabs(d);
+    if (ad < 0x1p-100f || ad > 0x1p100f) return !src_is_u16;              // f32 kernels guard this zone themselves
+    const float q0 = d * rc;
+    const float r = std::fma(-q0, range, d);
+    return std::fma(r, rc, q0) == d / range;
+  };
+  if (src_is_u16) {
+    for (uint32_t v = 0; v < 65536; ++v) if (!ok((float)v - black)) return false;
+    return true;
+  }
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 65536; ++i) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t bits = (uint32_t)(st >> 32);
+    bits = (bits & 0x807FFFFFu) | ((27u + (bits >> 23) % 200u) << 23);      // exponent in [2^-100, 2^100)
+    float d; std::memcpy(&d, &bits, 4);
+    if (!ok(d)) return false;
+  }
+  return true;
+}
 
 }  // namespace
 
@@ -452,6 +494,7 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.src_aligned4 = (reinterpret_cast<uintptr_t>(base) % 4 == 0) && (p->owidth % 2 == 0);
   f.width = p->width; f.height = p->height; f.owidth = p->owidth;
   f.black0 = p->black0; f.white0 = p->white0;
+  f.exact_norm = validate_cdiv_for_range(p->black0, p->white0 - p->black0, f.src_is_u16) ? 0 : 1;
   f.xoff = xoff; f.yoff = yoff;
   float mul[4];
   ipk::normalize_wbs(p->wb_coeffs, mul);                                                                   // colorspaces.rs:100

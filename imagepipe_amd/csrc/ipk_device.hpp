@@ -63,6 +63,22 @@ __device__ __forceinline__ float cbrtf_glibc(float x) {
   return ldexpf(ym, xe / 3);
 }
 
+// Same arithmetic without control flow, for callers that evaluate it on every lane of a wave and select afterwards
+// (any x: the result is only meaningful -- and only used -- for x > 1; +inf maps to +inf as in glibc).
+__device__ __forceinline__ float cbrtf_glibc_sel(float x) {
+  const int xe = __builtin_amdgcn_frexp_expf(x);
+  const float xm = __builtin_amdgcn_frexp_mantf(x);
+  const double dxm = (double)xm;
+  const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * dxm) * dxm);
+  const float t2 = u * u * u;
+  const int q = (xe * 21846) >> 16;                      // xe / 3 for 0 <= xe <= 128
+  const int rem = xe - 3 * q;
+  const double factor = rem == 0 ? 1.0 : (rem == 1 ? 1.2599210498948731647672 : 1.5874010519681994747517);
+  const float ym = (float)((double)u * ((double)t2 + 2.0 * dxm) / (2.0 * (double)t2 + dxm) * factor);
+  const float r = ldexpf(ym, q);
+  return __builtin_isinf(x) ? x : r;
+}
+
 // XYZ_LAB_TRANSFORM.lookup (src/color_conversions.rs:102-114 with the closure of :120-124)
 __device__ __forceinline__ float lab_lookup(const LutPair *__restrict__ lab, float v) {
   if (v < 0.0f || v > 1.0f) {
@@ -185,6 +201,57 @@ __device__ __forceinline__ float spline_interpolate(const SplineDev &s, float va
   }
   const int i = high > 0 ? high : 0;
   return spline_poly(s.py[i], s.c1[i], s.c2[i], s.c3[i], val - s.px[i]);
+}
+
+// Branch-free forms of the 2- and 3-knot cases for the fused kernel (same decisions as the literal
+// search above, applied as selects in reverse priority order); any other knot count takes the loop.
+__device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, float val) {
+  const int np = s.npoints;
+  if (np == 3) {
+    const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
+    const bool up = x1 < val, down = x1 > val;
+    const float bx = up ? x1 : x0, by = up ? s.py[1] : s.py[0];
+    const float k1 = up ? s.c1[1] : s.c1[0], k2 = up ? s.c2[1] : s.c2[0], k3 = up ? s.c3[1] : s.c3[0];
+    float r = spline_poly(by, k1, k2, k3, val - bx);
+    r = (!up && !down) ? s.py[1] : r;                  // exact knot hit
+    r = !(val > x0) ? s.py[0] : r;                     // val <= first, or NaN
+    r = (val >= x2) ? s.py[2] : r;                     // val >= end
+    return r;
+  }
+  if (np == 2) {
+    float r = spline_poly(s.py[0], s.c1[0], s.c2[0], s.c3[0], val - s.px[0]);
+    r = !(val > s.px[0]) ? s.py[0] : r;
+    r = (val >= s.px[1]) ? s.py[1] : r;
+    return r;
+  }
+  return spline_interpolate(s, val);
+}
+
+// ---- division by a positive constant, 4 instructions instead of the ~11 of an IEEE divide ---------
+// q0 = x*rc ; r = fma(-q0, c, x) ; q1 = fma(r, rc, q0) ; v_div_fixup(q1, c, x)
+// With rc = RN(1/c) the residual step returns the correctly rounded quotient (Markstein) whenever no
+// intermediate under/overflows; v_div_fixup_f32 restores the IEEE results for x = +-0, +-inf, NaN.
+// Checked EXHAUSTIVELY (all 2^31 positive f32 x, tests/test_gpu_fastdiv.py on the GPU and once on the
+// host) for every constant used below: the only failures are nonzero |x| < 2^-104 (all c) and
+// |x| > 2^126 (c < 1 only).  Call sites either prove their dividend is outside those zones (see the
+// comment at each) or raise `bad` through cdiv_guard(), which makes the wave redo the pixel group with
+// true divisions (FusedMath<true>), so results stay bit-identical to `x / c` for every input.
+__device__ __forceinline__ float cdiv_fast(float x, float c, float rc) {
+  const float q0 = x * rc;
+  const float r = __builtin_fmaf(-q0, c, x);
+  const float q1 = __builtin_fmaf(r, rc, q0);
+  return __builtin_amdgcn_div_fixupf(q1, c, x);
+}
+// true when x is a finite nonzero value outside [2^-100, 2^100] (zero, inf and NaN pass: the fixup
+// handles them).  v_frexp_exp_i32_f32 returns 0 for 0/inf/NaN.
+__device__ __forceinline__ bool cdiv_guard(float x) {
+  const int e = __builtin_amdgcn_frexp_expf(x);
+  return (unsigned)(e + 99) > 199u;
+}
+template <bool EXACT>
+__device__ __forceinline__ float cdiv(float x, float c, float rc) {
+  if (EXACT) return x / c;
+  return cdiv_fast(x, c, rc);
 }
 
 // ---- LDS table staging ---------------------------------------------------------------------

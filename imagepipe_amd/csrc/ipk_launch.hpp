@@ -47,6 +47,7 @@ struct FusedLaunch {
   size_t width, height, owidth;
   size_t row_off, out_r0, out_r1;
   float black0, white0;
+  int exact_norm;                // 1: gofloat's division must be a true division (see validate_cdiv)
   int xoff, yoff;
   const float *mul4, *cm12, *rgbm9;
   int has_curve, linear;
