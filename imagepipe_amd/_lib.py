@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libimagepipe_amd.so")
+SO_PATH = os.environ.get("IPK_SO_OVERRIDE") or os.path.join(_HERE, "libimagepipe_amd.so")   # override: dev ablation builds only
 
 IPK_OK, IPK_NOOP = 0, 1
 SRC_U16, SRC_F32, SRC_RGB8, SRC_RGB16 = 0, 1, 2, 3

@@ -37,6 +37,7 @@ struct Context {
   int num_cus = 0;
   std::vector<float> lut_host[3];
   void *lut_pairs[3] = {nullptr, nullptr, nullptr};      // device, 8192 x {v, dv}
+  void *lut_plain[3] = {nullptr, nullptr, nullptr};      // device, 8193 floats
   float xyz_d65_33[9];
   std::map<std::string, DevCfa> cfa_cache;
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
@@ -171,6 +172,8 @@ int ipk_init(int device) {
     for (int i = 0; i < 8192; ++i) { pairs[2 * i] = g.lut_host[t][i]; pairs[2 * i + 1] = g.lut_host[t][i + 1] - g.lut_host[t][i]; }
     HIPCHK(hipMalloc(&g.lut_pairs[t], pairs.size() * sizeof(float)));
     HIPCHK(hipMemcpy(g.lut_pairs[t], pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&g.lut_plain[t], ipk::kLutLen * sizeof(float)));
+    HIPCHK(hipMemcpy(g.lut_plain[t], g.lut_host[t].data(), ipk::kLutLen * sizeof(float), hipMemcpyHostToDevice));
   }
   g.device = device;
   g.ready = true;
@@ -180,7 +183,7 @@ int ipk_init(int device) {
 void ipk_shutdown(void) {
   if (!g.ready) return;
   (void)hipDeviceSynchronize();
-  for (int t = 0; t < 3; ++t) { if (g.lut_pairs[t]) (void)hipFree(g.lut_pairs[t]); g.lut_pairs[t] = nullptr; }
+  for (int t = 0; t < 3; ++t) { if (g.lut_pairs[t]) (void)hipFree(g.lut_pairs[t]); g.lut_pairs[t] = nullptr; if (g.lut_plain[t]) (void)hipFree(g.lut_plain[t]); g.lut_plain[t] = nullptr; }
   for (auto &kv : g.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); }
   g.cfa_cache.clear();
   for (auto &b : g.pool) (void)hipFree(b.p);
@@ -505,7 +508,7 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.spline = &sp;
   f.linear = p->linear;
   f.out_type = p->out_type;
-  f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma];
+  f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
   f.num_cus = g.num_cus;
   ipk::launch_fused_bayer(f, S(stream));
   HIPCHK(hipGetLastError());

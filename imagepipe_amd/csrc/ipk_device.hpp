@@ -142,6 +142,20 @@ __device__ __forceinline__ void lab_to_rgb(const Mat9 &mm, float l, float a, flo
   ob  = x * mm.m[6] + y * mm.m[7] + z * mm.m[8];
 }
 
+// Table branch of lookup() on a plain copy of the table (v2 - v1 evaluated per lookup, as the reference does);
+// the two reads are adjacent (ds_read2_b32).  Used where LDS space matters more than one subtraction.
+__device__ __forceinline__ float lut_interp_plain(const float *__restrict__ tab, float val) {
+  const float pos = val * kLutMaxF;
+  const uint32_t key = f32_as_u32_sat(pos);
+  const float base = truncf(pos);
+  const float a = pos - base;
+  const float v1 = tab[key], v2 = tab[key + 1];
+  return v1 + a * (v2 - v1);
+}
+__device__ __forceinline__ float gamma_sample_plain(const float *__restrict__ gam, float v) {
+  return lut_interp_plain(gam, rs_min(rs_max(v, 0.0f), 1.0f));
+}
+
 // OpGamma's per-sample step (src/ops/gamma.rs:22): apply_srgb_gamma(v.max(0).min(1)); the clamp makes
 // the out-of-table branch of lookup unreachable.
 __device__ __forceinline__ float gamma_sample(const LutPair *__restrict__ gam, float v) {
@@ -203,15 +217,36 @@ __device__ __forceinline__ float spline_interpolate(const SplineDev &s, float va
   return spline_poly(s.py[i], s.c1[i], s.c2[i], s.c3[i], val - s.px[i]);
 }
 
+// The same literal search with the knot arrays staged in LDS as [px | py | c1 | c2 | c3] (kSplineMaxKnots floats each):
+// per-lane indexed reads then use the LDS counter (lgkmcnt) and leave the kernel's global-memory pipeline alone.
+__device__ __forceinline__ float spline_interpolate_lds(const float *__restrict__ t, int np, int nseg, float val) {
+  const float *px = t, *py = t + kSplineMaxKnots, *c1 = t + 2 * kSplineMaxKnots, *c2 = t + 3 * kSplineMaxKnots, *c3 = t + 4 * kSplineMaxKnots;
+  if (val >= px[np - 1]) return py[np - 1];
+  if (val <= px[0]) return py[0];
+  int low = 0, high = nseg - 1;
+  while (low <= high) {
+    const int mid = (low + high) / 2;
+    const float xhere = px[mid];
+    if (xhere < val) low = mid + 1;
+    else if (xhere > val) high = mid - 1;
+    else return py[mid];
+  }
+  const int i = high > 0 ? high : 0;
+  return spline_poly(py[i], c1[i], c2[i], c3[i], val - px[i]);
+}
+
 // Branch-free forms of the 2- and 3-knot cases for the fused kernel (same decisions as the literal
 // search above, applied as selects in reverse priority order); any other knot count takes the loop.
-__device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, float val) {
+__device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
   const int np = s.npoints;
   if (np == 3) {
     const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
     const bool up = x1 < val, down = x1 > val;
-    const float bx = up ? x1 : x0, by = up ? s.py[1] : s.py[0];
-    const float k1 = up ? s.c1[1] : s.c1[0], k2 = up ? s.c2[1] : s.c2[0], k3 = up ? s.c3[1] : s.c3[0];
+    // segment coefficients by per-lane index from the LDS copy (a select between two kernel-argument loads would
+    // become a per-lane global load)
+    const int i = up ? 1 : 0;
+    const float bx = lds_knots[i], by = lds_knots[kSplineMaxKnots + i];
+    const float k1 = lds_knots[2 * kSplineMaxKnots + i], k2 = lds_knots[3 * kSplineMaxKnots + i], k3 = lds_knots[4 * kSplineMaxKnots + i];
     float r = spline_poly(by, k1, k2, k3, val - bx);
     r = (!up && !down) ? s.py[1] : r;                  // exact knot hit
     r = !(val > x0) ? s.py[0] : r;                     // val <= first, or NaN
@@ -224,7 +259,7 @@ __device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, floa
     r = (val >= s.px[1]) ? s.py[1] : r;
     return r;
   }
-  return spline_interpolate(s, val);
+  return spline_interpolate_lds(lds_knots, np, s.nseg, val);
 }
 
 // ---- division by a positive constant, 4 instructions instead of the ~11 of an IEEE divide ---------

@@ -11,6 +11,12 @@
 
 using namespace ipkd;
 
+// Development-only timing ablations (never defined in the product build; results are wrong by construction):
+//   1 no out-of-table Lab branch, 2 +no gamma, 3 +no curve, 4 no point-wise stage at all, 5 +no demosaic
+#ifndef IPK_ABLATE
+#define IPK_ABLATE 0
+#endif
+
 namespace ipk {
 
 // ------------------------------------------------------------------------------------------
@@ -410,7 +416,8 @@ struct FusedArgs {
   int has_curve, linear;
   uint32_t n_strips, n_segs;  // task grid
   uint32_t lc_base, lc_rem;   // lane-columns per strip: base (+1 for the first lc_rem strips)
-  const LutPair *lab_pairs, *gam_pairs;
+  const LutPair *lab_pairs;
+  const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
   SplineDev spline;
 };
 
@@ -432,21 +439,30 @@ __device__ __forceinline__ float dpp_wave_shl1(float old, float v) {   // lane i
 }
 
 // demosaic::full for one pixel with explicit tap validity: the frame-edge path (demosaic.rs:99-114).
-// pr/pc = parity of (row+yoff)/(col+xoff) in the RGGB tile; taps in the reference's order.
-__device__ __forceinline__ float4 demosaic_edge_px(const float t[9], uint32_t valid_mask, int pr, int pc) {
-  DemosaicAcc acc;
-  const int center = ((pr & 1) << 1 | (pc & 1));       // 0:R 1:G(r-row) 2:G(b-row) 3:B
-  const int center_color = center == 0 ? 0 : (center == 3 ? 2 : 1);
+// PR/PC = parity of (row+yoff)/(col+xoff) in the RGGB tile, so every tap's colour is a compile-time constant;
+// taps in the reference's order, sums start at 0.0, same-colour neighbours discarded (demosaic.rs:87).
+template <int PR, int PC>
+__device__ __forceinline__ float4 demosaic_edge_px(const float t[9], uint32_t valid_mask) {
+  constexpr int center_code = (PR << 1) | PC;          // 0:R 1:G(r-row) 2:G(b-row) 3:B
+  constexpr int center_color = center_code == 0 ? 0 : (center_code == 3 ? 2 : 1);
+  float s[3] = {0.0f, 0.0f, 0.0f}, n[3] = {0.0f, 0.0f, 0.0f};
   #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int dy = i / 3 - 1, dx = i % 3 - 1;
-    const int tr = (pr + dy) & 1, tc = (pc + dx) & 1;
-    const int tcode = (tr << 1) | tc;
+    const int tcode = (((PR + dy) & 1) << 1) | ((PC + dx) & 1);
     const int color = tcode == 0 ? 0 : (tcode == 3 ? 2 : 1);
-    const bool keep = (color != center_color) || i == 4;                    // demosaic.rs:87
-    if (((valid_mask >> i) & 1u) && keep) acc.add((uint32_t)color, t[i]);
+    if ((color != center_color) || i == 4) {
+      const bool ok = (valid_mask >> i) & 1u;
+      s[color] = ok ? s[color] + t[i] : s[color];        // static index after unrolling
+      n[color] = ok ? n[color] + 1.0f : n[color];
+    }
   }
-  return acc.finish();
+  // demosaic.rs:110-114; untouched channels stay 0.0
+  return make_float4(n[0] > 0.0f ? s[0] / n[0] : 0.0f, n[1] > 0.0f ? s[1] / n[1] : 0.0f, n[2] > 0.0f ? s[2] / n[2] : 0.0f, 0.0f);
+}
+__device__ __forceinline__ float4 demosaic_edge_dispatch(const float t[9], uint32_t m, int pr, int pc) {
+  if (pr == 0) return pc == 0 ? demosaic_edge_px<0, 0>(t, m) : demosaic_edge_px<0, 1>(t, m);
+  return pc == 0 ? demosaic_edge_px<1, 0>(t, m) : demosaic_edge_px<1, 1>(t, m);
 }
 
 // Interior pixel, all nine taps valid: the four tile roles written out.  Sums start from 0.0 and
@@ -481,8 +497,8 @@ constexpr float kRc100 = 1.0f / 100.0f, kRc255 = 1.0f / 255.0f, kRc116 = 1.0f / 
 //   ca = A*255-127, cb = B*255-127 (difference against 127, never -0);
 // guarded: x, z (arbitrary sums), cl = L*100 when a curve can produce tiny L.
 template <bool EXACT>
-__device__ __forceinline__ bool pointwise4(const FusedArgs &a, const LutPair *__restrict__ s_lab, const LutPair *__restrict__ s_gam,
-                                           const float4 px[4], PixOut o[4]) {
+__device__ __forceinline__ bool pointwise4(const FusedArgs &a, const LutPair *__restrict__ s_lab, const float *__restrict__ s_gam,
+                                           const float *__restrict__ s_knots, const float4 px[4], PixOut o[4]) {
   bool bad = false;
   float v[12], f[12];
   #pragma unroll
@@ -514,7 +530,7 @@ __device__ __forceinline__ bool pointwise4(const FusedArgs &a, const LutPair *__
   // ... then the direct branch where a value is outside [0,1]
   // (color_conversions.rs:103-104 with the closure of :120-124: v > 1 -> cbrt, v < 0 -> linear)
   #pragma unroll
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < (IPK_ABLATE >= 1 ? 0 : 12); ++k) {
     const bool hi = v[k] > 1.0f, lo = v[k] < 0.0f;
     if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = cbrtf_glibc_sel(v[k]); f[k] = hi ? c : f[k]; }
     if (__builtin_amdgcn_ballot_w64(lo) != 0) { const float t = (kLabK * v[k] + 16.0f) / 116.0f; f[k] = lo ? t : f[k]; }
@@ -529,7 +545,7 @@ __device__ __forceinline__ bool pointwise4(const FusedArgs &a, const LutPair *__
     const float A = cdiv<EXACT>(ca0 + 127.0f, 255.0f, kRc255);
     const float B = cdiv<EXACT>(cb0 + 127.0f, 255.0f, kRc255);
     // OpBaseCurve (curves.rs:44-48)
-    if (a.has_curve) L = EXACT ? spline_interpolate(a.spline, L) : spline_interpolate_sel(a.spline, L);
+    if (a.has_curve && IPK_ABLATE < 3) L = spline_interpolate_sel(a.spline, s_knots, L);
     // lab_to_xyz (color_conversions.rs:172-191)
     const float cl = L * 100.0f;
     const float ca = (A * 255.0f) - 127.0f;
@@ -550,7 +566,7 @@ __device__ __forceinline__ bool pointwise4(const FusedArgs &a, const LutPair *__
     float gg = X * a.rgbm.m[3] + Y * a.rgbm.m[4] + Z * a.rgbm.m[5];
     float bb = X * a.rgbm.m[6] + Y * a.rgbm.m[7] + Z * a.rgbm.m[8];
     // OpGamma (gamma.rs:17-23)
-    if (!a.linear) { rr = gamma_sample(s_gam, rr); gg = gamma_sample(s_gam, gg); bb = gamma_sample(s_gam, bb); }
+    if (!a.linear && IPK_ABLATE < 2) { rr = gamma_sample_plain(s_gam, rr); gg = gamma_sample_plain(s_gam, gg); bb = gamma_sample_plain(s_gam, bb); }
     o[j].r = rr; o[j].g = gg; o[j].b = bb;
   }
   return bad;
@@ -628,7 +644,61 @@ template <> struct OutStore<2> {   // u16 (output_16bit)
   }
 };
 
-// FULL = (W % 4 == 0): every active lane owns 4 valid pixels, so the hot path has no per-lane size logic.
+// Staged, wave-coalesced output for the FULL kernel.  Each lane deposits its 4 pixels (NDW dwords) at
+// stg[NDW*lane ...]; the wave's row segment is then NDW*64 contiguous dwords, written back as three
+// instructions of NDW/3 dwords per lane with lane-contiguous addresses.  The buffer is private to the wave
+// (LDS operations of one wave execute in order), so no barrier is involved.  `pix` = index of the strip's
+// first pixel in the output.
+template <int OUT> struct OutStage;
+template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 stores
+  static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
+    float4 *p = reinterpret_cast<float4 *>(stg + 12 * lane);
+    p[0] = make_float4(o[0].r, o[0].g, o[0].b, o[1].r);
+    p[1] = make_float4(o[1].g, o[1].b, o[2].r, o[2].g);
+    p[2] = make_float4(o[2].b, o[3].r, o[3].g, o[3].b);
+  }
+  static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
+    float4 *g = reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + pix * 3);
+    const float4 *s = reinterpret_cast<const float4 *>(stg);
+    const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
+    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2;
+  }
+};
+template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
+  static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
+    uint32_t q[12];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) { q[3 * j] = output8bit(o[j].r); q[3 * j + 1] = output8bit(o[j].g); q[3 * j + 2] = output8bit(o[j].b); }
+    uint32_t *p = stg + 3 * lane;
+    p[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    p[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+    p[2] = q[8] | (q[9] << 8) | (q[10] << 16) | (q[11] << 24);
+  }
+  static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
+    uint32_t *g = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);
+    const uint32_t q0 = stg[lane], q1 = stg[64 + lane], q2 = stg[128 + lane];
+    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2;
+  }
+};
+template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
+  static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
+    uint32_t q[12];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) { q[3 * j] = output16bit(o[j].r); q[3 * j + 1] = output16bit(o[j].g); q[3 * j + 2] = output16bit(o[j].b); }
+    uint2 *p = reinterpret_cast<uint2 *>(stg + 6 * lane);
+    p[0] = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+    p[1] = make_uint2(q[4] | (q[5] << 16), q[6] | (q[7] << 16));
+    p[2] = make_uint2(q[8] | (q[9] << 16), q[10] | (q[11] << 16));
+  }
+  static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
+    uint2 *g = reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);
+    const uint2 *s = reinterpret_cast<const uint2 *>(stg);
+    const uint2 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
+    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2;
+  }
+};
+
+// FULL = (W % 4 == 0 and W >= 256): every lane owns 4 valid pixels, so the hot path has no per-lane size logic.
 // Everything that is rare (frame-edge pixels, out-of-table Lab values, dividends outside cdiv_fast's proven
 // zone, the exact-division redo) sits behind a WAVE-UNIFORM branch (`ballot != 0`), which keeps the common
 // path straight-line code the scheduler can interleave across the lane's 4 pixels.
@@ -637,10 +707,19 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
   constexpr bool GUARD_NORM = sizeof(SrcT) == 4;
+  // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB), curve knots, and one 3 KB staging
+  // buffer per wave that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
   __shared__ LutPair s_lab[kLutPairs];
-  __shared__ LutPair s_gam[kLutPairs];
+  __shared__ float s_gam[kLutPairs + 4];
+  __shared__ float s_knots[5 * kSplineMaxKnots];         // base-curve knots
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * 768 : 4];
   load_lut_pairs(s_lab, a.lab_pairs);
-  load_lut_pairs(s_gam, a.gam_pairs);
+  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) s_gam[i] = a.gam_table[i];
+  if (threadIdx.x < kSplineMaxKnots) {
+    const int i = threadIdx.x;
+    s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
+    s_knots[3 * kSplineMaxKnots + i] = a.spline.c2[i]; s_knots[4 * kSplineMaxKnots + i] = a.spline.c3[i];
+  }
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -648,10 +727,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   if (task >= a.n_strips * a.n_segs) return;             // whole wave leaves together
   const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
 
-  // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each
-  const uint32_t lc0 = strip * a.lc_base + min(strip, a.lc_rem);
-  const uint32_t nl = a.lc_base + (strip < a.lc_rem ? 1u : 0u);
-  const bool lane_on = lane < nl;
+  // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each.  FULL: every strip is 64 lanes wide and the
+  // last one is shifted left to stay inside the frame; the columns it shares with its neighbour are computed by
+  // both waves (identical values written twice), which keeps every lane active and every access unpredicated.
+  const uint32_t w4 = (a.W + 3u) >> 2;
+  const uint32_t lc0 = FULL ? min(strip * 64u, w4 - 64u) : strip * a.lc_base + min(strip, a.lc_rem);
+  const uint32_t nl = FULL ? 64u : a.lc_base + (strip < a.lc_rem ? 1u : 0u);
+  const bool lane_on = FULL ? true : lane < nl;
   // lanes past the strip shadow its last lane: their loads stay in bounds and need no predicate
   const uint32_t col0 = 4u * (lc0 + min(lane, nl - 1));
   const uint32_t nvalid = FULL ? 4u : min(4u, a.W - col0);
@@ -664,7 +746,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl); every other lane
   // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
   const bool is_first = lane == 0, is_last = lane + 1 == nl;
-  const bool single = nl == 1;                           // one lane carries both halos: second one via h2
+  const bool single = FULL ? false : nl == 1;            // one lane carries both halos: second one via h2
   const int64_t hcol_want = is_first ? (int64_t)4 * lc0 - 1 : (int64_t)4 * (lc0 + nl);
   const uint32_t hcol = ((is_first || is_last) && hcol_want >= 0 && hcol_want < (int64_t)a.W) ? (uint32_t)hcol_want : col0;
   const uint32_t h2col = (single && 4u * (lc0 + nl) < a.W) ? 4u * (lc0 + nl) : col0;
@@ -718,10 +800,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
   if (r0 > 0) P = finish_row(issue_row(r0 - 1));
   C = finish_row(issue_row(r0));
-  RawRowT raw_next = (r0 < Hm1) ? issue_row(r0 + 1) : zero_raw;
+  // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
+  // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
+  (void)zero_raw;
+  RawRowT raw_next = issue_row(min(r0 + 1, Hm1));
   for (uint32_t r = r0; r < r1; ++r) {
-    if (r < Hm1) N = finish_row(raw_next);
-    if (r + 2 <= Hm1 && r + 1 < r1) raw_next = issue_row(r + 2);
+    N = finish_row(raw_next);                            // row r+1 (a copy of row H-1 past the frame: masked as an edge)
+    raw_next = issue_row(min(r + 2, Hm1));
     const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
     const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
     const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
@@ -768,28 +853,60 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
             if (r == Hm1) m &= ~0x1C0u;
             if (c == 0) m &= ~0x049u;
             if (c == Wm1) m &= ~0x124u;
-            px[j] = demosaic_edge_px(t, m, pr, (int)((j + (uint32_t)a.xoff) & 1u));
+            px[j] = demosaic_edge_dispatch(t, m, pr, (int)((j + (uint32_t)a.xoff) & 1u));
           }
         }
       }
     }
     PixOut o[4];
-    const bool bad = pointwise4<false>(a, s_lab, s_gam, px, o);
+#if IPK_ABLATE >= 5
+    for (int j = 0; j < 4; ++j) px[j] = make_float4(cw[j + 1], pw[j + 1], nw[j + 1], 0.0f);
+#endif
+#if IPK_ABLATE >= 4
+    const bool bad = false;
+    for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
+#else
+    const bool bad = pointwise4<false>(a, s_lab, s_gam, s_knots, px, o);
+#endif
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: some dividend outside cdiv_fast's proven zone
       PixOut oe[4];
-      pointwise4<true>(a, s_lab, s_gam, px, oe);
+      pointwise4<true>(a, s_lab, s_gam, s_knots, px, oe);
       #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (bad) o[j] = oe[j];
     }
-    if (lane_on) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
+#if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
+    if (OUT == 0 && FULL) {
+      float *rowp = reinterpret_cast<float *>(a.dst) + ((size_t)(r - a.out_r0) * a.W + 4u * lc0) * 3;
+      f4u q0{o[0].r, o[0].g, o[0].b, o[1].r}, q1{o[1].g, o[1].b, o[2].r, o[2].g}, q2{o[2].b, o[3].r, o[3].g, o[3].b};
+      reinterpret_cast<f4u *>(rowp)[lane] = q0; reinterpret_cast<f4u *>(rowp)[64 + lane] = q1; reinterpret_cast<f4u *>(rowp)[128 + lane] = q2;
+    }
+#elif IPK_ABLATE == 7    // timing only: no stores
+    if (o[0].r == 123.456f) reinterpret_cast<float *>(a.dst)[lane] = o[1].g + o[2].b + o[3].r;
+#else
+    if (FULL) {
+      // Lane-blocked -> lane-interleaved through the wave's LDS staging buffer, then three stores per lane whose
+      // addresses are contiguous across the wave (whole cache lines per instruction; a 48-byte lane stride would
+      // touch every line of the 3 KB span with each of its stores).
+      uint32_t *stg = s_stage + (threadIdx.x >> 6) * 768;
+      // The compiler reasons about one lane: a lane never reads back what it staged, so without these wave-scope
+      // fences it treats the staging writes as dead stores / reorders them past the reads.  Wavefront-scope fences
+      // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
+      OutStage<OUT>::stage(stg, lane, o);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      OutStage<OUT>::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + 4u * lc0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      if (lane_on) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
+    }
+#endif
     P = C; C = N;
   }
 }
 
 template <typename SrcT, bool VEC, int OUT>
 static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
-  if ((a.W & 3u) == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(1024), 0, s, a);
+  if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(a.dst) & 15u) == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(1024), 0, s, a);
   else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false>), dim3(grid), dim3(1024), 0, s, a);
 }
 
@@ -806,7 +923,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.has_curve = f.has_curve; a.linear = f.linear;
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
   a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs);
-  a.gam_pairs = reinterpret_cast<const LutPair *>(f.gam_pairs);
+  a.gam_table = reinterpret_cast<const float *>(f.gam_table);
 
   // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
   const uint32_t waves_per_block = 16;
@@ -814,7 +931,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;
   a.n_strips = (w4 + 63) / 64;
-  a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;
+  a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;   // balanced strips (generic kernel); FULL uses 64-lane strips
   const uint32_t nrows = a.out_r1 - a.out_r0;
   uint32_t segs = total_waves / a.n_strips;
   if (segs < 1) segs = 1;
