@@ -118,6 +118,10 @@ SIGNATURES = {
     "ipk_host_output8bit": (C.c_int, [_vp, _sz, _vp]),
     "ipk_host_output16bit": (C.c_int, [_vp, _sz, _vp]),
     "ipk_host_raw_to_srgb": (C.c_int, [C.POINTER(FusedParams), _vp, _vp]),
+    "ipk_selftest_cdiv": (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "ipk_selftest_lut_weight": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "ipk_selftest_clamp01": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "ipk_selftest_cbrtf": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
 }
 
 _lib = None

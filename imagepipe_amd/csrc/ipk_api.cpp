@@ -502,9 +502,21 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   float mul[4];
   ipk::normalize_wbs(p->wb_coeffs, mul);                                                                   // colorspaces.rs:100
   f.mul4 = mul; f.cm12 = p->cam_to_xyz_normalized; f.rgbm9 = g.xyz_d65_33;
+  // the fast point-wise form assumes finite, ordinary parameters (see pointwise2_fast): |value| <= 2^20, no NaN/inf
+  {
+    auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };        // false for NaN and inf
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
+    for (int i = 0; i < 12; ++i) ok = ok && sane(p->cam_to_xyz_normalized[i]);
+    f.fast_ok = ok ? 1 : 0;
+  }
   ipk::Spline sp;
   f.has_curve = !curve_is_noop(p->exposure, p->npoints);
-  if (f.has_curve) { int rc = build_curve(p->exposure, p->points, p->npoints, sp); if (rc) return rc; }
+  if (f.has_curve) {
+    int rc = build_curve(p->exposure, p->points, p->npoints, sp); if (rc) return rc;
+    for (int i = 0; i < sp.npoints; ++i) if (!(std::fabs(sp.px[i]) <= 0x1p20f && std::fabs(sp.py[i]) <= 0x1p20f && std::fabs(sp.c1[i]) <= 0x1p40f)) f.fast_ok = 0;
+    for (int i = 0; i < sp.nseg; ++i) if (!(std::fabs(sp.c2[i]) <= 0x1p40f && std::fabs(sp.c3[i]) <= 0x1p40f)) f.fast_ok = 0;
+  }
   f.spline = &sp;
   f.linear = p->linear;
   f.out_type = p->out_type;
@@ -512,6 +524,50 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.num_cus = g.num_cus;
   ipk::launch_fused_bayer(f, S(stream));
   HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// self-test hooks
+// ------------------------------------------------------------------------------------------
+static int selftest_collect(void *dev, uint64_t *n_bad, uint32_t *first_bad) {
+  struct { unsigned long long bad; unsigned int first; unsigned int pad; } h;
+  HIPCHK(hipMemcpy(&h, dev, sizeof(h), hipMemcpyDeviceToHost));
+  (void)hipFree(dev);
+  *n_bad = h.bad; if (first_bad) *first_bad = h.first;
+  return IPK_OK;
+}
+static int selftest_alloc(void **dev) {
+  struct { unsigned long long bad; unsigned int first; unsigned int pad; } h = {0, 0xFFFFFFFFu, 0};
+  HIPCHK(hipMalloc(dev, sizeof(h)));
+  HIPCHK(hipMemcpy(*dev, &h, sizeof(h), hipMemcpyHostToDevice));
+  return IPK_OK;
+}
+int ipk_selftest_cdiv(float c, int variant, float lo, float hi, int include_special, uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  if (!(c > 0.0f) || variant < 0 || variant > 2 || !n_bad) return fail(IPK_ERR_INVALID, "bad selftest arguments");
+  uint32_t lo_bits, hi_bits; std::memcpy(&lo_bits, &lo, 4); std::memcpy(&hi_bits, &hi, 4);
+  void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;
+  ipk::launch_selftest_cdiv(c, variant, lo_bits, hi_bits, include_special, dev, nullptr);
+  HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
+int ipk_selftest_lut_weight(uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;
+  ipk::launch_selftest_fract(dev, nullptr); HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
+int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;
+  ipk::launch_selftest_clamp(dev, nullptr); HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
+int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream) {
+  REQUIRE_INIT();
+  if (!in || !out || variant < 0 || variant > 2) return fail(IPK_ERR_INVALID, "bad selftest arguments");
+  ipk::launch_selftest_cbrt(in, out, n, variant, S(stream)); HIPCHK(hipGetLastError());
   return IPK_OK;
 }
 

@@ -410,6 +410,7 @@ struct FusedArgs {
   float min0, range0;         // blacklevels[0], whitelevels[0]-blacklevels[0]
   float inv_range0;           // RN(1/range0) for the 4-instruction division
   int exact_norm;             // 1: normalise with true divisions (host could not validate the fast form for range0)
+  int fast_ok;                // 1: parameters are finite and ordinary, pointwise2_fast may run (else literal path only)
   int xoff, yoff;             // Bayer phase: color_at(r,c) = RGGB[(r+yoff)&1][(c+xoff)&1]
   ToLabParams tolab;
   Mat9 rgbm;                  // XYZ_D65_33
@@ -482,94 +483,162 @@ __device__ __forceinline__ float4 demosaic_inner_px(float nw, float n, float ne,
 
 struct PixOut { float r, g, b; };
 
-constexpr float kRcWhiteX = 1.0f / kWhiteX, kRcWhiteZ = 1.0f / kWhiteZ;
-constexpr float kRc100 = 1.0f / 100.0f, kRc255 = 1.0f / 255.0f, kRc116 = 1.0f / 116.0f, kRc500 = 1.0f / 500.0f,
-                kRc200 = 1.0f / 200.0f, kRcLabK = 1.0f / kLabK;
+constexpr float kRcLabK = 1.0f / kLabK;
 
 
-// OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma for the 4 pixels of a lane.
-// EXACT=false: branch-free main path -- every division is cdiv_fast(), both arms of the Lab
-// piecewise functions are evaluated and selected, table lookups always run (clamped key) and only the
-// out-of-table values take a wave-uniform detour.  Returns per lane whether a dividend left the zone
-// where cdiv_fast is proven exact; the caller then redoes the group with EXACT=true (`x / c`).
-// Which dividends need no guard (nonzero magnitude provably >= 2^-21, divisor > 1):
-//   l = 116*fy-16, a+127, b+127, cl+16, 116*f-16 (all differences against a constant >= 16),
-//   ca = A*255-127, cb = B*255-127 (difference against 127, never -0);
-// guarded: x, z (arbitrary sums), cl = L*100 when a curve can produce tiny L.
-template <bool EXACT>
-__device__ __forceinline__ bool pointwise4(const FusedArgs &a, const LutPair *__restrict__ s_lab, const float *__restrict__ s_gam,
-                                           const float *__restrict__ s_knots, const float4 px[4], PixOut o[4]) {
-  bool bad = false;
-  float v[12], f[12];
-  #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    // camera_to_lab (color_conversions.rs:42-55)
-    const float r = rs_min(px[j].x * a.tolab.mul[0], 1.0f);
-    const float g = rs_min(px[j].y * a.tolab.mul[1], 1.0f);
-    const float b = rs_min(px[j].z * a.tolab.mul[2], 1.0f);
-    const float e = rs_min(px[j].w * a.tolab.mul[3], 1.0f);
-    const float x = r * a.tolab.cm[0] + g * a.tolab.cm[1] + b * a.tolab.cm[2] + e * a.tolab.cm[3];
-    const float y = r * a.tolab.cm[4] + g * a.tolab.cm[5] + b * a.tolab.cm[6] + e * a.tolab.cm[7];
-    const float z = r * a.tolab.cm[8] + g * a.tolab.cm[9] + b * a.tolab.cm[10] + e * a.tolab.cm[11];
-    // xyz_to_lab (color_conversions.rs:157-158); y / 1.0 is y
-    v[3 * j] = cdiv<EXACT>(x, kWhiteX, kRcWhiteX);
-    v[3 * j + 1] = y;
-    v[3 * j + 2] = cdiv<EXACT>(z, kWhiteZ, kRcWhiteZ);
-    if (!EXACT) bad |= cdiv_guard(x) | cdiv_guard(z);
+// ---- packed helpers ---------------------------------------------------------------------------------------
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 work on two f32 per lane; the lane's pixels are processed in pairs so
+// the multiply/add/fma chains (each op still individually rounded: -ffp-contract=off) issue as packed instructions.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 F2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 S2(float a) { f2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 min2(f2 a, float m) { return F2(rs_min(a.x, m), rs_min(a.y, m)); }
+
+// 1/c = rc_hi + rc_lo.  q = fma(x, rc_hi, x*rc_lo) equals x/c for EVERY finite x with 2^-100 <= |x| <= 2^100 for the
+// constants 0.95047, 1.08883, 100, 255, 116, 500, 200 (exhaustive on-device proof, tests/test_gpu_selftest.py
+// test_cdiv_two_step_variant); it is NOT exact for 24389/27, which keeps the three-step residual form.
+constexpr float rc_hi(float c) { return 1.0f / c; }
+constexpr float rc_lo(float c) { return (float)(1.0 / (double)c - (double)(1.0f / c)); }
+__device__ __forceinline__ f2 cdiv2s(f2 x, float hi, float lo) { return fma2(x, S2(hi), x * S2(lo)); }
+__device__ __forceinline__ f2 cdiv3s(f2 x, float c, float rc) {
+  const f2 q0 = x * S2(rc);
+  const f2 r = fma2(-q0, S2(c), x);
+  return fma2(r, S2(rc), q0);
+}
+__device__ __forceinline__ float cdiv3s1(float x, float c, float rc) {
+  const float q0 = x * rc;
+  const float r = __builtin_fmaf(-q0, c, x);
+  return __builtin_fmaf(r, rc, q0);
+}
+
+// XYZ_LAB_TRANSFORM.lookup's direct branch for v > 1 (color_conversions.rs:103-104,123): cbrtf; the short form when the
+// whole wave's out-of-table values are below 2
+__device__ __forceinline__ float lab_cbrt(float v, bool hi) {
+  if (__builtin_amdgcn_ballot_w64(hi && v >= 2.0f) == 0) return cbrtf_glibc_1to2(v);
+  return cbrtf_glibc_sel(v);
+}
+
+// OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma for TWO pixels of a lane, fast form.  Bit-identical to the literal
+// form (pointwise_exact) whenever it returns false; returns true ("bad") for a lane whose inputs leave the zone where
+// that equivalence is proven, and the caller then recomputes the lane's pixels literally.
+//
+// What differs from the literal evaluation, and why the bits are the same:
+//  * x / c -> cdiv2s / cdiv3s (multiply + fma forms), proven exact on 2^-100 <= |x| <= 2^100 finite; dividends are
+//    kept in that zone by (a) the channel sanity check below (finite inputs, host-validated finite parameters, so no
+//    inf/NaN reaches a division), (b) explicit exponent guards on x and z (arbitrary sums) and on cl when a curve is
+//    present, (c) the structure of the other dividends: l = 116*fy-16, a+127, b+127, cl+16, 116*f-16, A*255-127 are
+//    differences against a constant >= 16, hence 0 or >= 2^-21 in magnitude, and a zero dividend gives +0 in both forms
+//    (these differences are never -0; x and z can be -0 but the table lookup maps +-0 to the same value);
+//  * the E channel term e*cm[3] is dropped: E is +0.0 for the RGGB tiles this kernel accepts and cm[3] is finite
+//    (host-checked), so the term is +-0 and only changes (-0)+(+0), whose sign the lookup ignores as well;
+//  * lookup(): key and weight via v_cvt_u32 / v_fract (proven == pos - trunc(pos) on [0,8192]); the table branch
+//    runs for every lane and out-of-table values (bit pattern above 1.0f; -0 is also caught and takes the linear
+//    branch, which yields table[0] bit-for-bit) are patched afterwards behind wave-uniform branches;
+//  * v.max(0).min(1) -> v_med3_f32 (proven equal on every f32 up to the sign of zero, which the lookup ignores).
+struct FastBad { bool b; };
+// `par` = LDS copy of the uniform parameters (mul[0..3], cm[4..15], rgbm[16..24]): read through the LDS they end up in
+// vector registers instead of competing with the wave's many 64-bit condition masks for scalar registers.
+__device__ __forceinline__ bool pointwise2_fast(const FusedArgs &a, const float *__restrict__ par, const LutPair *__restrict__ s_lab,
+                                                const float *__restrict__ s_gam, const float *__restrict__ s_knots,
+                                                const float4 &pa, const float4 &pb, PixOut &oa, PixOut &ob) {
+  bool bad = !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
+  // camera_to_lab (color_conversions.rs:42-55)
+  const f2 r = min2(F2(pa.x, pb.x) * S2(par[0]), 1.0f);
+  const f2 g = min2(F2(pa.y, pb.y) * S2(par[1]), 1.0f);
+  const f2 b = min2(F2(pa.z, pb.z) * S2(par[2]), 1.0f);
+  const f2 x = r * S2(par[4]) + g * S2(par[5]) + b * S2(par[6]);
+  const f2 y = r * S2(par[8]) + g * S2(par[9]) + b * S2(par[10]);
+  const f2 z = r * S2(par[12]) + g * S2(par[13]) + b * S2(par[14]);
+  bad |= cdiv_guard(x.x) | cdiv_guard(x.y) | cdiv_guard(z.x) | cdiv_guard(z.y);
+  // xyz_to_lab (color_conversions.rs:156-169)
+  const f2 xr = cdiv2s(x, rc_hi(kWhiteX), rc_lo(kWhiteX));
+  const f2 zr = cdiv2s(z, rc_hi(kWhiteZ), rc_lo(kWhiteZ));
+  float v[6] = {xr.x, xr.y, y.x, y.y, zr.x, zr.y};
+  float f[6];
+  {
+    const f2 p0 = xr * S2(kLutMaxF), p1 = y * S2(kLutMaxF), p2 = zr * S2(kLutMaxF);
+    const float pos[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+    LutPair e[6]; float w[6];
+    #pragma unroll
+    for (int k = 0; k < 6; ++k) { e[k] = s_lab[f32_as_u32_sat(pos[k])]; w[k] = __builtin_amdgcn_fractf(pos[k]); }
+    #pragma unroll
+    for (int k = 0; k < 6; k += 2) {
+      const f2 t = F2(e[k].x, e[k + 1].x) + F2(w[k], w[k + 1]) * F2(e[k].y, e[k + 1].y);
+      f[k] = t.x; f[k + 1] = t.y;
+    }
   }
-  // the three XYZ_LAB_TRANSFORM lookups (:160-162): table branch for everyone (key clamped so the LDS read
-  // stays in the table; NaN -> key 0 and a NaN weight, as in the reference) ...
+#if IPK_ABLATE < 1
   #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const float pos = v[k] * kLutMaxF;
-    const uint32_t key = min(f32_as_u32_sat(pos), (uint32_t)(kLutPairs - 1));
-    const float w = pos - truncf(pos);
-    const LutPair p = s_lab[key];
-    f[k] = p.x + w * p.y;
+  for (int k = 0; k < 6; ++k) {
+    const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
+    if (__builtin_amdgcn_ballot_w64(oor) != 0) {
+      const bool hi = v[k] > 1.0f, lo = oor && !hi;                     // lo: negative (or -0 / NaN: the linear form gives the table's answer / NaN)
+      if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
+      if (__builtin_amdgcn_ballot_w64(lo) != 0) { const float t = (kLabK * v[k] + 16.0f) / 116.0f; f[k] = lo ? t : f[k]; }
+    }
   }
-  // ... then the direct branch where a value is outside [0,1]
-  // (color_conversions.rs:103-104 with the closure of :120-124: v > 1 -> cbrt, v < 0 -> linear)
-  #pragma unroll
-  for (int k = 0; k < (IPK_ABLATE >= 1 ? 0 : 12); ++k) {
-    const bool hi = v[k] > 1.0f, lo = v[k] < 0.0f;
-    if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = cbrtf_glibc_sel(v[k]); f[k] = hi ? c : f[k]; }
-    if (__builtin_amdgcn_ballot_w64(lo) != 0) { const float t = (kLabK * v[k] + 16.0f) / 116.0f; f[k] = lo ? t : f[k]; }
+#endif
+  const f2 fx = F2(f[0], f[1]), fy = F2(f[2], f[3]), fz = F2(f[4], f[5]);
+  const f2 l = S2(116.0f) * fy - S2(16.0f);
+  const f2 a0 = S2(500.0f) * (fx - fy);
+  const f2 b0 = S2(200.0f) * (fy - fz);
+  f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
+  const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+  const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+  // OpBaseCurve (curves.rs:44-48)
+  if (a.has_curve && IPK_ABLATE < 3) L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
+  // lab_to_xyz (color_conversions.rs:172-191)
+  const f2 cl = L * S2(100.0f);
+  const f2 ca = (A * S2(255.0f)) - S2(127.0f);
+  const f2 cb = (B * S2(255.0f)) - S2(127.0f);
+  const f2 gy = cdiv2s(cl + S2(16.0f), rc_hi(116.0f), rc_lo(116.0f));
+  const f2 gx = cdiv2s(ca, rc_hi(500.0f), rc_lo(500.0f)) + gy;
+  const f2 gz = gy - cdiv2s(cb, rc_hi(200.0f), rc_lo(200.0f));
+  const f2 gx3 = gx * gx * gx, gy3 = gy * gy * gy, gz3 = gz * gz * gz;
+  const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
+  const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
+  // cl / k keeps the fix-up: a curve may hand over L = -0.0
+  const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
+  const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
+  const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
+  if (a.has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
+  const f2 xq = F2(gx3.x > kLabE ? gx3.x : lx.x, gx3.y > kLabE ? gx3.y : lx.y);
+  const f2 yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
+  const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
+  const f2 X = xq * S2(kWhiteX), Y = yq /* * 1.0 */, Z = zq * S2(kWhiteZ);
+  // lab_to_rgb (color_conversions.rs:61-63)
+  f2 rr = X * S2(par[16]) + Y * S2(par[17]) + Z * S2(par[18]);
+  f2 gg = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);
+  f2 bb = X * S2(par[22]) + Y * S2(par[23]) + Z * S2(par[24]);
+  // OpGamma (gamma.rs:17-23)
+  if (!a.linear && IPK_ABLATE < 2) {
+    const float c[6] = {__builtin_amdgcn_fmed3f(rr.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(rr.y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gg.x, 0.0f, 1.0f),
+                        __builtin_amdgcn_fmed3f(gg.y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb.y, 0.0f, 1.0f)};
+    const f2 q0 = F2(c[0], c[1]) * S2(kLutMaxF), q1 = F2(c[2], c[3]) * S2(kLutMaxF), q2 = F2(c[4], c[5]) * S2(kLutMaxF);
+    const float pos[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+    float v1[6], v2[6], w[6];
+    #pragma unroll
+    for (int k = 0; k < 6; ++k) { const uint32_t key = f32_as_u32_sat(pos[k]); v1[k] = s_gam[key]; v2[k] = s_gam[key + 1]; w[k] = __builtin_amdgcn_fractf(pos[k]); }
+    rr = F2(v1[0], v1[1]) + F2(w[0], w[1]) * (F2(v2[0], v2[1]) - F2(v1[0], v1[1]));
+    gg = F2(v1[2], v1[3]) + F2(w[2], w[3]) * (F2(v2[2], v2[3]) - F2(v1[2], v1[3]));
+    bb = F2(v1[4], v1[5]) + F2(w[4], w[5]) * (F2(v2[4], v2[5]) - F2(v1[4], v1[5]));
   }
-  #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float fx = f[3 * j], fy = f[3 * j + 1], fz = f[3 * j + 2];
-    const float l = 116.0f * fy - 16.0f;
-    const float ca0 = 500.0f * (fx - fy);
-    const float cb0 = 200.0f * (fy - fz);
-    float L = cdiv<EXACT>(l, 100.0f, kRc100);
-    const float A = cdiv<EXACT>(ca0 + 127.0f, 255.0f, kRc255);
-    const float B = cdiv<EXACT>(cb0 + 127.0f, 255.0f, kRc255);
-    // OpBaseCurve (curves.rs:44-48)
-    if (a.has_curve && IPK_ABLATE < 3) L = spline_interpolate_sel(a.spline, s_knots, L);
-    // lab_to_xyz (color_conversions.rs:172-191)
-    const float cl = L * 100.0f;
-    const float ca = (A * 255.0f) - 127.0f;
-    const float cb = (B * 255.0f) - 127.0f;
-    const float gy = cdiv<EXACT>(cl + 16.0f, 116.0f, kRc116);
-    const float gx = cdiv<EXACT>(ca, 500.0f, kRc500) + gy;
-    const float gz = gy - cdiv<EXACT>(cb, 200.0f, kRc200);
-    const float gx3 = gx * gx * gx;
-    const float xr = (gx3 > kLabE) ? gx3 : cdiv<EXACT>(116.0f * gx - 16.0f, kLabK, kRcLabK);
-    const bool ybig = cl > kLabK * kLabE;
-    const float yr = ybig ? gy * gy * gy : cdiv<EXACT>(cl, kLabK, kRcLabK);
-    if (!EXACT) bad |= (a.has_curve != 0) & !ybig & cdiv_guard(cl);
-    const float gz3 = gz * gz * gz;
-    const float zr = (gz3 > kLabE) ? gz3 : cdiv<EXACT>(116.0f * gz - 16.0f, kLabK, kRcLabK);
-    const float X = xr * kWhiteX, Y = yr * kWhiteY, Z = zr * kWhiteZ;
-    // lab_to_rgb (color_conversions.rs:61-63)
-    float rr = X * a.rgbm.m[0] + Y * a.rgbm.m[1] + Z * a.rgbm.m[2];
-    float gg = X * a.rgbm.m[3] + Y * a.rgbm.m[4] + Z * a.rgbm.m[5];
-    float bb = X * a.rgbm.m[6] + Y * a.rgbm.m[7] + Z * a.rgbm.m[8];
-    // OpGamma (gamma.rs:17-23)
-    if (!a.linear && IPK_ABLATE < 2) { rr = gamma_sample_plain(s_gam, rr); gg = gamma_sample_plain(s_gam, gg); bb = gamma_sample_plain(s_gam, bb); }
-    o[j].r = rr; o[j].g = gg; o[j].b = bb;
-  }
+  oa.r = rr.x; oa.g = gg.x; oa.b = bb.x;
+  ob.r = rr.y; ob.g = gg.y; ob.b = bb.y;
   return bad;
+}
+
+// The literal per-pixel evaluation (device functions of ipk_device.hpp: true divisions, the reference's control flow).
+__device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const LutPair *__restrict__ s_lab, const float *__restrict__ s_gam,
+                                                  const float *__restrict__ s_knots, const float4 &p) {
+  float l, ca, cb;
+  camera_to_lab(s_lab, a.tolab, p.x, p.y, p.z, p.w, l, ca, cb);
+  if (a.has_curve && IPK_ABLATE < 3) l = spline_interpolate_lds(s_knots, a.spline.npoints, a.spline.nseg, l);
+  PixOut o;
+  lab_to_rgb(a.rgbm, l, ca, cb, o.r, o.g, o.b);
+  if (!a.linear && IPK_ABLATE < 2) { o.r = gamma_sample_plain(s_gam, o.r); o.g = gamma_sample_plain(s_gam, o.g); o.b = gamma_sample_plain(s_gam, o.b); }
+  return o;
 }
 
 template <typename SrcT, bool VEC>
@@ -712,9 +781,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   __shared__ LutPair s_lab[kLutPairs];
   __shared__ float s_gam[kLutPairs + 4];
   __shared__ float s_knots[5 * kSplineMaxKnots];         // base-curve knots
+  __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * 768 : 4];
   load_lut_pairs(s_lab, a.lab_pairs);
   for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) s_gam[i] = a.gam_table[i];
+  if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
+  else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
+  else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) {
     const int i = threadIdx.x;
     s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
@@ -863,18 +936,21 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     for (int j = 0; j < 4; ++j) px[j] = make_float4(cw[j + 1], pw[j + 1], nw[j + 1], 0.0f);
 #endif
 #if IPK_ABLATE >= 4
-    const bool bad = false;
     for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
-    const bool bad = pointwise4<false>(a, s_lab, s_gam, s_knots, px, o);
-#endif
-    if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: some dividend outside cdiv_fast's proven zone
-      PixOut oe[4];
-      pointwise4<true>(a, s_lab, s_gam, s_knots, px, oe);
-      #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (bad) o[j] = oe[j];
+    bool bad = a.fast_ok == 0;
+    if (a.fast_ok) {
+      bad = pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[0], px[1], o[0], o[1]);
+      bad |= pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[2], px[3], o[2], o[3]);
     }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
+        if (bad) o[j] = e;
+      }
+    }
+#endif
 #if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
     if (OUT == 0 && FULL) {
       float *rowp = reinterpret_cast<float *>(a.dst) + ((size_t)(r - a.out_r0) * a.W + 4u * lc0) * 3;
@@ -917,6 +993,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.min0 = f.black0; a.range0 = f.white0 - f.black0;                       // gofloat.rs:86-89
   a.inv_range0 = 1.0f / a.range0;
   a.exact_norm = f.exact_norm;
+  a.fast_ok = f.fast_ok;
   a.xoff = f.xoff; a.yoff = f.yoff;
   a.tolab = make_tolab(f.mul4, f.cm12);
   for (int i = 0; i < 9; ++i) a.rgbm.m[i] = f.rgbm9[i];
@@ -955,6 +1032,79 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     else launch_fused_t<uint16_t, false, 2>(a, blocks, s);
   }
   return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Self-test kernels: exhaustive on-device proofs of the arithmetic shortcuts the fused kernel uses
+// (tests/test_gpu_selftest.py).  Each compares a shortcut with the plain IEEE expression over every
+// f32 bit pattern and reports the mismatches.
+// ------------------------------------------------------------------------------------------
+struct SelftestOut { unsigned long long bad; unsigned int first_bad; unsigned int pad; };
+
+__device__ __forceinline__ bool same_f32(float a, float b) {
+  return (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+}
+// variant 0: cdiv_fast (with v_div_fixup); 1: the three arithmetic steps only; 2: two steps with a hi/lo reciprocal
+// Only dividends with lo_bits <= |x| bits <= hi_bits (plus, if include_special, 0/inf/NaN) are checked.
+__global__ void k_selftest_cdiv(float c, float rc, float rc_lo, int variant, unsigned lo_bits, unsigned hi_bits, int include_special,
+                                SelftestOut *out) {
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const unsigned bits = (unsigned)i, mag = bits & 0x7FFFFFFFu;
+    const bool special = mag == 0 || mag >= 0x7F800000u;
+    if (special ? !include_special : (mag < lo_bits || mag > hi_bits)) continue;
+    const float x = __uint_as_float(bits);
+    float q;
+    if (variant == 0) q = cdiv_fast(x, c, rc);
+    else if (variant == 1) { const float q0 = x * rc; const float r = __builtin_fmaf(-q0, c, x); q = __builtin_fmaf(r, rc, q0); }
+    else { const float t = x * rc_lo; q = __builtin_fmaf(x, rc, t); }
+    if (!same_f32(q, x / c)) { ++bad; if (bits < first) first = bits; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
+// pos - trunc(pos) versus v_fract_f32(pos) for every f32 pos in [0, 8192] (the lookup's weight)
+__global__ void k_selftest_fract(SelftestOut *out) {
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned hi = __float_as_uint(8192.0f);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i <= hi; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float pos = __uint_as_float((unsigned)i);
+    if (!same_f32(pos - truncf(pos), __builtin_amdgcn_fractf(pos))) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
+// clamp: v.max(0.0).min(1.0) versus v_med3_f32(v, 0, 1), every bit pattern (NaN -> 0; the sign of a zero result is
+// ignored: the gamma lookup maps +-0 to the same value)
+__global__ void k_selftest_clamp(SelftestOut *out) {
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float v = __uint_as_float((unsigned)i);
+    const float a = rs_min(rs_max(v, 0.0f), 1.0f), b = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+    if (!(a == b)) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
+// device cbrt variants on an array (the host compares with libm): 0 literal glibc port, 1 select form, 2 fast form for (1,2)
+__global__ void k_selftest_cbrt(const float *__restrict__ in, float *__restrict__ out, size_t n, int variant) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = in[i];
+    out[i] = variant == 0 ? cbrtf_glibc(x) : (variant == 1 ? cbrtf_glibc_sel(x) : cbrtf_glibc_1to2(x));
+  }
+}
+
+int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bits, int include_special, void *out_dev, hipStream_t s) {
+  const float rc = 1.0f / c;
+  const float rc_lo = (float)(1.0 / (double)c - (double)rc);
+  hipLaunchKernelGGL(k_selftest_cdiv, dim3(256 * 8), dim3(256), 0, s, c, rc, rc_lo, variant, lo_bits, hi_bits, include_special,
+                     reinterpret_cast<SelftestOut *>(out_dev));
+  return 0;
+}
+int launch_selftest_fract(void *out_dev, hipStream_t s) { hipLaunchKernelGGL(k_selftest_fract, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev)); return 0; }
+int launch_selftest_clamp(void *out_dev, hipStream_t s) { hipLaunchKernelGGL(k_selftest_clamp, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev)); return 0; }
+int launch_selftest_cbrt(const float *in, float *out, size_t n, int variant, hipStream_t s) {
+  hipLaunchKernelGGL(k_selftest_cbrt, dim3(256 * 8), dim3(256), 0, s, in, out, n, variant); return 0;
 }
 
 }  // namespace ipk

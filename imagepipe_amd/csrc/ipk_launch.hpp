@@ -48,6 +48,7 @@ struct FusedLaunch {
   size_t row_off, out_r0, out_r1;
   float black0, white0;
   int exact_norm;                // 1: gofloat's division must be a true division (see validate_cdiv)
+  int fast_ok;                   // 1: matrix / multipliers / curve are finite and ordinary (fast point-wise form allowed)
   int xoff, yoff;
   const float *mul4, *cm12, *rgbm9;
   int has_curve, linear;
@@ -57,5 +58,11 @@ struct FusedLaunch {
   int num_cus;
 };
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);
+
+// exhaustive on-device checks of the arithmetic shortcuts (see ipk_kernels.hip "Self-test kernels")
+int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bits, int include_special, void *out_dev, hipStream_t s);
+int launch_selftest_fract(void *out_dev, hipStream_t s);
+int launch_selftest_clamp(void *out_dev, hipStream_t s);
+int launch_selftest_cbrt(const float *in, float *out, size_t n, int variant, hipStream_t s);
 
 }  // namespace ipk

@@ -301,6 +301,23 @@ IPK_API int ipk_host_output8bit(const float *src, size_t n, uint8_t *dst);
 IPK_API int ipk_host_output16bit(const float *src, size_t n, uint16_t *dst);
 IPK_API int ipk_host_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst);
 
+/* ---------------------------------------------------------------------------------------- */
+/* Self-test hooks: on-device, exhaustive checks that the arithmetic shortcuts of the fused     */
+/* kernel reproduce the plain IEEE expressions of the reference (used by tests/, not by callers) */
+/* ---------------------------------------------------------------------------------------- */
+/* x / c (src/color_conversions.rs:158,168,177-179,184-187; src/ops/gofloat.rs:126) versus the kernel's
+ * multiply/fma forms, over every f32 x with lo <= |x| <= hi (and 0/inf/NaN if include_special).
+ * variant 0: cdiv_fast incl. v_div_fixup; 1: the three arithmetic steps; 2: two steps, hi/lo reciprocal. */
+IPK_API int ipk_selftest_cdiv(float c, int variant, float lo, float hi, int include_special,
+                              uint64_t *n_bad, uint32_t *first_bad_bits);
+/* pos - pos.trunc() (src/color_conversions.rs:108-109) versus v_fract_f32 for every pos in [0, 8192] */
+IPK_API int ipk_selftest_lut_weight(uint64_t *n_bad, uint32_t *first_bad_bits);
+/* v.max(0.0).min(1.0) (src/ops/gamma.rs:22) versus v_med3_f32(v,0,1) for every f32 */
+IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
+/* the device cbrtf routines (variant 0 literal glibc port, 1 select form, 2 form for 1<x<2) on a device array;
+ * callers compare with the host libm's cbrtf (src/color_conversions.rs:123 -> f32::cbrt) */
+IPK_API int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

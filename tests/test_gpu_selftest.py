@@ -1,0 +1,101 @@
+"""Exhaustive on-device proofs of the arithmetic shortcuts used by the fused kernel (bit-exactness is the bar):
+constant division as multiply/fma, v_fract for the lookup weight, v_med3 for the gamma clamp, and the device
+cbrtf against the HOST libm (what Rust's f32::cbrt calls) over enumerable domains."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# every divisor constant of the hot path (color_conversions.rs:7,158,168,177-179,181-187) + typical level ranges
+CONSTS = [0.95047, 1.08883, 100.0, 255.0, 116.0, 500.0, 200.0, float(np.float32(24389.0) / np.float32(27.0)), 15871.0, 4031.0, 959.0, 65535.0, 16319.0]
+
+
+@pytest.fixture(scope="module")
+def L():
+    import imagepipe_amd
+    imagepipe_amd.init(0)
+    return imagepipe_amd.lib()
+
+
+def _cdiv(L, c, variant, lo, hi, special):
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_cdiv(c, variant, lo, hi, special, C.byref(n), C.byref(first)) == 0
+    return n.value, first.value
+
+
+@pytest.mark.parametrize("c", CONSTS)
+def test_cdiv_fast_exact_on_every_f32_in_the_proven_zone(L, c):
+    """variant 0 (with v_div_fixup): every f32 with 2^-100 <= |x| <= 2^100, plus +-0, +-inf and every NaN"""
+    bad, first = _cdiv(L, c, 0, 2.0 ** -100, 2.0 ** 100, 1)
+    assert bad == 0, "c=%r: %d mismatches, first x bits 0x%08x" % (c, bad, first)
+
+
+@pytest.mark.parametrize("c", CONSTS)
+def test_cdiv_three_steps_exact_on_finite_nonzero(L, c):
+    """variant 1 (no fix-up): exact for finite nonzero x in the zone (what the guarded call sites rely on)"""
+    bad, first = _cdiv(L, c, 1, 2.0 ** -100, 2.0 ** 100, 0)
+    assert bad == 0, "c=%r: %d mismatches, first x bits 0x%08x" % (c, bad, first)
+
+
+@pytest.mark.parametrize("c", [c for c in CONSTS if c > 1.0])
+def test_cdiv_divisors_above_one_need_no_upper_guard(L, c):
+    bad, first = _cdiv(L, c, 1, 2.0 ** -100, float(np.finfo(np.float32).max), 0)
+    assert bad == 0, "c=%r: %d mismatches, first x bits 0x%08x" % (c, bad, first)
+
+
+def test_cdiv_two_step_variant(L):
+    """variant 2, q = fma(x, rc_hi, x*rc_lo) with 1/c = rc_hi + rc_lo: exact on every f32 in the zone for SOME constants only
+    (the quotient of two 24-bit numbers can sit within 2^-49 of a rounding boundary, the size of this form's error), so the
+    kernel uses it exactly for the constants proven here and the three-step form elsewhere"""
+    res = {c: _cdiv(L, c, 2, 2.0 ** -100, 2.0 ** 100, 0)[0] for c in CONSTS}
+    print("two-step constant division mismatches:", res)
+    # the kernel's cdiv2() call sites (ipk_kernels.hip pointwise4_fast): the white point and the Lab scale constants
+    for c in (0.95047, 1.08883, 100.0, 255.0, 116.0, 500.0, 200.0):
+        assert res[c] == 0, "two-step division is not exact for c=%r" % c
+
+
+def test_lut_weight_fract(L):
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_lut_weight(C.byref(n), C.byref(first)) == 0
+    assert n.value == 0, "v_fract differs from pos - trunc(pos) at bits 0x%08x" % first.value
+
+
+def test_clamp_med3(L):
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_clamp01(C.byref(n), C.byref(first)) == 0
+    assert n.value == 0, "v_med3(v,0,1) differs from v.max(0).min(1) at bits 0x%08x" % first.value
+
+
+def _device_cbrt(L, x, variant):
+    import torch
+    d = torch.from_numpy(x).cuda(); o = torch.empty_like(d)
+    assert L.ipk_selftest_cbrtf(C.c_void_p(d.data_ptr()), C.c_void_p(o.data_ptr()), x.size, variant, None) == 0
+    torch.cuda.synchronize()
+    return o.cpu().numpy()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_cbrtf_equals_host_libm_on_every_f32_in_1_to_8_and_beyond(L, orc, variant):
+    """cbrtf depends on the mantissa and on xe mod 3 only (glibc 2.35 s_cbrtf.c), so [1,8) covers every case; a
+    sweep of larger exponents and +inf covers the ldexp step"""
+    lo, hi = np.float32(1.0).view(np.uint32), np.float32(8.0).view(np.uint32)
+    x = np.arange(int(lo) + 1, int(hi), dtype=np.uint32).view(np.float32)
+    got = _device_cbrt(L, x, variant)
+    want = orc.lookup(orc.LUT_XYZ_LAB, x)             # x > 1: the oracle's lookup() calls the host libm's cbrtf directly
+    bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, "%d mismatches, first x=%r" % (bad.size, x[bad[0]])
+    big = np.concatenate([np.float32(2.0) ** np.arange(3, 128, dtype=np.float32) * np.float32(1.2345678), np.array([np.inf, 3.4e38], np.float32)]).astype(np.float32)
+    assert np.array_equal(_device_cbrt(L, big, variant).view(np.uint32), orc.lookup(orc.LUT_XYZ_LAB, big).view(np.uint32))
+
+
+def test_device_cbrtf_fast_form_every_f32_in_1_to_2(L, orc):
+    lo, hi = np.float32(1.0).view(np.uint32), np.float32(2.0).view(np.uint32)
+    x = np.arange(int(lo) + 1, int(hi), dtype=np.uint32).view(np.float32)
+    got = _device_cbrt(L, x, 2)
+    want = orc.lookup(orc.LUT_XYZ_LAB, x)
+    bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, "%d mismatches, first x=%r" % (bad.size, x[bad[0]])
+
+
