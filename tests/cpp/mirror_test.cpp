@@ -1,0 +1,44 @@
+// Exercises include/imagepipe_amd.hpp (the C++ mirror of Pipeline / ImageOp / OpBuffer) on one raw frame:
+//   mirror_test <in.u16> <width> <height> <cfa> <maxwidth> <rotation> <out.f32>
+// Runs Pipeline::run (C driver, fused when legal) and the op-by-op loop, requires them to agree bit for bit,
+// and writes the result for the Python test to compare with the oracle.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <tuple>
+#include <vector>
+#include "imagepipe_amd.hpp"
+
+int main(int argc, char **argv) {
+  if (argc != 8) { std::fprintf(stderr, "usage\n"); return 2; }
+  const size_t w = std::atol(argv[2]), h = std::atol(argv[3]);
+  std::vector<uint16_t> raw(w * h);
+  FILE *f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(raw.data(), 2, raw.size(), f) != raw.size()) { std::fprintf(stderr, "bad input\n"); return 2; }
+  std::fclose(f);
+  try {
+    if (ipk_init(0) != 0) { std::fprintf(stderr, "%s\n", ipk_last_error()); return 3; }
+    imagepipe::ImageSource img;
+    img.kind = imagepipe::ImageSource::Raw; img.width = w; img.height = h; img.cfa = argv[4];
+    for (int i = 0; i < 4; ++i) { img.blacklevels[i] = 512.0f; img.whitelevels[i] = 16383.0f; }
+    const float wb[4] = {2.0f, 1.0f, 1.5f, NAN};
+    std::copy(wb, wb + 4, img.wb_coeffs);
+    const float scale[3] = {1.10f, 1.05f, 1.20f};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) img.cam_to_xyz_normalized[r * 4 + c] *= scale[r];
+    img.data = imagepipe::DeviceArray(raw.data(), raw.size() * 2);
+    auto pipe = imagepipe::Pipeline::new_from_source(std::move(img));
+    pipe.globals.settings.maxwidth = std::atol(argv[5]);
+    pipe.ops.transform.rotation = std::atoi(argv[6]);
+    auto a = pipe.run();
+    auto b = pipe.run_ops();
+    const std::vector<float> va = a->to_host(), vb = b->to_host();
+    if (a->width != b->width || a->height != b->height || va.size() != vb.size() || std::memcmp(va.data(), vb.data(), va.size() * 4) != 0) {
+      std::fprintf(stderr, "driver and op loop disagree\n"); return 4;
+    }
+    auto o8 = pipe.output_8bit();
+    std::printf("%zu %zu %d %zu\n", a->width, a->height, pipe.last_used_fused ? 1 : 0, o8.data.size());
+    FILE *o = std::fopen(argv[7], "wb");
+    std::fwrite(va.data(), 4, va.size(), o); std::fclose(o);
+  } catch (const std::exception &e) { std::fprintf(stderr, "error: %s\n", e.what()); return 5; }
+  return 0;
+}

@@ -260,3 +260,27 @@ def test_full_size_strip_matches_oracle(ipa, orc):
         s0, s1 = max(0, r0 - 2), min(H, r1 + 2)              # even offsets keep the CFA phase
         sub = orc.pipeline_run(_oracle_desc(orc, frame[s0:s1]))
         assert_bits_equal(got[r0:r1].cpu().numpy(), sub[r0 - s0: r1 - s0], "strip %d..%d" % (r0, r1))
+
+
+# ---------------------------------------------------------------------------------------------
+# the C++ mirror of Pipeline / ImageOp / OpBuffer (include/imagepipe_amd.hpp), built by __graft_entry__.build()
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfa,shape,maxwidth,rotation", [("RGGB", (64, 256), 0, 0), ("GRBG", (50, 70), 0, 0), ("RGGB", (64, 96), 24, 0),
+                                                       ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", (48, 72), 0, 1)])
+def test_cpp_mirror_pipeline(orc, tmp_path, cfa, shape, maxwidth, rotation):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "build", "mirror_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(os.path.dirname(exe))])
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 60, h, w)
+    raw.tofile(tmp_path / "in.u16")
+    out = subprocess.run([exe, str(tmp_path / "in.u16"), str(w), str(h), cfa, str(maxwidth), str(rotation), str(tmp_path / "out.f32")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ow, oh, fused, n8 = [int(v) for v in out.stdout.split()]
+    want = orc.pipeline_run(_oracle_desc(orc, raw, cfa, maxwidth=maxwidth, rotation=rotation))
+    assert (oh, ow) == want.shape[:2] and n8 == ow * oh * 3
+    assert bool(fused) == (cfa in CFAS and maxwidth == 0 and rotation == 0)
+    assert_bits_equal(np.fromfile(tmp_path / "out.f32", np.float32).reshape(oh, ow, 3), want, "C++ mirror")
