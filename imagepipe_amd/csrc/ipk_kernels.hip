@@ -486,13 +486,26 @@ struct PixOut { float r, g, b; };
 constexpr float kRcLabK = 1.0f / kLabK;
 
 
-// ---- packed helpers ---------------------------------------------------------------------------------------
-// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 work on two f32 per lane; the lane's pixels are processed in pairs so
-// the multiply/add/fma chains (each op still individually rounded: -ffp-contract=off) issue as packed instructions.
+// ---- pixel-pair helpers -----------------------------------------------------------------------------------
+// The lane's pixels are processed in pairs so that two independent dependency chains interleave.  Packed f32
+// instructions (v_pk_mul/add/fma_f32) were tried for the pairs and measured slower than scalar code on MI355X
+// (tools/ubench.hip: v_mul/v_add 2.75 cycles per wave64 instruction, v_pk_* 4.8, v_fma 4.1), so the pair type is a
+// plain struct and the translation unit is built with -fno-slp-vectorize.
+#ifdef IPK_PACKED_PAIRS   // measured slower on MI355X (v_pk_* = 4.8 cycles vs 2 x 2.75 for mul/add, plus packing moves): off
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 F2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ f2 S2(float a) { f2 r; r.x = a; r.y = a; return r; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else   // pixel pairs as two scalars; the build also passes -fno-slp-vectorize (0.96 -> 0.87 ms on the 100 MP frame)
+struct f2 { float x, y; };
+__device__ __forceinline__ f2 F2(float a, float b) { return f2{a, b}; }
+__device__ __forceinline__ f2 S2(float a) { return f2{a, a}; }
+__device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#endif
 __device__ __forceinline__ f2 min2(f2 a, float m) { return F2(rs_min(a.x, m), rs_min(a.y, m)); }
 
 // 1/c = rc_hi + rc_lo.  q = fma(x, rc_hi, x*rc_lo) equals x/c for EVERY finite x with 2^-100 <= |x| <= 2^100 for the

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Times the BASELINE.json configurations that are not the headline bench line (device-resident, HIP events):
+   C2  24 MP RGGB, fused and staged;  C3 100 MP fused (same as bench.py);  C5 8640x5760 X-Trans -> 2160x1440 (staged)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import imagepipe_amd as ipa
+import util
+
+XTRANS = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def frame(h, w, seed, is_float):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    v = torch.randint(0, 16384, (h * w,), generator=g, device="cuda", dtype=torch.int32)
+    return v.to(torch.float32) if is_float else v.to(torch.int16)
+
+
+def main():
+    ipa.init(0)
+    res = {}
+    for name, (h, w, cfa, maxw, is_float) in {"C2_24MP_rggb_f32": (4000, 6000, "RGGB", 0, True), "C2_24MP_rggb_u16": (4000, 6000, "RGGB", 0, False),
+                                                 "C3_100MP_rggb_f32": (10000, 10000, "RGGB", 0, True),
+                                                 "C5_50MP_xtrans_to_2160": (5760, 8640, XTRANS, 2160, True)}.items():
+        img = ipa.RawImage(width=w, height=h, data=frame(h, w, 7, is_float), cfa=cfa, is_float=is_float, blacklevels=[util.BLACK] * 4,
+                           whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+        pipe = ipa.Pipeline.new_from_source(img)
+        pipe.globals.settings.maxwidth = maxw
+        out = pipe.run()
+        r = {"out": [out.width, out.height], "fused": pipe.last_used_fused, "ms": round(timeit(lambda: pipe.run(out=out.data)), 4)}
+        r["MP_per_s_in"] = round(h * w / 1e6 / (r["ms"] * 1e-3), 1)
+        if pipe.last_used_fused:
+            pipe.allow_fused = False
+            o2 = pipe.run()
+            r["staged_ms"] = round(timeit(lambda: pipe.run(out=o2.data), n=5), 4)
+            assert torch.equal(o2.data.view(torch.int32), out.data.view(torch.int32)), "fused != staged"
+        res[name] = r
+        del pipe, img, out
+        torch.cuda.empty_cache()
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
