@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--band", action="store_true",
+                    help="additionally time ONE frame row-sharded over the N GPUs with the RCCL halo exchange (reported as an extra "
+                         "'band_mode' object; the headline value stays the batch-sharded one)")
     return ap.parse_args()
 
 
@@ -160,6 +163,38 @@ def main():
                     result["roofline"]["traffic_source"] = os.path.relpath(profs[-1], ROOT)
             except Exception:
                 pass
+
+    # ---- optional: one frame sharded by row bands over the ranks, 1-row halo exchange (RCCL P2P) before every launch ----
+    if args.band:
+        from imagepipe_amd import parallel as par
+        bands = par.band_plan(H, world, 2)
+        band = bands[rank]
+        slab, own = par.alloc_slab(band, W, src.dtype, "cuda")
+        own.copy_(src.view(H, W)[band.out_row0: band.out_row0 + band.out_rows])
+        plan_b = ipa.FusedPlan(width=W, height=H, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
+                               cam_to_xyz_normalized=cm, out_type=out_type, band=(band.src_row0, band.src_rows, band.out_row0, band.out_rows))
+        out_b = plan_b.new_output()
+
+        def step_band():
+            if world > 1:
+                par.exchange_halo_inplace(slab, band, bands)
+            plan_b.run(slab.view(-1), out_b, stream)
+
+        for _ in range(args.warmup):
+            step_band()
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            step_band()
+        barrier()
+        eb = time.perf_counter() - tb
+        if dist is not None:
+            t = torch.tensor([eb], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            eb = float(t[0])
+        result["band_mode"] = {"ms_per_frame": round(eb / args.steps * 1e3, 4), "value": round(args.steps * H * W / 1e6 / eb, 1), "unit": "MP/s",
+                               "scaling": "strong", "rows_per_rank": band.out_rows, "halo_bytes_per_neighbour": W * (4 if is_float else 2),
+                               "gather": "none (bands stay on their GPUs)"}
 
     # ---- CPU baseline: the oracle's reference-shaped pipeline (unfused, one task per row) on this host ----
     if rank == 0 and not args.no_cpu_baseline:

@@ -82,6 +82,34 @@ def exchange_halo(band_rows: torch.Tensor, band: Band, bands: Sequence[Band], gr
     return slab
 
 
+def alloc_slab(band: Band, width: int, dtype, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Persistent slab for one band: returns (slab [src_rows, W], own [out_rows, W]) where `own` is the view of the rows this
+    rank owns.  Fill `own` once per frame, then exchange_halo_inplace() receives the neighbours' edge rows straight into the
+    slab's first/last row -- no per-frame concatenation of a band that is hundreds of MB."""
+    slab = torch.empty((band.src_rows, width), dtype=dtype, device=device)
+    top = band.out_row0 - band.src_row0
+    return slab, slab[top: top + band.out_rows]
+
+
+def exchange_halo_inplace(slab: torch.Tensor, band: Band, bands: Sequence[Band], group=None) -> None:
+    """Halo exchange on a slab from alloc_slab(): sends the band's first/last own row, receives into the halo rows."""
+    if band.out_rows == 0:
+        return
+    rank = band.rank
+    up = next((b for b in reversed(bands[:rank]) if b.out_rows > 0), None)
+    down = next((b for b in bands[rank + 1:] if b.out_rows > 0), None)
+    top = band.out_row0 - band.src_row0
+    ops = []
+    if up is not None:
+        ops += [dist.P2POp(dist.isend, slab[top], up.rank, group), dist.P2POp(dist.irecv, slab[0], up.rank, group)]
+    if down is not None:
+        ops += [dist.P2POp(dist.isend, slab[top + band.out_rows - 1], down.rank, group),
+                dist.P2POp(dist.irecv, slab[band.src_rows - 1], down.rank, group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
 def gather_bands(out_band: torch.Tensor, bands: Sequence[Band], width: int, to: str = "all", group=None) -> Optional[torch.Tensor]:
     """Reassembles the [rows, W, 3] output bands.  to="all": every rank gets the frame (all_gather over xGMI);
     to="root": only rank 0 (gather); bands may differ in height, so they are padded to the tallest."""

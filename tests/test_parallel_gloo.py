@@ -58,6 +58,11 @@ def _worker(rank, world, port, case, q):
           ok_full = np.array_equal(full.numpy().view(np.uint32), whole.view(np.uint32))
           out2, root = par.process_frame_banded(own, h, w, compute, period=period, gather="root")
           ok_root = (root is None) if rank else np.array_equal(root.numpy().view(np.uint32), whole.view(np.uint32))
+          # in-place slab variant (what bench.py --band uses)
+          slab, own_view = par.alloc_slab(b, w, torch.int16, "cpu")
+          own_view.copy_(own)
+          par.exchange_halo_inplace(slab, b, bands)
+          ok_band = ok_band and np.array_equal(slab.numpy().view(np.uint16), raw[b.src_row0: b.src_row0 + b.src_rows])
           frames = par.shard_frames(7, rank, world)
           q.put((rank, ok_band, ok_full, ok_root, frames, (b.src_row0, b.src_rows, b.out_row0, b.out_rows)))
       except Exception as e:                                   # never leave the parent waiting on the queue

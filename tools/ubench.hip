@@ -44,11 +44,21 @@ DEF_KERNEL(v_fma_f32, DECL_F32, OP3("v_fma_f32"))
 DEF_KERNEL(v_med3_f32, DECL_F32, OP3("v_med3_f32"))
 DEF_KERNEL(v_div_fixup_f32, DECL_F32, OP3("v_div_fixup_f32"))
 #define OPCND \
-  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a0) : "v"(c)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a1) : "v"(c)); \
-  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a2) : "v"(c)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a3) : "v"(c)); \
-  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a4) : "v"(c)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a5) : "v"(c)); \
-  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a6) : "v"(c)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a7) : "v"(c));
-DEF_KERNEL(v_cndmask_b32, DECL_F32, OPCND)
+  asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a0) : "v"(c), "s"(msk)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a1) : "v"(c), "s"(msk)); \
+  asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a2) : "v"(c), "s"(msk)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a3) : "v"(c), "s"(msk)); \
+  asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a4) : "v"(c), "s"(msk)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a5) : "v"(c), "s"(msk)); \
+  asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a6) : "v"(c), "s"(msk)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a7) : "v"(c), "s"(msk));
+#define DECL_F32M DECL_F32; unsigned long long msk = __builtin_amdgcn_ballot_w64(c > 0.5f) ^ 0x5555555555555555ull
+DEF_KERNEL(v_cndmask_b32, DECL_F32M, OPCND)
+DEF_KERNEL(v_sub_f32, DECL_F32, OP2("v_sub_f32"))
+DEF_KERNEL(v_max_f32, DECL_F32, OP2("v_max_f32"))
+DEF_KERNEL(v_mov_b32, DECL_F32, OP1("v_mov_b32"))
+DEF_KERNEL(v_cvt_f32_u32, DECL_F32, OP1("v_cvt_f32_u32"))
+DEF_KERNEL(v_lshlrev_b32, DECL_F32, OP2("v_lshlrev_b32"))
+DEF_KERNEL(v_lshl_add_u32, DECL_F32, OP3("v_lshl_add_u32"))
+DEF_KERNEL(v_mbcnt_lo, DECL_F32, OP2("v_mbcnt_lo_u32_b32"))
+DEF_KERNEL(v_min3_f32, DECL_F32, OP3("v_min3_f32"))
+DEF_KERNEL(v_mad_f32_legacyfree, DECL_F32, OP3("v_mad_u32_u24"))
 DEF_KERNEL(v_cvt_u32_f32, DECL_F32, OP1("v_cvt_u32_f32"))
 DEF_KERNEL(v_trunc_f32, DECL_F32, OP1("v_trunc_f32"))
 DEF_KERNEL(v_fract_f32, DECL_F32, OP1("v_fract_f32"))
@@ -108,14 +118,14 @@ struct Entry { const char *name; void (*fn)(float *, unsigned long long *, float
 #define E(NAME) {#NAME, k_##NAME}
 
 int main() {
-  std::vector<Entry> es = {E(v_mul_f32), E(v_add_f32), E(v_min_f32), E(v_fma_f32), E(v_med3_f32), E(v_div_fixup_f32), E(v_cndmask_b32),
+  std::vector<Entry> es = {E(v_mul_f32), E(v_add_f32), E(v_min_f32), E(v_fma_f32), E(v_med3_f32), E(v_div_fixup_f32), E(v_cndmask_b32), E(v_sub_f32), E(v_max_f32), E(v_mov_b32), E(v_cvt_f32_u32), E(v_lshlrev_b32), E(v_lshl_add_u32), E(v_mbcnt_lo), E(v_min3_f32), E(v_mad_f32_legacyfree),
                            E(v_cvt_u32_f32), E(v_trunc_f32), E(v_fract_f32), E(v_rcp_f32), E(v_frexp_exp_i32_f32), E(v_frexp_mant_f32), E(v_ldexp_f32),
                            E(v_and_b32), E(v_add_u32), E(v_mov_dpp), E(v_cmp_gt_f32), E(v_pk_mul_f32), E(v_pk_add_f32), E(v_pk_fma_f32),
                            E(v_mul_f64), E(v_add_f64), E(v_fma_f64), E(v_rcp_f64)};
   float *out; unsigned long long *cyc;
   hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&cyc, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int wpsimd : {1, 4}) {
+  for (int wpsimd : {4}) {
     // grid: 256 CUs x wpsimd blocks of 256 threads (one wave per SIMD each)
     const int blocks = 256 * wpsimd;
     printf("--- %d wave(s) per SIMD ---\n", wpsimd);
