@@ -284,3 +284,64 @@ def test_cpp_mirror_pipeline(orc, tmp_path, cfa, shape, maxwidth, rotation):
     assert (oh, ow) == want.shape[:2] and n8 == ow * oh * 3
     assert bool(fused) == (cfa in CFAS and maxwidth == 0 and rotation == 0)
     assert_bits_equal(np.fromfile(tmp_path / "out.f32", np.float32).reshape(oh, ow, 3), want, "C++ mirror")
+
+
+# ---------------------------------------------------------------------------------------------
+# strip geometry of the FULL kernel (64-lane strips, last one shifted left) x output types x source types
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(10, 256), (12, 260), (23, 512), (17, 1028), (40, 2052), (11, 4096 + 8)])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_fused_full_kernel_strip_geometry_all_outputs(ipa, orc, shape, is_float):
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 61 + w, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "GBRG", is_float=is_float))
+    d = _oracle_desc(orc, src, "GBRG")
+    got = pipe.run(); assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(d), "f32 out %dx%d" % (w, h))
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, "GBRG")))
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, "GBRG")))
+
+
+def test_fused_extreme_levels_fall_back_to_true_division(ipa, orc):
+    """white-black ranges the host cannot validate for the multiply/fma division (tiny, huge, negative) and absurd
+    parameters must still be bit-exact (exact_norm / literal point-wise path)"""
+    h, w = 24, 300
+    raw = util.noise_u16(util.SEED + 62, h, w).astype(np.float32)
+    for black, white in [(0.0, 1e-30), (0.0, 3e38), (16383.0, 512.0), (512.0, 512.0), (1e-30, 16383.0)]:
+        kw = dict(blacklevels=[black] * 4, whitelevels=[white] * 4)
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "RGGB", is_float=True, **kw))
+        assert_bits_equal(pipe.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "RGGB", **kw)), "levels %r" % ((black, white),))
+    for wb, scale in [((2.0, 0.0, 1.5, 1.0), 1.0), ((1e30, 1.0, 1e-30, 1.0), 1.0), ((2.0, 1.0, 1.5, np.nan), 1e25), ((-2.0, 1.0, -1.5, 1.0), -3.0)]:
+        cm = (util.cam_matrix() * np.float32(scale)).astype(np.float32)
+        kw = dict(wb_coeffs=wb, cam_to_xyz_normalized=cm)
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "RGGB", is_float=True, **kw))
+        assert_bits_equal(pipe.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "RGGB", **kw)), "params %r" % ((wb, scale),))
+
+
+def test_fused_denormal_and_huge_samples_take_the_guarded_path(ipa, orc):
+    """f32 mosaics full of denormals / 1e-35-class values / huge values: every dividend guard fires somewhere"""
+    h, w = 16, 512
+    rng = np.random.default_rng(5)
+    expo = rng.integers(-149, 127, size=(h, w)).astype(np.float64)
+    raw = (np.ldexp(rng.uniform(1, 2, size=(h, w)), expo.astype(np.int64)) * rng.choice([-1.0, 1.0], size=(h, w))).astype(np.float32)
+    for black, white in [(0.0, 1.0), (0.0, 16383.0)]:
+        kw = dict(blacklevels=[black] * 4, whitelevels=[white] * 4)
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "BGGR", is_float=True, **kw))
+        assert_bits_equal(pipe.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "BGGR", **kw)), "wild samples")
+
+
+def test_errors_are_reported_not_computed(ipa):
+    import ctypes as C
+    import torch
+    L = ipa.lib()
+    z = torch.zeros(64, device="cuda")
+    assert L.ipk_tolab(None, 4, 4, 0, None, None, None, None) == -2                         # null buffers
+    assert L.ipk_demosaic_full(C.c_void_p(z.data_ptr()), 4, 4, b"RGXB", C.c_void_p(z.data_ptr()), None) == -2   # bad CFA
+    assert b"CFA" in L.ipk_last_error()
+    out = (C.c_size_t * 4)()
+    assert L.ipk_size_image(0, 0, 0, 0, 9, 9, out) == -2                                    # the reference underflows below 10x10
+    with pytest.raises(ipa.IpkError):
+        ipa.Pipeline.new_from_source(ipa.RawImage(width=8, height=8, data=ipa.upload_u16(np.zeros((8, 8), np.uint16)), cfa="RGGB")).run()

@@ -55,6 +55,22 @@ def main():
         res[name] = r
         del pipe, img, out
         torch.cuda.empty_cache()
+    # PCIe-inclusive: the host-pointer form (upload 24 MP u16, fused kernel, download f32 RGB), pageable host memory
+    import ctypes as C
+    h, w = 4000, 6000
+    raw = util.noise_u16(util.SEED + 2, h, w)
+    img = ipa.RawImage(width=w, height=h, data=ipa.upload_u16(raw), cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                       wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    d = ipa.Pipeline.new_from_source(img).desc()
+    out = np.empty(h * w * 3, np.float32)
+    used = C.c_int(0)
+    L = ipa.lib()
+    L.ipk_host_pipeline_run(C.byref(d), raw.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 0, C.byref(used))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        assert L.ipk_host_pipeline_run(C.byref(d), raw.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 0, C.byref(used)) == 0
+    dt = (time.perf_counter() - t0) / 3
+    res["host_pcie_inclusive_24MP_u16_to_f32"] = {"ms": round(dt * 1e3, 2), "MP_per_s": round(h * w / 1e6 / dt, 1), "bytes_moved": h * w * 2 + h * w * 12}
     print(json.dumps(res, indent=1))
 
 
