@@ -217,6 +217,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
+        dist.barrier()                      # the other ranks wait here while rank 0 runs the CPU baseline leg
         dist.destroy_process_group()
 
 

@@ -308,7 +308,10 @@ int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, si
   if (src_row0 > need0 || src_row0 + src_rows < need1) return fail(IPK_ERR_INVALID, "band rows [%zu,%zu) do not cover taps [%zu,%zu)", src_row0, src_row0 + src_rows, need0, need1);
   ipk::Cfa cfa; DevCfa dev;
   int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
-  ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
+  int xoff, yoff;
+  if (cfa.bayer_phase(xoff, yoff))       // the four RGGB phases: row-walking kernel (coalesced loads, register window, staged stores)
+    ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, dst4, g.num_cus, S(stream));
+  else ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }

@@ -6,6 +6,7 @@
 // 13-bit lookup tables (and the 48x48 CFA colour table), no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
 #include "ipk_device.hpp"
 #include "ipk_launch.hpp"
 
@@ -673,6 +674,7 @@ __device__ __forceinline__ void load_raw4<uint16_t, false>(const uint16_t *p, ui
 }
 
 template <int OUT> struct OutStore;
+template <> struct OutStore<3> { static __device__ __forceinline__ void store(void *, size_t, uint32_t, const PixOut *, bool) {} };
 template <> struct OutStore<0> {   // f32 RGB (Pipeline::run)
   typedef float elem;
   static __device__ __forceinline__ void store(void *dst, size_t pix, uint32_t nvalid, const PixOut o[4], bool) {
@@ -732,6 +734,10 @@ template <> struct OutStore<2> {   // u16 (output_16bit)
 // (LDS operations of one wave execute in order), so no barrier is involved.  `pix` = index of the strip's
 // first pixel in the output.
 template <int OUT> struct OutStage;
+template <> struct OutStage<3> {   // unused: OUT == 3 leaves the kernel before the point-wise stages
+  static __device__ __forceinline__ void stage(uint32_t *, uint32_t, const PixOut *) {}
+  static __device__ __forceinline__ void flush(const uint32_t *, uint32_t, void *, size_t) {}
+};
 template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 stores
   static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
     float4 *p = reinterpret_cast<float4 *>(stg + 12 * lane);
@@ -780,6 +786,28 @@ template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
   }
 };
 
+// OUT == 3: "demosaic only" -- the kernel skips normalisation and the point-wise stages and writes demosaic::full's
+// 4-channel RGBE pixels (16 dwords per lane, four lane-contiguous dwordx4 stores).  This is the staged OpDemosaic for
+// Bayer sources, sharing the row-walking skeleton with the fused kernel.
+struct RgbeStage {
+  static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const float4 px[4]) {
+    float4 *p = reinterpret_cast<float4 *>(stg + 16 * lane);
+    p[0] = px[0]; p[1] = px[1]; p[2] = px[2]; p[3] = px[3];
+  }
+  static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
+    float4 *g = reinterpret_cast<float4 *>(dst) + pix;
+    const float4 *s = reinterpret_cast<const float4 *>(stg);
+    const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane], q3 = s[192 + lane];
+    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2; g[192 + lane] = q3;
+  }
+  static __device__ __forceinline__ void store_direct(void *dst, size_t pix, uint32_t nvalid, const float4 px[4]) {
+    float4 *g = reinterpret_cast<float4 *>(dst) + pix;
+    #pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((uint32_t)j < nvalid) g[j] = px[j];
+  }
+};
+
 // FULL = (W % 4 == 0 and W >= 256): every lane owns 4 valid pixels, so the hot path has no per-lane size logic.
 // Everything that is rare (frame-edge pixels, out-of-table Lab values, dividends outside cdiv_fast's proven
 // zone, the exact-division redo) sits behind a WAVE-UNIFORM branch (`ballot != 0`), which keeps the common
@@ -788,16 +816,19 @@ template <typename SrcT, bool VEC, int OUT, bool FULL>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
-  constexpr bool GUARD_NORM = sizeof(SrcT) == 4;
+  constexpr bool DEMO = OUT == 3;                        // demosaic only (staged OpDemosaic)
+  constexpr bool GUARD_NORM = sizeof(SrcT) == 4 && !DEMO;
   // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB), curve knots, and one 3 KB staging
   // buffer per wave that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
-  __shared__ LutPair s_lab[kLutPairs];
-  __shared__ float s_gam[kLutPairs + 4];
+  __shared__ LutPair s_lab[DEMO ? 1 : kLutPairs];
+  __shared__ float s_gam[DEMO ? 4 : kLutPairs + 4];
   __shared__ float s_knots[5 * kSplineMaxKnots];         // base-curve knots
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
-  __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * 768 : 4];
-  load_lut_pairs(s_lab, a.lab_pairs);
-  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) s_gam[i] = a.gam_table[i];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * (DEMO ? 1024 : 768) : 4];
+  if (!DEMO) {
+    load_lut_pairs(s_lab, a.lab_pairs);
+    for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) s_gam[i] = a.gam_table[i];
+  }
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
@@ -859,6 +890,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     const float d0 = t.v0 - min0, d1 = t.v1 - min0, d2 = t.v2 - min0, d3 = t.v3 - min0, dh = t.h - min0, dh2 = t.h2 - min0;
     RowWin w;
     float h, h2 = 0.0f;
+    if (DEMO) {                                          // input is an OpBuffer already: no OpGoFloat step
+      w.v0 = t.v0; w.v1 = t.v1; w.v2 = t.v2; w.v3 = t.v3;
+      w.l = dpp_wave_shr1(t.h, w.v3);
+      const float rr0 = dpp_wave_shl1(t.h, w.v0);
+      w.r = is_last ? (single ? t.h2 : t.h) : rr0;
+      return w;
+    }
     bool redo = exact_norm;
     if (GUARD_NORM) redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
                                                                 cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
@@ -878,7 +916,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     return w;
   };
 
-  const bool store_aligned = (OUT == 0) ? true : ((OUT == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
+  const bool store_aligned = (OUT == 0 || OUT == 3) ? true : ((OUT == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
   const uint32_t Hm1 = a.H - 1, Wm1 = a.W - 1;
   const bool col_edge = lane_on && (col0 == 0 || col0 + 3 >= Wm1);
 
@@ -944,6 +982,19 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
         }
       }
     }
+    if (DEMO) {
+      if (FULL) {
+        uint32_t *stg = s_stage + (threadIdx.x >> 6) * 1024;
+        RgbeStage::stage(stg, lane, px);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        RgbeStage::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + 4u * lc0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else if (lane_on) {
+        RgbeStage::store_direct(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, px);
+      }
+      P = C; C = N;
+      continue;
+    }
     PixOut o[4];
 #if IPK_ABLATE >= 5
     for (int j = 0; j < 4; ++j) px[j] = make_float4(cw[j + 1], pw[j + 1], nw[j + 1], 0.0f);
@@ -993,10 +1044,45 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   }
 }
 
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks);
+
+// Staged demosaic::full for an RGGB-phase Bayer mosaic (OUT == 3 of the row-walking kernel).  Same band arguments as the
+// generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
+void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
+                           int xoff, int yoff, float *dst4, int num_cus, hipStream_t s) {
+  FusedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.src = src; a.dst = dst4; a.W = (uint32_t)width; a.H = (uint32_t)img_height; a.owidth = width;
+  a.row_off = (uint32_t)src_row0; a.out_r0 = (uint32_t)out_row0; a.out_r1 = (uint32_t)(out_row0 + out_rows);
+  a.xoff = xoff; a.yoff = yoff; a.range0 = 1.0f; a.inv_range0 = 1.0f;
+  unsigned blocks;
+  fused_task_grid(a, num_cus, blocks);
+  if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(dst4) & 15u) == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0)
+    hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true>), dim3(blocks), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false>), dim3(blocks), dim3(1024), 0, s, a);
+}
+
 template <typename SrcT, bool VEC, int OUT>
 static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
   if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(a.dst) & 15u) == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(1024), 0, s, a);
   else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false>), dim3(grid), dim3(1024), 0, s, a);
+}
+
+// task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks) {
+  const uint32_t waves_per_block = 16;
+  const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
+  const uint32_t total_waves = grid * waves_per_block;
+  const uint32_t w4 = (a.W + 3) / 4;
+  a.n_strips = (w4 + 63) / 64;
+  a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;   // balanced strips (generic kernel); FULL uses 64-lane strips
+  const uint32_t nrows = a.out_r1 - a.out_r0;
+  uint32_t segs = total_waves / a.n_strips;
+  if (segs < 1) segs = 1;
+  if (segs > nrows) segs = nrows;
+  a.n_segs = segs;
+  const uint32_t tasks = a.n_strips * a.n_segs;
+  blocks = (tasks + waves_per_block - 1) / waves_per_block;
 }
 
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
@@ -1015,20 +1101,8 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
 
-  // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
-  const uint32_t waves_per_block = 16;
-  const uint32_t grid = (uint32_t)(f.num_cus > 0 ? f.num_cus : 256);
-  const uint32_t total_waves = grid * waves_per_block;
-  const uint32_t w4 = (a.W + 3) / 4;
-  a.n_strips = (w4 + 63) / 64;
-  a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;   // balanced strips (generic kernel); FULL uses 64-lane strips
-  const uint32_t nrows = a.out_r1 - a.out_r0;
-  uint32_t segs = total_waves / a.n_strips;
-  if (segs < 1) segs = 1;
-  if (segs > nrows) segs = nrows;
-  a.n_segs = segs;
-  const uint32_t tasks = a.n_strips * a.n_segs;
-  const unsigned blocks = (tasks + waves_per_block - 1) / waves_per_block;
+  unsigned blocks;
+  fused_task_grid(a, f.num_cus, blocks);
 
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
   if (!f.src_is_u16) {

@@ -26,6 +26,9 @@ void launch_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size
 void launch_demosaic_full(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
                           const uint32_t *lookups_dev, float *dst4, hipStream_t s);
 
+void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
+                           int xoff, int yoff, float *dst4, int num_cus, hipStream_t s);
+
 template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
                              int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,

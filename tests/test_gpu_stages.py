@@ -95,7 +95,7 @@ def _demosaic(ipa, cfa, buf, nw=0, nh=0):
 
 
 @pytest.mark.parametrize("cfa", CFAS)
-@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (10, 10), (49, 97), (64, 256)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (10, 10), (49, 97), (64, 256), (33, 260), (21, 1028), (3, 512), (1, 256)])
 def test_demosaic_full_vs_oracle(ipa, orc, cfa, shape):
     h, w = shape
     buf = util.uniform_f32(util.SEED + 7, h * w, -0.05, 1.0).reshape(h, w)
