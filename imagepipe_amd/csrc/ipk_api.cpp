@@ -348,6 +348,20 @@ int ipk_scale_down_opbuf(const float *src4, size_t width, size_t height, size_t 
   return ipk_transform_buffer_f32(src4, width, height, 0, 0, (int64_t)width - 1, 0, 0, (int64_t)height - 1, nwidth, nheight, 4, nullptr, dst4, stream);
 }
 
+// OpGoFloat (CFA branch) + scaled_demosaic in one pass over the raw frame (used by ipk_pipeline_run when OpDemosaic::run
+// would take its scaled_demosaic branch: the 1-channel f32 intermediate never exists)
+int ipk_raw_scaled_demosaic(const void *src, int src_type, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                            float black0, float white0, const char *cfa_pat, size_t nwidth, size_t nheight, float *dst4, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst4 || !cfa_pat || !dims_ok(width, height) || !dims_ok(nwidth, nheight) || (src_type != IPK_SRC_U16 && src_type != IPK_SRC_F32))
+    return fail(IPK_ERR_INVALID, "bad raw_scaled_demosaic arguments");
+  ipk::Cfa cfa; DevCfa dev; int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
+  if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, y, width, height, black0, white0, nwidth, nheight, dev.cfa48, dst4, S(stream));
+  else ipk::launch_raw_scaled_demosaic<float>(static_cast<const float *>(src), owidth, x, y, width, height, black0, white0, nwidth, nheight, dev.cfa48, dst4, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
 int ipk_demosaic_run(const float *src, size_t width, size_t height, size_t colors, const char *cfa_pat,
                      size_t demosaic_width, size_t demosaic_height, float *dst4, size_t *out_width, size_t *out_height, void *stream) {
   REQUIRE_INIT();
@@ -643,8 +657,21 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   size_t w = r.width, h = r.height, colors;
   int monochrome = 0;
   void *buf = nullptr;
-  // gofloat
-  if (raw) {
+  // gofloat (+ demosaic when OpDemosaic::run would take its scaled_demosaic branch: one pass over the raw frame)
+  bool demosaic_done = false;
+  if (d->allow_fused && cfa_branch && d->cpp == 1) {
+    ipk::Cfa cfa;
+    const float scale = ipk::calculate_scaling_total(w, h, dw, dh).scale;
+    if (ipk::Cfa::parse(d->cfa, cfa) && cfa.valid() && scale >= ipk::demosaic_minscale(cfa.width)) {          // demosaic.rs:47-50
+      rc = sc.get(dw * dh * 4 * sizeof(float), &buf); if (rc) return rc;
+      rc = ipk_raw_scaled_demosaic(src, d->src_type, d->width, r.x, r.y, w, h, d->blacklevels[0], d->whitelevels[0], d->cfa, dw, dh,
+                                   static_cast<float *>(buf), stream);
+      if (rc < 0) return rc;
+      w = dw; h = dh; colors = 4; demosaic_done = true;
+    }
+  }
+  if (demosaic_done) {
+  } else if (raw) {
     if (d->cpp == 1 && !d->is_cfa) {
       colors = 4; monochrome = 1;
       rc = sc.get(w * h * 4 * sizeof(float), &buf); if (rc) return rc;
@@ -674,7 +701,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   }
   if (rc < 0) return rc;
   // demosaic
-  {
+  if (!demosaic_done) {
     void *o = nullptr; size_t ow, oh;
     rc = sc.get(std::max(w * h, dw * dh) * 4 * sizeof(float), &o); if (rc) return rc;
     rc = ipk_demosaic_run(static_cast<const float *>(buf), w, h, colors, d->cfa, dw, dh, static_cast<float *>(o), &ow, &oh, stream);

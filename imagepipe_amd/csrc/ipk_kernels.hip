@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstring>
+#include <cmath>
 #include "ipk_device.hpp"
 #include "ipk_launch.hpp"
 
@@ -192,8 +193,18 @@ struct TransformArgs {
   uint32_t width, height, nwidth, nheight, components;
   float tlx, tly;                 // topleft as f32
   float skip_x_x, skip_x_y, skip_y_x, skip_y_y;
+  float inv_skip_x_x, inv_skip_y_y;   // RN(1/skip) for cdiv_fast
+  int fast_x, fast_y;                 // host validated the multiply/fma division for that divisor
   int has_cfa;
+  // optional fused OpGoFloat (CFA branch, gofloat.rs:122-130/158-166): the source is the raw sensor frame
+  int norm; float min0, range0; uint64_t src_pitch, src_x, src_y;
 };
+// (v - center) / skip  (scaling.rs:104-105): cdiv_fast when the host validated the divisor and the dividend is in the proven
+// zone, the IEEE division otherwise (zero or negative skips of degenerate / rotated transforms, absurd centres)
+__device__ __forceinline__ float tb_div(float d, float skip, float inv, int fast) {
+  if (fast && !cdiv_guard(d)) return cdiv_fast(d, skip, inv);
+  return d / skip;
+}
 template <typename T> struct PixCast;
 template <> struct PixCast<float>    { static __device__ __forceinline__ float to(float v) { return v; }    static __device__ __forceinline__ float from(float f) { return f; } };
 template <> struct PixCast<uint8_t>  { static __device__ __forceinline__ float to(uint8_t v) { return (float)v; }  static __device__ __forceinline__ uint8_t from(float f) { float c = rs_min(rs_max(f, 0.0f), 255.0f); return (uint8_t)f32_as_u32_sat(c); } };
@@ -225,15 +236,19 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
     const float center_y = center_y_r + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
 
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    const uint32_t xm0 = from_x % 48;                                       // cfa.color_at(y, x) = pattern[y%48][x%48], kept incrementally
+    uint32_t ym48 = (from_y % 48) * 48;
     for (uint32_t y = from_y; y <= to_y; ++y) {
-      const float delta_y = ((float)y - center_y) / a.skip_y_y;
+      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
       const float dy2 = delta_y * delta_y;
+      uint32_t xm = xm0;
       for (uint32_t x = from_x; x <= to_x; ++x) {
-        const float delta_x = ((float)x - center_x) / a.skip_x_x;
+        const float delta_x = tb_div((float)x - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
         float factor = 1.0f - (delta_x * delta_x) - dy2;                    // scaling.rs:106
         factor = (factor < 0.0f) ? 0.0f : factor;
         if (a.has_cfa) {
-          const uint32_t c = s_cfa[(y % 48) * 48 + (x % 48)];               // cfa.color_at(y, x)
+          const uint32_t c = s_cfa[ym48 + xm];                              // cfa.color_at(y, x)
+          xm = (xm == 47) ? 0 : xm + 1;
           const float t = PixCast<T>::to(src[(size_t)y * a.width + x]) * factor;
           if (c == 0) { s0 += t; n0 += factor; }
           else if (c == 1) { s1 += t; n1 += factor; }
@@ -248,6 +263,7 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
         }
         if (x == 0xFFFFFFFFu) break;
       }
+      ym48 = (ym48 == 47 * 48) ? 0 : ym48 + 48;
       if (y == 0xFFFFFFFFu) break;
     }
     // scaling.rs:122-126: untouched components keep the zero fill
@@ -258,6 +274,24 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
     if (a.components > 3) o[3] = (n3 > 0.0f) ? PixCast<T>::from(s3 / n3) : PixCast<T>::from(0.0f);
   }
 }
+// Host check of a runtime divisor for cdiv_fast (same obligations as ipk_api.cpp's validate_cdiv_for_range): positive,
+// ordinary magnitude, and the three-step quotient equal to the IEEE one on a spread of dividends.
+static int cdiv_host_ok(float c) {
+  if (!(c >= 0x1p-60f && c <= 0x1p60f)) return 0;
+  const float rc = 1.0f / c;
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 4096; ++i) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t bits = (uint32_t)(st >> 32);
+    bits = (bits & 0x807FFFFFu) | ((100u + (bits >> 23) % 54u) << 23);       // |d| in [2^-27, 2^27): the dividends are pixel offsets
+    float d; std::memcpy(&d, &bits, 4);
+    const float q0 = d * rc;
+    const float r = std::fma(-q0, c, d);
+    if (std::fma(r, rc, q0) != d / c) return 0;
+  }
+  return 1;
+}
+
 template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
                              int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,
@@ -271,9 +305,82 @@ void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t 
   a.skip_x_y = ((float)try_ - (float)tly) / ((float)(nwidth - 1));
   a.skip_y_x = ((float)blx - (float)tlx) / ((float)(nheight - 1));
   a.skip_y_y = ((float)bly - (float)tly) / ((float)(nheight - 1));
+  a.inv_skip_x_x = 1.0f / a.skip_x_x; a.inv_skip_y_y = 1.0f / a.skip_y_y;
+  a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
   a.has_cfa = cfa48_dev != nullptr;
+  a.norm = 0; a.min0 = 0.0f; a.range0 = 1.0f; a.src_pitch = width; a.src_x = 0; a.src_y = 0;
   hipLaunchKernelGGL(k_transform_buffer<T>, grid_rows(nwidth, nheight, 128), dim3(128), 0, s, src, a, cfa48_dev, dst);
 }
+
+// OpGoFloat (CFA branch) + scaling::scaled_demosaic in one pass over the raw sensor frame: dst4 = scaled_demosaic(gofloat(src)).
+// T = uint16_t or float sensor samples; writes f32 RGBE.  (src/ops/gofloat.rs:122-130,158-166 + src/scaling.rs:132-145)
+template <typename T>
+__global__ void k_raw_scaled_demosaic(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48, float *__restrict__ dst) {
+  __shared__ uint8_t s_cfa[48 * 48];
+  for (int i = threadIdx.x; i < 48 * 48; i += blockDim.x) s_cfa[i] = cfa48[i];
+  __syncthreads();
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= a.nwidth) return;
+  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+    const float from_x_r = a.tlx + a.skip_y_x * (float)row;
+    const float to_x_r = a.tlx + a.skip_y_x * (float)(row + 1);
+    const float from_y_r = a.tly + a.skip_y_y * (float)row;
+    const float to_y_r = a.tly + a.skip_y_y * (float)(row + 1);
+    const float center_x_r = a.tlx + (a.skip_y_x * (float)row) + (a.skip_y_x / 2.0f) - 0.5f;
+    const float center_y_r = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f;
+    const uint32_t from_x = min(a.width - 1, f32_as_u32_sat(floorf(from_x_r + (a.skip_x_x * (float)col))));
+    const uint32_t to_x = min(a.width - 1, f32_as_u32_sat(floorf(to_x_r + (a.skip_x_x * (float)(col + 1)))));
+    const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(from_y_r + (a.skip_x_y * (float)col))));
+    const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(to_y_r + (a.skip_x_y * (float)(col + 1)))));
+    const float center_x = center_x_r + (a.skip_x_x * (float)col) + (a.skip_x_x / 2.0f);
+    const float center_y = center_y_r + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    const uint32_t xm0 = from_x % 48;
+    uint32_t ym48 = (from_y % 48) * 48;
+    for (uint32_t y = from_y; y <= to_y; ++y) {
+      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
+      const float dy2 = delta_y * delta_y;
+      uint32_t xm = xm0;
+      const T *rowp = src + (size_t)(y + a.src_y) * a.src_pitch + a.src_x;
+      for (uint32_t x = from_x; x <= to_x; ++x) {
+        const float delta_x = tb_div((float)x - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
+        float factor = 1.0f - (delta_x * delta_x) - dy2;
+        factor = (factor < 0.0f) ? 0.0f : factor;
+        const uint32_t c = s_cfa[ym48 + xm];
+        xm = (xm == 47) ? 0 : xm + 1;
+        const float sv = rs_min(((float)rowp[x] - a.min0) / a.range0, 1.0f);       // gofloat.rs:126
+        const float t = sv * factor;
+        if (c == 0) { s0 += t; n0 += factor; }
+        else if (c == 1) { s1 += t; n1 += factor; }
+        else if (c == 2) { s2 += t; n2 += factor; }
+        else { s3 += t; n3 += factor; }
+        if (x == 0xFFFFFFFFu) break;
+      }
+      ym48 = (ym48 == 47 * 48) ? 0 : ym48 + 48;
+      if (y == 0xFFFFFFFFu) break;
+    }
+    float4 o;
+    o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
+    reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
+  }
+}
+template <typename T>
+void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0,
+                                size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, float *dst4, hipStream_t s) {
+  TransformArgs a;
+  a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
+  a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
+  a.skip_x_x = ((float)((int64_t)width - 1) - 0.0f) / ((float)(nwidth - 1));
+  a.skip_x_y = (0.0f - 0.0f) / ((float)(nwidth - 1));
+  a.skip_y_x = (0.0f - 0.0f) / ((float)(nheight - 1));
+  a.skip_y_y = ((float)((int64_t)height - 1) - 0.0f) / ((float)(nheight - 1));
+  a.inv_skip_x_x = 1.0f / a.skip_x_x; a.inv_skip_y_y = 1.0f / a.skip_y_y;
+  a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
+  a.has_cfa = 1; a.norm = 1; a.min0 = black0; a.range0 = white0 - black0; a.src_pitch = owidth; a.src_x = x; a.src_y = y;
+  hipLaunchKernelGGL(k_raw_scaled_demosaic<T>, grid_rows(nwidth, nheight, 128), dim3(128), 0, s, src, a, cfa48_dev, dst4);
+}
+template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, size_t, size_t, const uint8_t *, float *, hipStream_t);
+template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, size_t, size_t, const uint8_t *, float *, hipStream_t);
 template void launch_transform_buffer<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, float *, hipStream_t);
 template void launch_transform_buffer<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint8_t *, hipStream_t);
 template void launch_transform_buffer<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint16_t *, hipStream_t);

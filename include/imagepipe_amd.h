@@ -171,6 +171,10 @@ IPK_API int ipk_scaled_demosaic(const float *src, size_t width, size_t height, c
                                 size_t nwidth, size_t nheight, float *dst4, void *stream);
 IPK_API int ipk_scale_down_opbuf(const float *src4, size_t width, size_t height,
                                  size_t nwidth, size_t nheight, float *dst4, void *stream);
+/* OpGoFloat::run_raw (CFA branch, src/ops/gofloat.rs:122-130,158-166) followed by scaling::scaled_demosaic
+ * (src/scaling.rs:132-145) in one pass over the raw sensor frame; src_type IPK_SRC_U16 or IPK_SRC_F32. */
+IPK_API int ipk_raw_scaled_demosaic(const void *src, int src_type, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                    float black0, float white0, const char *cfa, size_t nwidth, size_t nheight, float *dst4, void *stream);
 /* OpDemosaic::run dispatch (src/ops/demosaic.rs:27-61).  colors = 1 or 4.  dst4 must hold
  * max(width*height, demosaic_width*demosaic_height)*4 floats.  IPK_NOOP = pass-through.
  * out_width / out_height receive the result size. */
