@@ -345,3 +345,39 @@ def test_errors_are_reported_not_computed(ipa):
     assert L.ipk_size_image(0, 0, 0, 0, 9, 9, out) == -2                                    # the reference underflows below 10x10
     with pytest.raises(ipa.IpkError):
         ipa.Pipeline.new_from_source(ipa.RawImage(width=8, height=8, data=ipa.upload_u16(np.zeros((8, 8), np.uint16)), cfa="RGGB")).run()
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized sweep: sizes, CFA phase, crops, levels, white balance, camera matrix, curve, output depth
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_randomized_configurations(ipa, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    h = int(rng.integers(10, 80)); w = int(rng.choice([rng.integers(10, 300), 256, 260, 512, 4 * int(rng.integers(64, 200))]))
+    cfa = CFAS[int(rng.integers(0, 4))]
+    crops = tuple(int(v) for v in rng.integers(0, 4, 4)) if rng.integers(0, 2) else (0, 0, 0, 0)
+    if h - crops[0] - crops[2] < 10 or w - crops[1] - crops[3] < 10:
+        crops = (0, 0, 0, 0)
+    is_float = bool(rng.integers(0, 2))
+    black = float(rng.choice([0.0, 64.0, 256.5, 512.0, 1024.0])); white = float(rng.choice([1023.0, 4095.0, 16383.0, 65535.0]))
+    raw = (rng.integers(0, int(white) + 200, size=(h, w))).astype(np.uint16)
+    src = (raw.astype(np.float32) + rng.uniform(-0.5, 0.5, size=(h, w)).astype(np.float32)) if is_float else raw
+    wb = (float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.8, 1.2)), float(rng.uniform(0.5, 3.0)), float(rng.choice([np.nan, 1.0, 0.0])))
+    cm = (util.cam_matrix() * rng.uniform(0.7, 1.3, size=(3, 1)).astype(np.float32) + rng.normal(0, 0.05, size=(3, 4)).astype(np.float32)).astype(np.float32)
+    cm[:, 3] = 0.0 if rng.integers(0, 2) else rng.normal(0, 0.1, 3).astype(np.float32)
+    npts = int(rng.integers(0, 5))
+    xs = np.sort(rng.uniform(0.05, 0.95, npts)); ys = np.sort(rng.uniform(0.05, 0.95, npts))
+    points = [(float(np.float32(a)), float(np.float32(b))) for a, b in zip(xs, ys)]
+    exposure = float(rng.choice([0.0, 0.0, 0.3, -0.7]))
+    linear = bool(rng.integers(0, 2))
+    kw = dict(blacklevels=[black] * 4, whitelevels=[white] * 4, wb_coeffs=wb, cam_to_xyz_normalized=cm)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops, **kw))
+    pipe.ops.basecurve.points = points; pipe.ops.basecurve.exposure = exposure
+    pipe.globals.settings.linear = linear
+    d = lambda: _oracle_desc(orc, src, cfa, crops=crops, points=points, exposure=exposure, linear=linear, **kw)
+    got = pipe.run(); assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(d()), "randomized seed %d (%dx%d %s crops %r float %s)" % (seed, w, h, cfa, crops, is_float))
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(d()))
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(d()))
