@@ -116,6 +116,8 @@ class RawImage:
     whitelevels: Sequence[float] = (65535, 65535, 65535, 65535)
     wb_coeffs: Sequence[float] = (1.0, 1.0, 1.0, float("nan"))
     cam_to_xyz_normalized: Optional[np.ndarray] = None      # [[f32;4];3]; default SRGB_D65_43
+    cam_to_xyz: Optional[np.ndarray] = None                 # [[f32;4];3]; only OpToLab.get_temp reads it
+    xyz_to_cam: Optional[np.ndarray] = None                 # [[f32;3];4]; only OpToLab.set_temp reads it
     orientation: int = OR_NORMAL
     is_float: bool = False
 
@@ -138,6 +140,13 @@ class OtherImage:
 def upload_u16(a: np.ndarray) -> torch.Tensor:
     """uint16 numpy -> device tensor (torch has no uint16 arithmetic; the bits are kept in int16)."""
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint16).view(np.int16).reshape(-1)).cuda()
+
+
+def xyz_d65_34():
+    """XYZ_D65_34 (color_conversions.rs:9-11) from the library's own f32 inverse"""
+    o = (C.c_float * 12)()
+    _lib.check(lib().ipk_const_matrix(3, o), "ipk_const_matrix")
+    return np.array(o[:], np.float32).reshape(4, 3)
 
 
 SRGB_D65_43 = np.array([[0.4124564, 0.3575761, 0.1804375, 0.0],
@@ -305,10 +314,25 @@ class OpToLab(ImageOp):
         if isinstance(img, RawImage):
             cm = SRGB_D65_43 if img.cam_to_xyz_normalized is None else np.asarray(img.cam_to_xyz_normalized, np.float32)
             self.cam_to_xyz_normalized = cm.reshape(3, 4)
+            self.cam_to_xyz = self.cam_to_xyz_normalized if img.cam_to_xyz is None else np.asarray(img.cam_to_xyz, np.float32).reshape(3, 4)
+            self.xyz_to_cam = xyz_d65_34() if img.xyz_to_cam is None else np.asarray(img.xyz_to_cam, np.float32).reshape(4, 3)
             self.wb_coeffs = [float(v) for v in img.wb_coeffs]
         else:
-            self.cam_to_xyz_normalized = SRGB_D65_43
+            self.cam_to_xyz_normalized = self.cam_to_xyz = SRGB_D65_43
+            self.xyz_to_cam = xyz_d65_34()
             self.wb_coeffs = [1.0, 1.0, 1.0, 0.0]
+
+    def set_temp(self, temp, tint):
+        """colorspaces.rs:59-70 (host-side)"""
+        wb = (C.c_float * 4)()
+        _lib.check(lib().ipk_tolab_set_temp(_farr(self.xyz_to_cam, 12), float(temp), float(tint), wb), "ipk_tolab_set_temp")
+        self.wb_coeffs = list(wb)
+
+    def get_temp(self):
+        """colorspaces.rs:72-84 (host-side)"""
+        t, ti = C.c_float(), C.c_float()
+        _lib.check(lib().ipk_tolab_get_temp(_farr(self.cam_to_xyz, 12), _farr(self.wb_coeffs, 4), C.byref(t), C.byref(ti)), "ipk_tolab_get_temp")
+        return t.value, ti.value
 
     def run(self, pipeline, buf):
         out = OpBuffer.new(buf.width, buf.height, 3, buf.monochrome)

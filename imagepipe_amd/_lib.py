@@ -71,6 +71,11 @@ SIGNATURES = {
     "ipk_size_image": (C.c_int, [_sz] * 6 + [_szp]),
     "ipk_calculate_scaling_total": (C.c_int, [_sz] * 4 + [_fp, _szp, _szp]),
     "ipk_normalize_wbs": (C.c_int, [_fp, _fp]),
+    "ipk_const_matrix": (C.c_int, [C.c_int, _fp]),
+    "ipk_temp_to_xyz": (C.c_int, [C.c_float, _fp]),
+    "ipk_xyz_to_temp": (C.c_int, [_fp, _fp, _fp]),
+    "ipk_tolab_set_temp": (C.c_int, [_fp, C.c_float, C.c_float, _fp]),
+    "ipk_tolab_get_temp": (C.c_int, [_fp, _fp, _fp, _fp]),
     "ipk_spline_new": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "ipk_rotatecrop_calc_size": (C.c_int, [_fp, C.c_float, _sz, _sz, C.c_int, _szp, _szp]),
     "ipk_cfa_shift": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),

@@ -229,6 +229,21 @@ int ipk_calculate_scaling_total(size_t width, size_t height, size_t maxwidth, si
   return IPK_OK;
 }
 int ipk_normalize_wbs(const float *vals4, float *out4) { ipk::normalize_wbs(vals4, out4); return IPK_OK; }
+int ipk_const_matrix(int which, float *out12) {
+  if (!out12) return fail(IPK_ERR_INVALID, "ipk_const_matrix: null output");
+  const ipk::Mat33 s = ipk::srgb_d65_33(), x = ipk::inverse(s);
+  switch (which) {
+    case 0: for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out12[r * 3 + c] = s.m[r][c]; return IPK_OK;      // SRGB_D65_33
+    case 1: for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out12[r * 3 + c] = x.m[r][c]; return IPK_OK;      // XYZ_D65_33
+    case 2: ipk::srgb_d65_43(out12); return IPK_OK;                                                                   // SRGB_D65_43
+    case 3: for (int r = 0; r < 4; ++r) for (int c = 0; c < 3; ++c) out12[r * 3 + c] = r < 3 ? x.m[r][c] : 0.0f; return IPK_OK;   // XYZ_D65_34
+  }
+  return fail(IPK_ERR_INVALID, "ipk_const_matrix: which must be 0..3");
+}
+int ipk_temp_to_xyz(float temp, float *out3) { ipk::temp_to_xyz(temp, out3); return IPK_OK; }
+int ipk_xyz_to_temp(const float *xyz3, float *temp, float *tint) { ipk::xyz_to_temp(xyz3, *temp, *tint); return IPK_OK; }
+int ipk_tolab_set_temp(const float *xyz_to_cam12, float temp, float tint, float *wb4) { ipk::tolab_set_temp(xyz_to_cam12, temp, tint, wb4); return IPK_OK; }
+int ipk_tolab_get_temp(const float *cam_to_xyz12, const float *wb4, float *temp, float *tint) { ipk::tolab_get_temp(cam_to_xyz12, wb4, *temp, *tint); return IPK_OK; }
 int ipk_spline_new(const float *pts, int npts, float *px, float *py, float *c1s, float *c2s, float *c3s) {
   ipk::Spline s;
   if (!s.build(pts, npts)) return fail(IPK_ERR_INVALID, "invalid curve (%d points)", npts);

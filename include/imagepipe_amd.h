@@ -101,6 +101,15 @@ IPK_API int ipk_calculate_scaling_total(size_t width, size_t height, size_t maxw
                                         float *scale, size_t *nwidth, size_t *nheight);
 /* OpToLab's normalize_wbs (src/ops/colorspaces.rs:12-27) */
 IPK_API int ipk_normalize_wbs(const float *vals4, float *out4);
+/* The colour constants of src/color_conversions.rs:1-18: which = 0 SRGB_D65_33 (9 floats), 1 XYZ_D65_33 (9; the f32
+ * cofactor inverse, :20-39), 2 SRGB_D65_43 (12, [[f32;4];3]), 3 XYZ_D65_34 (12, [[f32;3];4]) */
+IPK_API int ipk_const_matrix(int which, float *out12);
+/* temp_to_xyz / xyz_to_temp (src/color_conversions.rs:277-310) and OpToLab::set_temp / get_temp
+ * (src/ops/colorspaces.rs:59-85): xyz_to_cam12 = [[f32;3];4], cam_to_xyz12 = [[f32;4];3], row-major */
+IPK_API int ipk_temp_to_xyz(float temp, float *out3);
+IPK_API int ipk_xyz_to_temp(const float *xyz3, float *temp, float *tint);
+IPK_API int ipk_tolab_set_temp(const float *xyz_to_cam12, float temp, float tint, float *wb4);
+IPK_API int ipk_tolab_get_temp(const float *cam_to_xyz12, const float *wb4, float *temp, float *tint);
 /* SplineFunc::new (src/ops/curves.rs:68-124): pts = npts (x,y) pairs; arrays sized >= npts+2.
  * Returns the knot count (>= 2) or a negative status. */
 IPK_API int ipk_spline_new(const float *pts, int npts, float *px, float *py, float *c1s, float *c2s, float *c3s);

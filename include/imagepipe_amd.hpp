@@ -73,6 +73,8 @@ struct ImageSource {
   float blacklevels[4] = {0, 0, 0, 0}, whitelevels[4] = {65535, 65535, 65535, 65535};
   float wb_coeffs[4] = {1.0f, 1.0f, 1.0f, NAN};
   float cam_to_xyz_normalized[12] = {0.4124564f, 0.3575761f, 0.1804375f, 0, 0.2126729f, 0.7151522f, 0.0721750f, 0, 0.0193339f, 0.1191920f, 0.9503041f, 0};
+  float cam_to_xyz[12] = {0.4124564f, 0.3575761f, 0.1804375f, 0, 0.2126729f, 0.7151522f, 0.0721750f, 0, 0.0193339f, 0.1191920f, 0.9503041f, 0};
+  bool has_xyz_to_cam = false; float xyz_to_cam[12] = {};   // [[f32;3];4]; OpToLab::set_temp only (default XYZ_D65_34)
   int orientation = IPK_OR_NORMAL;
   // Other
   int bits = 8;
@@ -182,12 +184,21 @@ struct OpRotateCrop : ImageOp {
 
 // src/ops/colorspaces.rs
 struct OpToLab : ImageOp {
-  float cam_to_xyz_normalized[12]; float wb_coeffs[4];
+  float cam_to_xyz[12]; float cam_to_xyz_normalized[12]; float xyz_to_cam[12]; float wb_coeffs[4];
   explicit OpToLab(const ImageSource &img) {
-    if (img.kind == ImageSource::Raw) { std::memcpy(cam_to_xyz_normalized, img.cam_to_xyz_normalized, sizeof(cam_to_xyz_normalized)); std::memcpy(wb_coeffs, img.wb_coeffs, sizeof(wb_coeffs)); }
-    else { const float s[12] = {0.4124564f, 0.3575761f, 0.1804375f, 0, 0.2126729f, 0.7151522f, 0.0721750f, 0, 0.0193339f, 0.1191920f, 0.9503041f, 0};
-           std::memcpy(cam_to_xyz_normalized, s, sizeof(s)); const float w[4] = {1, 1, 1, 0}; std::memcpy(wb_coeffs, w, sizeof(w)); }
+    check(ipk_const_matrix(3, xyz_to_cam), "const_matrix");
+    if (img.kind == ImageSource::Raw) {
+      std::memcpy(cam_to_xyz, img.cam_to_xyz, sizeof(cam_to_xyz));
+      std::memcpy(cam_to_xyz_normalized, img.cam_to_xyz_normalized, sizeof(cam_to_xyz_normalized));
+      if (img.has_xyz_to_cam) std::memcpy(xyz_to_cam, img.xyz_to_cam, sizeof(xyz_to_cam));
+      std::memcpy(wb_coeffs, img.wb_coeffs, sizeof(wb_coeffs));
+    } else {
+      check(ipk_const_matrix(2, cam_to_xyz), "const_matrix"); std::memcpy(cam_to_xyz_normalized, cam_to_xyz, sizeof(cam_to_xyz));
+      const float w[4] = {1, 1, 1, 0}; std::memcpy(wb_coeffs, w, sizeof(w));
+    }
   }
+  void set_temp(float temp, float tint) { check(ipk_tolab_set_temp(xyz_to_cam, temp, tint, wb_coeffs), "set_temp"); }           // :59-70
+  std::pair<float, float> get_temp() const { float t, ti; check(ipk_tolab_get_temp(cam_to_xyz, wb_coeffs, &t, &ti), "get_temp"); return {t, ti}; }   // :72-84
   const char *name() const override { return "to_lab"; }
   Buf run(const PipelineGlobals &, Buf buf) const override {
     auto out = std::make_shared<OpBuffer>(buf->width, buf->height, 3, buf->monochrome);

@@ -107,6 +107,10 @@ def _declare(L):
     sig("orc_normalize_wbs", None, _f32p, _f32p)
     sig("orc_tolab", None, _f32p, _sz, _sz, C.c_int, _f32p, _f32p, _f32p)
     sig("orc_fromlab", None, _f32p, _sz, _sz, _f32p)
+    sig("orc_temp_to_xyz", None, C.c_float, _f32p)
+    sig("orc_xyz_to_temp", None, _f32p, _f32p)
+    sig("orc_tolab_set_temp", None, _f32p, C.c_float, C.c_float, _f32p)
+    sig("orc_tolab_get_temp", None, _f32p, _f32p, _f32p)
     sig("orc_spline_new", C.c_int, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p)
     sig("orc_spline_interpolate", C.c_int, _f32p, C.c_int, _f32p, _f32p, _sz)
     sig("orc_basecurve", C.c_int, _f32p, _sz, _sz, C.c_float, _f32p, C.c_int, _f32p)
@@ -334,6 +338,22 @@ def tolab(buf4, wb_coeffs, cam_to_xyz_normalized, monochrome=False):
 def fromlab(buf3):
     buf3 = _f32(buf3); h, w, _ = buf3.shape
     out = np.empty_like(buf3); lib().orc_fromlab(buf3.ravel(), w, h, out.ravel()); return out
+
+
+def temp_to_xyz(temp):
+    o = np.empty(3, np.float32); lib().orc_temp_to_xyz(temp, o); return o
+
+
+def xyz_to_temp(xyz):
+    o = np.empty(2, np.float32); lib().orc_xyz_to_temp(_f32(xyz), o); return float(o[0]), float(o[1])
+
+
+def tolab_set_temp(xyz_to_cam, temp, tint):
+    o = np.empty(4, np.float32); lib().orc_tolab_set_temp(_f32(xyz_to_cam).ravel(), temp, tint, o); return o
+
+
+def tolab_get_temp(cam_to_xyz, wb_coeffs):
+    o = np.empty(2, np.float32); lib().orc_tolab_get_temp(_f32(cam_to_xyz).ravel(), _f32(wb_coeffs), o); return float(o[0]), float(o[1])
 
 
 def _pts(points):

@@ -696,6 +696,93 @@ ORC_API void orc_fromlab(const float *src3, size_t width, size_t height, float *
   }
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* White-balance temperature helpers  (src/color_conversions.rs:277-310,                 */
+/* src/ops/colorspaces.rs:59-85) -- host-side, once per edit, not per pixel              */
+/* ------------------------------------------------------------------------------------ */
+/* CIE 1931 2-degree standard observer colour-matching functions, 380..780 nm in 5 nm steps (public CIE data; the
+   reference tabulates the same values at src/color_conversions.rs:193-275) */
+static const double CIE_XBAR[81] = {
+  0.001368, 0.002236, 0.004243, 0.007650, 0.014310, 0.023190, 0.043510, 0.077630, 0.134380,
+  0.214770, 0.283900, 0.328500, 0.348280, 0.348060, 0.336200, 0.318700, 0.290800, 0.251100,
+  0.195360, 0.142100, 0.095640, 0.057950, 0.032010, 0.014700, 0.004900, 0.002400, 0.009300,
+  0.029100, 0.063270, 0.109600, 0.165500, 0.225750, 0.290400, 0.359700, 0.433450, 0.512050,
+  0.594500, 0.678400, 0.762100, 0.842500, 0.916300, 0.978600, 1.026300, 1.056700, 1.062200,
+  1.045600, 1.002600, 0.938400, 0.854450, 0.751400, 0.642400, 0.541900, 0.447900, 0.360800,
+  0.283500, 0.218700, 0.164900, 0.121200, 0.087400, 0.063600, 0.046770, 0.032900, 0.022700,
+  0.015840, 0.011359, 0.008111, 0.005790, 0.004109, 0.002899, 0.002049, 0.001440, 0.001000,
+  0.000690, 0.000476, 0.000332, 0.000235, 0.000166, 0.000117, 0.000083, 0.000059, 0.000042,
+};
+static const double CIE_YBAR[81] = {
+  0.000039, 0.000064, 0.000120, 0.000217, 0.000396, 0.000640, 0.001210, 0.002180, 0.004000,
+  0.007300, 0.011600, 0.016840, 0.023000, 0.029800, 0.038000, 0.048000, 0.060000, 0.073900,
+  0.090980, 0.112600, 0.139020, 0.169300, 0.208020, 0.258600, 0.323000, 0.407300, 0.503000,
+  0.608200, 0.710000, 0.793200, 0.862000, 0.914850, 0.954000, 0.980300, 0.994950, 1.000000,
+  0.995000, 0.978600, 0.952000, 0.915400, 0.870000, 0.816300, 0.757000, 0.694900, 0.631000,
+  0.566800, 0.503000, 0.441200, 0.381000, 0.321000, 0.265000, 0.217000, 0.175000, 0.138200,
+  0.107000, 0.081600, 0.061000, 0.044580, 0.032000, 0.023200, 0.017000, 0.011920, 0.008210,
+  0.005723, 0.004102, 0.002929, 0.002091, 0.001484, 0.001047, 0.000740, 0.000520, 0.000361,
+  0.000249, 0.000172, 0.000120, 0.000085, 0.000060, 0.000042, 0.000030, 0.000021, 0.000015,
+};
+static const double CIE_ZBAR[81] = {
+  0.006450, 0.010550, 0.020050, 0.036210, 0.067850, 0.110200, 0.207400, 0.371300, 0.645600,
+  1.039050, 1.385600, 1.622960, 1.747060, 1.782600, 1.772110, 1.744100, 1.669200, 1.528100,
+  1.287640, 1.041900, 0.812950, 0.616200, 0.465180, 0.353300, 0.272000, 0.212300, 0.158200,
+  0.111700, 0.078250, 0.057250, 0.042160, 0.029840, 0.020300, 0.013400, 0.008750, 0.005750,
+  0.003900, 0.002750, 0.002100, 0.001800, 0.001650, 0.001400, 0.001100, 0.001000, 0.000800,
+  0.000600, 0.000340, 0.000240, 0.000190, 0.000100, 0.000050, 0.000030, 0.000020, 0.000010,
+  0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000,
+  0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000,
+  0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000, 0.000000,
+};
+
+/* f64::powi(5) == compiler-rt/libgcc __powidf2: square-and-multiply */
+static double powi5(double a) { double r = 1.0; int b = 5; for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; } return r; }
+
+/* color_conversions.rs:277-293 */
+ORC_API void orc_temp_to_xyz(float temp, float *out3) {
+  const double C1 = 3.7417717905326694e-16, C2 = 0.014387773457709927;
+  double xyz[3] = {0.0, 0.0, 0.0};
+  for (int i = 0; i < 81; i++) {
+    double wavelength = (double)(380 + 5 * i) / 1.0e9;
+    double power = C1 / (powi5(wavelength) * (exp(C2 / ((double)temp * wavelength)) - 1.0));
+    xyz[0] += power * CIE_XBAR[i]; xyz[1] += power * CIE_YBAR[i]; xyz[2] += power * CIE_ZBAR[i];
+  }
+  double mx = fmax(fmax(xyz[0], xyz[1]), xyz[2]);
+  out3[0] = (float)(xyz[0] / mx); out3[1] = (float)(xyz[1] / mx); out3[2] = (float)(xyz[2] / mx);
+}
+/* color_conversions.rs:295-310 */
+ORC_API void orc_xyz_to_temp(const float *xyz, float *temp_tint) {
+  float mn = 1000.0f, mx = 40000.0f, temp = 0.0f;
+  float n[3] = {0.0f, 0.0f, 0.0f};
+  while ((mx - mn) > 1.0f) {
+    temp = (mx + mn) / 2.0f;
+    orc_temp_to_xyz(temp, n);
+    if ((n[2] / n[0]) > (xyz[2] / xyz[0])) mx = temp; else mn = temp;
+  }
+  temp_tint[0] = temp; temp_tint[1] = (n[1] / n[0]) / (xyz[1] / xyz[0]);
+}
+/* OpToLab::set_temp (colorspaces.rs:59-70); xyz_to_cam is [[f32;3];4] row-major; writes wb_coeffs[4] */
+ORC_API void orc_tolab_set_temp(const float *xyz_to_cam12, float temp, float tint, float *wb4) {
+  float t[3]; orc_temp_to_xyz(temp, t);
+  float xyz[3] = {t[0], t[1] / tint, t[2]};
+  float w[4];
+  for (int i = 0; i < 4; i++) {
+    w[i] = 0.0f;
+    for (int j = 0; j < 3; j++) w[i] += xyz_to_cam12[i * 3 + j] * xyz[j];
+    w[i] = 1.0f / w[i];
+  }
+  orc_normalize_wbs(w, wb4);
+}
+/* OpToLab::get_temp (colorspaces.rs:72-84); cam_to_xyz is [[f32;4];3] row-major */
+ORC_API void orc_tolab_get_temp(const float *cam_to_xyz12, const float *wb4, float *temp_tint) {
+  float xyz[3] = {0.0f, 0.0f, 0.0f};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) { float mul = wb4[j]; if (mul > 0.0f) xyz[i] += cam_to_xyz12[i * 4 + j] / mul; }
+  orc_xyz_to_temp(xyz, temp_tint);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* OpBaseCurve / SplineFunc  (src/ops/curves.rs:33-157)                                   */
 /* ------------------------------------------------------------------------------------ */

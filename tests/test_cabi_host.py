@@ -169,3 +169,44 @@ def test_pipeline_sizes_random_vs_oracle(L, orc):
         od = orc.make_pipeline(np.zeros((h, w, 3), np.uint8), maxwidth=kw["maxwidth"], maxheight=kw["maxheight"], rotation=kw["rotation"],
                                crops=(kw["crop_top"], kw["crop_right"], kw["crop_bottom"], kw["crop_left"]), rotatecrop=rc)
         assert ((a.value, b.value), (c.value, e.value)) == orc.pipeline_sizes(od)
+
+
+def test_wb_temperature_helpers_vs_oracle(L, orc):
+    """temp_to_xyz / xyz_to_temp / OpToLab::set_temp / get_temp (host-only maths; no reference test pins them)"""
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    for temp in [1000.0, 2500.0, 3200.5, 5003.0, 6504.0, 9000.0, 25000.0, 40000.0]:
+        o = (C.c_float * 3)(); L.ipk_temp_to_xyz(temp, o)
+        want = orc.temp_to_xyz(temp)
+        assert np.array_equal(np.array(o[:], np.float32).view(np.uint32), want.view(np.uint32))
+        assert max(o[:]) == 1.0
+        t, ti = C.c_float(), C.c_float()
+        L.ipk_xyz_to_temp(fa(want), C.byref(t), C.byref(ti))
+        assert (np.float32(t.value), np.float32(ti.value)) == tuple(np.float32(v) for v in orc.xyz_to_temp(want))
+        assert abs(t.value - temp) <= 2.0 and abs(ti.value - 1.0) < 1e-3        # round trip of the bisection
+    # independent anchor: the Planckian locus at 6500 K has CIE 1931 chromaticity (0.3135, 0.3237) (published value)
+    p = orc.temp_to_xyz(6500.0).astype(np.float64)
+    assert abs(p[0] / p.sum() - 0.3135) < 2e-4 and abs(p[1] / p.sum() - 0.3237) < 2e-4
+    xyz_to_cam = np.array([[0.9, 0.1, -0.05], [-0.3, 1.2, 0.1], [0.05, -0.2, 1.1], [0.0, 0.0, 0.0]], np.float32)
+    cam_to_xyz = np.array([[0.6, 0.3, 0.1, 0.0], [0.25, 0.7, 0.05, 0.0], [0.02, 0.1, 0.9, 0.0]], np.float32)
+    for temp, tint in [(5000.0, 1.0), (3000.0, 1.1), (7500.0, 0.9)]:
+        wb = (C.c_float * 4)(); L.ipk_tolab_set_temp(fa(xyz_to_cam.ravel()), temp, tint, wb)
+        assert np.array_equal(np.array(wb[:], np.float32).view(np.uint32), orc.tolab_set_temp(xyz_to_cam, temp, tint).view(np.uint32))
+        t, ti = C.c_float(), C.c_float()
+        L.ipk_tolab_get_temp(fa(cam_to_xyz.ravel()), wb, C.byref(t), C.byref(ti))
+        assert (np.float32(t.value), np.float32(ti.value)) == tuple(np.float32(v) for v in orc.tolab_get_temp(cam_to_xyz, np.array(wb[:], np.float32)))
+
+
+def test_const_matrices_and_mirror_temp(L, orc):
+    m = (C.c_float * 12)()
+    L.ipk_const_matrix(0, m); assert np.array_equal(np.array(m[:9], np.float32), orc.const_srgb_d65_33().ravel())
+    L.ipk_const_matrix(1, m); assert np.array_equal(np.array(m[:9], np.float32).view(np.uint32), orc.const_xyz_d65_33().ravel().view(np.uint32))
+    L.ipk_const_matrix(2, m); assert np.array_equal(np.array(m[:], np.float32), orc.const_srgb_d65_43().ravel())
+    L.ipk_const_matrix(3, m); assert np.array_equal(np.array(m[:9], np.float32), orc.const_xyz_d65_33().ravel()) and m[9:] == [0.0] * 3
+    assert L.ipk_const_matrix(4, m) == -2
+    import imagepipe_amd as ip
+    op = ip.OpToLab(ip.OtherImage(16, 16, None))
+    op.set_temp(5000.0, 1.0)
+    want = orc.tolab_set_temp(np.vstack([orc.const_xyz_d65_33(), np.zeros((1, 3), np.float32)]), 5000.0, 1.0)
+    assert np.array_equal(np.array(op.wb_coeffs, np.float32).view(np.uint32), want.view(np.uint32))
+    t, ti = op.get_temp()
+    assert abs(t - 5000.0) < 3.0 and abs(ti - 1.0) < 2e-3
