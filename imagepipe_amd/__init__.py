@@ -435,8 +435,47 @@ class PipelineOps:
         return [getattr(self, n) for n in self.ORDER]
 
 
+class PipelineCache:
+    """Pipeline::new_cache(size) (src/pipeline.rs:43,258-260): byte-budgeted LRU of device OpBuffers keyed by op hash."""
+
+    def __init__(self, max_bytes):
+        h = C.c_void_p()
+        _lib.check(lib().ipk_cache_new(int(max_bytes), C.byref(h)), "ipk_cache_new")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().ipk_cache_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def clear(self):
+        _lib.check(lib().ipk_cache_clear(self.handle), "ipk_cache_clear")
+
+    def contains(self, key: bytes) -> bool:
+        return bool(_lib.check(lib().ipk_cache_contains(self.handle, key), "ipk_cache_contains"))
+
+    def stats(self):
+        b, e = C.c_size_t(), C.c_size_t()
+        hi, mi, ev = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(lib().ipk_cache_stats(self.handle, C.byref(b), C.byref(e), C.byref(hi), C.byref(mi), C.byref(ev)), "ipk_cache_stats")
+        return dict(bytes=b.value, entries=e.value, hits=hi.value, misses=mi.value, evictions=ev.value)
+
+    def get(self, key: bytes):
+        """Copy of the memoised buffer as a numpy array (tests), or None."""
+        p, w, h, c, m = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
+        rc = _lib.check(lib().ipk_cache_get(self.handle, key, C.byref(p), C.byref(w), C.byref(h), C.byref(c), C.byref(m)), "ipk_cache_get")
+        if rc == IPK_NOOP:
+            return None
+        out = np.empty(w.value * h.value * c.value, np.float32)
+        _lib.check(lib().ipk_stream_sync(_stream()), "ipk_stream_sync")
+        _lib.check(lib().ipk_memcpy_d2h(out.ctypes.data, p, out.nbytes, None), "ipk_memcpy_d2h")
+        return out.reshape(h.value, w.value, c.value)
+
+
 class Pipeline:
-    """src/pipeline.rs:246-470 (cache == None; hashing/caching/serialisation are out of scope).
+    """src/pipeline.rs:246-470.  Settings (de)serialisation is out of scope.
 
     `run()` hands the whole op list to the C driver (ipk_pipeline_run), which uses the fused
     raw->sRGB kernel when every op between gofloat and gamma allows it and the staged kernels
@@ -448,6 +487,8 @@ class Pipeline:
         self.ops = PipelineOps(img)
         self.allow_fused = True
         self.last_used_fused = None
+        self.last_ops_run = None              # bit i set when op i executed in the last run (0 = served from the cache)
+        self.source_id = 0                    # extension of the hash chain: identifies the frame inside a shared PipelineCache
 
     @staticmethod
     def new_from_source(img):
@@ -516,30 +557,45 @@ class Pipeline:
         _lib.check(lib().ipk_pipeline_sizes(C.byref(d), C.byref(a), C.byref(b), C.byref(c), C.byref(e)), "ipk_pipeline_sizes")
         return (a.value, b.value), (c.value, e.value)
 
-    def _run(self, out_type, out: Optional[torch.Tensor] = None):
+    def hashes(self, out_type=OUT_F32):
+        """The eight chained op hashes of pipeline.rs:342-361 (host-only)."""
+        d = self.desc()
+        out = C.create_string_buffer(256)
+        _lib.check(lib().ipk_pipeline_hashes(C.byref(d), out_type, int(self.source_id), out), "ipk_pipeline_hashes")
+        return [out.raw[32 * i: 32 * i + 32] for i in range(8)]
+
+    def _run(self, out_type, out: Optional[torch.Tensor] = None, cache: Optional[PipelineCache] = None):
         d = self.desc()
         _, (fw, fh) = self.sizes()
         dt = {OUT_F32: torch.float32, OUT_U8: torch.uint8, OUT_U16: torch.int16}[out_type]
         if out is None:
             out = torch.empty(fw * fh * 3, dtype=dt, device="cuda")
         used = C.c_int(0)
-        _lib.check(lib().ipk_pipeline_run(C.byref(d), _ptr(self.globals.image.data), _ptr(out), out_type, C.byref(used), _stream()),
-                   "ipk_pipeline_run")
+        if cache is None:
+            _lib.check(lib().ipk_pipeline_run(C.byref(d), _ptr(self.globals.image.data), _ptr(out), out_type, C.byref(used), _stream()),
+                       "ipk_pipeline_run")
+            self.last_ops_run = 0xFF
+        else:
+            mask = C.c_int(0)
+            _lib.check(lib().ipk_pipeline_run_cached(C.byref(d), _ptr(self.globals.image.data), int(self.source_id), cache.handle, out_type,
+                                                     _ptr(out), C.byref(mask), C.byref(used), _stream()), "ipk_pipeline_run_cached")
+            self.last_ops_run = mask.value
         self.last_used_fused = bool(used.value)
         return out, fw, fh
 
-    def run(self, out: Optional[torch.Tensor] = None) -> OpBuffer:
-        data, w, h = self._run(OUT_F32, out)
+    def run(self, cache: Optional[PipelineCache] = None, out: Optional[torch.Tensor] = None) -> OpBuffer:
+        """Pipeline::run(cache) (pipeline.rs:311-375)"""
+        data, w, h = self._run(OUT_F32, out, cache)
         return OpBuffer(w, h, 3, False, data)
 
-    def output_8bit(self):
+    def output_8bit(self, cache: Optional[PipelineCache] = None):
         """Pipeline::output_8bit slow path (pipeline.rs:404-421): returns (width, height, uint8 device tensor)."""
-        data, w, h = self._run(OUT_U8)
+        data, w, h = self._run(OUT_U8, None, cache)
         return w, h, data
 
-    def output_16bit(self):
+    def output_16bit(self, cache: Optional[PipelineCache] = None):
         """Pipeline::output_16bit slow path (pipeline.rs:451-468): uint16 bits in an int16 device tensor."""
-        data, w, h = self._run(OUT_U16)
+        data, w, h = self._run(OUT_U16, None, cache)
         return w, h, data
 
 

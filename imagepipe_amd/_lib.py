@@ -128,6 +128,16 @@ SIGNATURES = {
     "ipk_selftest_lut_weight": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_clamp01": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_cbrtf": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
+    "ipk_selftest_cache_put": (C.c_int, [_vp, C.c_char_p, _sz]),
+    "ipk_selftest_sha256": (C.c_int, [C.c_char_p, _sz, C.c_char_p]),
+    "ipk_pipeline_hashes": (C.c_int, [C.POINTER(PipelineDesc), C.c_int, C.c_uint64, C.c_char_p]),
+    "ipk_cache_new": (C.c_int, [_sz, C.POINTER(C.c_void_p)]),
+    "ipk_cache_free": (C.c_int, [_vp]),
+    "ipk_cache_clear": (C.c_int, [_vp]),
+    "ipk_cache_contains": (C.c_int, [_vp, C.c_char_p]),
+    "ipk_cache_stats": (C.c_int, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ipk_cache_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int)]),
+    "ipk_pipeline_run_cached": (C.c_int, [C.POINTER(PipelineDesc), _vp, C.c_uint64, _vp, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/imagepipe_amd.h"
+#include "ipk_hash.hpp"
 #include "ipk_host.hpp"
 #include "ipk_launch.hpp"
 
@@ -148,7 +149,26 @@ bool validate_cdiv_for_range_uncached(float black, float range, bool src_is_u16)
   return true;
 }
 
+// One cached OpBuffer: device memory owned by the cache (and by whoever still holds the shared_ptr).
+struct CBuf {
+  void *p = nullptr; size_t w = 0, h = 0, colors = 0; int mono = 0;
+  ~CBuf() { if (p) (void)hipFree(p); }
+  size_t bytes() const { return w * h * colors * sizeof(float); }        // pipeline.rs:369
+};
+using CBufP = std::shared_ptr<CBuf>;
+int cbuf_new(size_t w, size_t h, size_t colors, int mono, CBufP &out) {
+  out = std::make_shared<CBuf>();
+  out->w = w; out->h = h; out->colors = colors; out->mono = mono;
+  if (hipMalloc(&out->p, std::max<size_t>(out->bytes(), 1)) != hipSuccess) { out->p = nullptr; return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", out->bytes()); }
+  return IPK_OK;
+}
+
 }  // namespace
+
+struct ipk_cache {
+  ipk::LruByteCache<CBuf> lru;
+  explicit ipk_cache(size_t bytes) : lru(bytes) {}
+};
 
 extern "C" {
 
@@ -788,6 +808,252 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   else if (out_type == IPK_OUT_U16) rc = ipk_output16bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint16_t *>(dst), stream);
   else rc = IPK_OK;
   return rc < 0 ? rc : IPK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pipeline::run with a cache (src/pipeline.rs:341-372): hash chain + memoised device OpBuffers
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Negotiated {
+  ipk::Rect r; size_t dw, dh, fw, fh; ipk::RotateCrop rc; int linear; int orientation; bool transform_noop;
+};
+int negotiate(const ipk_pipeline_desc *d, int out_type, Negotiated &n) {
+  if (!d) return fail(IPK_ERR_INVALID, "null descriptor");
+  if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  int rc = ipk_pipeline_sizes(d, &n.dw, &n.dh, &n.fw, &n.fh); if (rc) return rc;
+  ipk::size_image(d->crop_top, d->crop_right, d->crop_bottom, d->crop_left, d->width, d->height, n.r);
+  n.rc = ipk::RotateCrop();
+  n.rc.crop_top = d->rotatecrop[0]; n.rc.crop_right = d->rotatecrop[1]; n.rc.crop_bottom = d->rotatecrop[2];
+  n.rc.crop_left = d->rotatecrop[3]; n.rc.rotation = d->rotatecrop[4];
+  { // the state the two folds leave in the op (pipeline.rs:318-335), which its Serialize impl exposes to the hash
+    size_t w = n.r.width, h = n.r.height;
+    n.rc.transform_forward(w, h, w, h);
+    ipk::transform_forward(d->rotation, w, h, w, h);
+    w = n.fw; h = n.fh;
+    ipk::transform_forward(d->rotation, w, h, w, h);
+    n.rc.transform_reverse(w, h, w, h);
+  }
+  n.linear = out_type == IPK_OUT_U8 ? 0 : (out_type == IPK_OUT_U16 ? 1 : (d->linear != 0));
+  n.orientation = ipk::transform_orientation(d->rotation, d->fliph != 0, d->flipv != 0);
+  n.transform_noop = n.orientation == IPK_OR_NORMAL || n.orientation == IPK_OR_UNKNOWN;
+  return IPK_OK;
+}
+// ophashes[0..7] of pipeline.rs:342-361.  Field order follows the reference structs.
+void hash_chain(const ipk_pipeline_desc *d, const Negotiated &n, uint64_t source_id, ipk::BufHash out[8]) {
+  ipk::BufHasher h;
+  // PipelineSettings (pipeline.rs:110-137)
+  h.usize(d->maxwidth); h.usize(d->maxheight); h.usize(n.dw); h.usize(n.dh); h.boolean(n.linear != 0); h.boolean(true);
+  // gofloat (gofloat.rs:4-12).  The reference hashes no identity of the image at all (a PipelineCache is only
+  // valid for one source); source_id + the source geometry make one cache safe across several resident frames.
+  h.str_raw("gofloat");
+  h.usize(d->crop_top); h.usize(d->crop_right); h.usize(d->crop_bottom); h.usize(d->crop_left); h.boolean(d->is_cfa != 0);
+  h.f32s(d->blacklevels, 4); h.f32s(d->whitelevels, 4);
+  h.u64(source_id); h.u64(uint64_t(d->src_type)); h.usize(d->width); h.usize(d->height); h.u64(uint64_t(d->cpp));
+  out[0] = h.result();
+  h.str_raw("demosaic"); h.string(d->cfa);                                               // demosaic.rs:4-6
+  out[1] = h.result();
+  h.str_raw("rotatecrop");                                                               // rotatecrop.rs:10-18
+  h.f32(n.rc.crop_top); h.f32(n.rc.crop_right); h.f32(n.rc.crop_bottom); h.f32(n.rc.crop_left); h.f32(n.rc.rotation);
+  h.f32(n.rc.input_ratio); h.boolean(n.rc.has_output); if (n.rc.has_output) { h.usize(n.rc.out_w); h.usize(n.rc.out_h); }
+  out[2] = h.result();
+  h.str_raw("to_lab"); h.f32s(d->cam_to_xyz_normalized, 12); h.f32s(d->wb_coeffs, 4);   // colorspaces.rs:5-10 (the fields run() reads)
+  out[3] = h.result();
+  h.str_raw("basecurve"); h.f32(d->exposure); h.u64(uint64_t(d->npoints)); h.f32s(d->points, size_t(2 * std::max(0, d->npoints)));   // curves.rs:6-9
+  out[4] = h.result();
+  h.str_raw("from_lab"); out[5] = h.result();
+  h.str_raw("gamma"); out[6] = h.result();
+  h.str_raw("transform"); h.u64(uint64_t(d->rotation)); h.boolean(d->fliph != 0); h.boolean(d->flipv != 0);                          // transform.rs:15-19
+  out[7] = h.result();
+}
+ipk::BufHash key_of(const uint8_t *k) { ipk::BufHash b; std::memcpy(b.data(), k, 32); return b; }
+}  // namespace
+
+int ipk_pipeline_hashes(const ipk_pipeline_desc *d, int out_type, uint64_t source_id, uint8_t *out256) {
+  if (!out256) return fail(IPK_ERR_INVALID, "null output");
+  Negotiated n; int rc = negotiate(d, out_type, n); if (rc) return rc;
+  if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
+  ipk::BufHash hs[8]; hash_chain(d, n, source_id, hs);
+  for (int i = 0; i < 8; ++i) std::memcpy(out256 + 32 * i, hs[i].data(), 32);
+  return IPK_OK;
+}
+
+int ipk_cache_new(size_t max_bytes, ipk_cache **out) {
+  if (!out) return fail(IPK_ERR_INVALID, "null output");
+  *out = new ipk_cache(max_bytes);
+  return IPK_OK;
+}
+int ipk_cache_free(ipk_cache *c) {
+  if (c) { if (g.ready) (void)hipDeviceSynchronize(); delete c; }
+  return IPK_OK;
+}
+int ipk_cache_clear(ipk_cache *c) {
+  if (!c) return fail(IPK_ERR_INVALID, "null cache");
+  if (g.ready) (void)hipDeviceSynchronize();
+  c->lru.clear();
+  return IPK_OK;
+}
+int ipk_cache_contains(const ipk_cache *c, const uint8_t *key32) {
+  if (!c || !key32) return fail(IPK_ERR_INVALID, "null argument");
+  return c->lru.contains(key_of(key32)) ? 1 : 0;
+}
+int ipk_cache_stats(const ipk_cache *c, size_t *bytes, size_t *entries, uint64_t *hits, uint64_t *misses, uint64_t *evictions) {
+  if (!c) return fail(IPK_ERR_INVALID, "null cache");
+  size_t b, e; uint64_t hi, mi, ev; c->lru.stats(b, e, hi, mi, ev);
+  if (bytes) *bytes = b; if (entries) *entries = e; if (hits) *hits = hi; if (misses) *misses = mi; if (evictions) *evictions = ev;
+  return IPK_OK;
+}
+int ipk_cache_get(ipk_cache *c, const uint8_t *key32, const float **data, size_t *width, size_t *height, size_t *colors, int *monochrome) {
+  if (!c || !key32) return fail(IPK_ERR_INVALID, "null argument");
+  CBufP b = c->lru.get(key_of(key32));
+  if (!b) return IPK_NOOP;
+  if (data) *data = static_cast<const float *>(b->p);
+  if (width) *width = b->w; if (height) *height = b->h; if (colors) *colors = b->colors; if (monochrome) *monochrome = b->mono;
+  return IPK_OK;
+}
+int ipk_selftest_cache_put(ipk_cache *c, const uint8_t *key32, size_t bytes) {   // LRU bookkeeping without device memory (CPU tests)
+  if (!c || !key32) return fail(IPK_ERR_INVALID, "null argument");
+  c->lru.put(key_of(key32), std::make_shared<CBuf>(), bytes);
+  return IPK_OK;
+}
+int ipk_selftest_sha256(const void *data, size_t n, uint8_t *out32) {
+  ipk::Sha256 s; s.update(data, n); const auto r = s.result(); std::memcpy(out32, r.data(), 32); return IPK_OK;
+}
+
+int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_t source_id, ipk_cache *cache, int out_type, void *dst,
+                            int *ops_run, int *used_fused, void *stream) {
+  REQUIRE_INIT();
+  if (!d || !src || !dst || !cache) return fail(IPK_ERR_INVALID, "null argument");
+  if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
+  Negotiated n; int rc = negotiate(d, out_type, n); if (rc) return rc;
+  ipk::BufHash hs[8]; hash_chain(d, n, source_id, hs);
+  if (ops_run) *ops_run = 0;
+  if (used_fused) *used_fused = 0;
+  hipStream_t st = S(stream);
+
+  // the latest op whose output is memoised (pipeline.rs:352-361: every hash is looked up, the last hit wins)
+  CBufP buf; int startpos = 0;
+  for (int i = 0; i < 8; ++i) { CBufP hit = cache->lru.get(hs[i]); if (hit) { buf = hit; startpos = i + 1; } }
+
+  const bool raw = d->src_type == IPK_SRC_U16 || d->src_type == IPK_SRC_F32;
+  const bool cfa_branch = raw && !(d->cpp == 1 && !d->is_cfa) && d->cpp != 3;
+  const size_t w0 = n.r.width, h0 = n.r.height;
+  int mask = 0;
+
+  // Nothing memoised and the whole chain is one fused launch: cheaper on this machine than materialising seven
+  // intermediates; only the final buffer enters the cache.
+  if (startpos == 0 && d->allow_fused && cfa_branch && d->cpp == 1 && n.rc.noop() && n.transform_noop) {
+    const float scale = ipk::calculate_scaling_total(w0, h0, n.dw, n.dh).scale;
+    ipk::Cfa cfa; int xo, yo;
+    if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && cfa.bayer_phase(xo, yo)) {
+      ipk_pipeline_desc d2 = *d; d2.linear = n.linear;
+      CBufP o; rc = cbuf_new(n.fw, n.fh, 3, 0, o); if (rc) return rc;
+      int fused = 0;
+      rc = ipk_pipeline_run(&d2, src, o->p, IPK_OUT_F32, &fused, stream); if (rc < 0) return rc;
+      cache->lru.put(hs[7], o, o->bytes());
+      buf = o; startpos = 8; mask = 0xFF;
+      if (used_fused) *used_fused = fused;
+    }
+  }
+
+  for (int i = startpos; i < 8; ++i) {
+    CBufP o;
+    switch (i) {
+      case 0: {                                                          // gofloat
+        if (d->allow_fused && cfa_branch && d->cpp == 1) {               // + demosaic in the same pass when it would scale
+          ipk::Cfa cfa;
+          const float scale = ipk::calculate_scaling_total(w0, h0, n.dw, n.dh).scale;
+          if (ipk::Cfa::parse(d->cfa, cfa) && cfa.valid() && scale >= ipk::demosaic_minscale(cfa.width) && !cache->lru.contains(hs[1])) {
+            rc = cbuf_new(n.dw, n.dh, 4, 0, o); if (rc) return rc;
+            rc = ipk_raw_scaled_demosaic(src, d->src_type, d->width, n.r.x, n.r.y, w0, h0, d->blacklevels[0], d->whitelevels[0], d->cfa, n.dw, n.dh,
+                                         static_cast<float *>(o->p), stream);
+            if (rc < 0) return rc;
+            mask |= 3; buf = o; cache->lru.put(hs[1], o, o->bytes()); i = 1;   // op 1's output; op 0's is never materialised
+            continue;
+          }
+        }
+        if (raw) {
+          if (d->cpp == 1 && !d->is_cfa) {
+            rc = cbuf_new(w0, h0, 4, 1, o); if (rc) return rc;
+            rc = d->src_type == IPK_SRC_U16
+              ? ipk_gofloat_mono_u16(static_cast<const uint16_t *>(src), d->width, n.r.x, n.r.y, w0, h0, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(o->p), stream)
+              : ipk_gofloat_mono_f32(static_cast<const float *>(src), d->width, n.r.x, n.r.y, w0, h0, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(o->p), stream);
+          } else if (d->cpp == 3) {
+            rc = cbuf_new(w0, h0, 4, 0, o); if (rc) return rc;
+            rc = d->src_type == IPK_SRC_U16
+              ? ipk_gofloat_rgb_u16(static_cast<const uint16_t *>(src), d->width, n.r.x, n.r.y, w0, h0, d->blacklevels, d->whitelevels, static_cast<float *>(o->p), stream)
+              : ipk_gofloat_rgb_f32(static_cast<const float *>(src), d->width, n.r.x, n.r.y, w0, h0, d->blacklevels, d->whitelevels, static_cast<float *>(o->p), stream);
+          } else {
+            if (d->cpp != 1) return fail(IPK_ERR_UNSUPPORTED, "cpp=%d sources are not supported", d->cpp);
+            rc = cbuf_new(w0, h0, 1, 0, o); if (rc) return rc;
+            rc = d->src_type == IPK_SRC_U16
+              ? ipk_gofloat_cfa_u16(static_cast<const uint16_t *>(src), d->width, n.r.x, n.r.y, w0, h0, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(o->p), stream)
+              : ipk_gofloat_cfa_f32(static_cast<const float *>(src), d->width, n.r.x, n.r.y, w0, h0, d->blacklevels[0], d->whitelevels[0], static_cast<float *>(o->p), stream);
+          }
+        } else {
+          rc = cbuf_new(w0, h0, 4, 0, o); if (rc) return rc;
+          rc = d->src_type == IPK_SRC_RGB8
+            ? ipk_gofloat_other_u8(static_cast<const uint8_t *>(src), d->width, n.r.x, n.r.y, w0, h0, static_cast<float *>(o->p), stream)
+            : ipk_gofloat_other_u16(static_cast<const uint16_t *>(src), d->width, n.r.x, n.r.y, w0, h0, static_cast<float *>(o->p), stream);
+        }
+        break;
+      }
+      case 1: {                                                          // demosaic
+        size_t ow, oh;
+        rc = cbuf_new(std::max(buf->w, n.dw), std::max(buf->h, n.dh), 4, buf->mono, o); if (rc) return rc;
+        rc = ipk_demosaic_run(static_cast<const float *>(buf->p), buf->w, buf->h, buf->colors, d->cfa, n.dw, n.dh, static_cast<float *>(o->p), &ow, &oh, stream);
+        if (rc >= 0 && rc != IPK_NOOP) { o->w = ow; o->h = oh; }
+        break;
+      }
+      case 2: {                                                          // rotatecrop
+        size_t ow, oh;
+        rc = ipk_rotatecrop(static_cast<const float *>(buf->p), buf->w, buf->h, buf->colors, d->rotatecrop, nullptr, &ow, &oh, stream);
+        if (rc < 0 || rc == IPK_NOOP) break;
+        rc = cbuf_new(ow, oh, buf->colors, buf->mono, o); if (rc) return rc;
+        rc = ipk_rotatecrop(static_cast<const float *>(buf->p), buf->w, buf->h, buf->colors, d->rotatecrop, static_cast<float *>(o->p), &ow, &oh, stream);
+        break;
+      }
+      case 3:                                                            // to_lab
+        rc = cbuf_new(buf->w, buf->h, 3, buf->mono, o); if (rc) return rc;
+        rc = ipk_tolab(static_cast<const float *>(buf->p), buf->w, buf->h, buf->mono, d->wb_coeffs, d->cam_to_xyz_normalized, static_cast<float *>(o->p), stream);
+        break;
+      case 4:                                                            // basecurve
+        if (curve_is_noop(d->exposure, d->npoints)) { rc = IPK_NOOP; break; }
+        rc = cbuf_new(buf->w, buf->h, 3, buf->mono, o); if (rc) return rc;
+        rc = ipk_basecurve(static_cast<const float *>(buf->p), buf->w, buf->h, d->exposure, d->points, d->npoints, static_cast<float *>(o->p), stream);
+        break;
+      case 5:                                                            // from_lab
+        rc = cbuf_new(buf->w, buf->h, 3, buf->mono, o); if (rc) return rc;
+        rc = ipk_fromlab(static_cast<const float *>(buf->p), buf->w, buf->h, static_cast<float *>(o->p), stream);
+        break;
+      case 6:                                                            // gamma
+        if (n.linear) { rc = IPK_NOOP; break; }
+        rc = cbuf_new(buf->w, buf->h, 3, buf->mono, o); if (rc) return rc;
+        rc = ipk_gamma(static_cast<const float *>(buf->p), buf->w, buf->h, 3, 0, static_cast<float *>(o->p), stream);
+        break;
+      case 7: {                                                          // transform
+        if (n.transform_noop) { rc = IPK_NOOP; break; }
+        size_t ow, oh;
+        rc = cbuf_new(buf->w, buf->h, 3, buf->mono, o); if (rc) return rc;
+        rc = ipk_rotate_buffer(static_cast<const float *>(buf->p), buf->w, buf->h, n.orientation, static_cast<float *>(o->p), &ow, &oh, stream);
+        if (rc >= 0) { o->w = ow; o->h = oh; }
+        break;
+      }
+    }
+    if (rc < 0) return rc;
+    if (rc != IPK_NOOP) buf = o;                                         // a no-op hands its input on (the same Arc under a second key)
+    mask |= 1 << i;
+    cache->lru.put(hs[i], buf, buf->bytes());
+  }
+  if (ops_run) *ops_run = mask;
+  if (buf->w != n.fw || buf->h != n.fh || buf->colors != 3)
+    return fail(IPK_ERR_INVALID, "internal: produced %zux%zux%zu, negotiated %zux%zu", buf->w, buf->h, buf->colors, n.fw, n.fh);
+  const size_t cnt = buf->w * buf->h * 3;
+  if (out_type == IPK_OUT_U8) rc = ipk_output8bit(static_cast<const float *>(buf->p), cnt, static_cast<uint8_t *>(dst), stream);
+  else if (out_type == IPK_OUT_U16) rc = ipk_output16bit(static_cast<const float *>(buf->p), cnt, static_cast<uint16_t *>(dst), stream);
+  else { HIPCHK(hipMemcpyAsync(dst, buf->p, cnt * sizeof(float), hipMemcpyDeviceToDevice, st)); rc = IPK_OK; }
+  if (rc < 0) return rc;
+  // `buf` may be evicted (and its memory freed) as soon as we return; hipFree waits for the device, so the copy above is safe
+  return IPK_OK;
 }
 
 // ------------------------------------------------------------------------------------------

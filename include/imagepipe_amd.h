@@ -291,6 +291,37 @@ IPK_API int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *
 IPK_API int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused);
 
 /* ---------------------------------------------------------------------------------------- */
+/* Stage-boundary caching contract of Pipeline::run(Some(cache)) (src/pipeline.rs:341-372;    */
+/* BufHasher src/hasher.rs:12-48; PipelineCache = MultiCache<BufHash, OpBuffer>, :43,258-260)  */
+/* ---------------------------------------------------------------------------------------- */
+
+/* The eight chained op hashes (32 bytes each, op order gofloat..transform) Pipeline::run computes after
+ * size negotiation: hash i covers PipelineSettings and ops 0..i, so editing op k changes hashes k..7 only.
+ * out_type selects the `linear` the settings carry (output_8bit / output_16bit force it).  source_id is an
+ * extension: the reference hashes nothing that identifies the image; a nonzero id lets one cache hold the
+ * buffers of several resident frames.  Host-only. */
+IPK_API int ipk_pipeline_hashes(const ipk_pipeline_desc *d, int out_type, uint64_t source_id, uint8_t *out256);
+
+/* Pipeline::new_cache(size): a byte-budgeted LRU of device OpBuffers.  `get` refreshes recency; `put` evicts
+ * least-recently-used entries until the newcomer fits.  Use one stream per cache. */
+typedef struct ipk_cache ipk_cache;
+IPK_API int ipk_cache_new(size_t max_bytes, ipk_cache **out);
+IPK_API int ipk_cache_free(ipk_cache *cache);
+IPK_API int ipk_cache_clear(ipk_cache *cache);
+IPK_API int ipk_cache_contains(const ipk_cache *cache, const uint8_t *key32);                 /* 1 / 0 */
+IPK_API int ipk_cache_stats(const ipk_cache *cache, size_t *bytes, size_t *entries, uint64_t *hits, uint64_t *misses, uint64_t *evictions);
+/* Borrow a memoised buffer (IPK_NOOP when absent).  The pointer stays valid until the entry is evicted. */
+IPK_API int ipk_cache_get(ipk_cache *cache, const uint8_t *key32, const float **data, size_t *width, size_t *height,
+                          size_t *colors, int *monochrome);
+
+/* Pipeline::run / output_8bit / output_16bit with Some(cache): resumes after the last op whose hash is in the
+ * cache, stores every buffer it materialises under that op's hash, writes the final image to the DEVICE buffer
+ * dst.  *ops_run (may be NULL) = bit i set when op i executed (0 = served from the cache).  With nothing
+ * memoised and a fusable chain the whole run is one ipk_raw_to_srgb launch and only the final buffer is stored. */
+IPK_API int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_t source_id, ipk_cache *cache,
+                                    int out_type, void *dst, int *ops_run, int *used_fused, void *stream);
+
+/* ---------------------------------------------------------------------------------------- */
 /* Host-pointer forms of the stage kernels: what a Rust `impl ImageOp::run` binds when it keeps   */
 /* its OpBuffers in host Vec<f32>s.  Same arguments as the device forms, minus the stream.       */
 /* ---------------------------------------------------------------------------------------- */
@@ -330,6 +361,9 @@ IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* the device cbrtf routines (variant 0 literal glibc port, 1 select form, 2 form for 1<x<2) on a device array;
  * callers compare with the host libm's cbrtf (src/color_conversions.rs:123 -> f32::cbrt) */
 IPK_API int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream);
+/* host-side test hooks of the caching contract: LRU bookkeeping without device memory; SHA-256 known answers */
+IPK_API int ipk_selftest_cache_put(ipk_cache *cache, const uint8_t *key32, size_t bytes);
+IPK_API int ipk_selftest_sha256(const void *data, size_t n, uint8_t *out32);
 
 #ifdef __cplusplus
 }

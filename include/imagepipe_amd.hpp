@@ -7,6 +7,7 @@
 // Buffers live in HBM (DeviceArray); `run` returns either the SAME shared_ptr (the reference's "return the input Arc")
 // or a fresh buffer.  Header-only; link with -limagepipe_amd.  Errors throw imagepipe::Error where the reference panics.
 #pragma once
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -269,11 +270,27 @@ struct PipelineOps {
 struct SRGBImage { size_t width, height; std::vector<uint8_t> data; };
 struct SRGBImage16 { size_t width, height; std::vector<uint16_t> data; };
 
-// src/pipeline.rs:246-470, cache == None
+// PipelineCache = MultiCache<BufHash, OpBuffer> (src/pipeline.rs:43); Pipeline::new_cache(size) (:258-260)
+class PipelineCache {
+ public:
+  explicit PipelineCache(size_t max_bytes) { check(ipk_cache_new(max_bytes, &c_), "cache_new"); }
+  ~PipelineCache() { ipk_cache_free(c_); }
+  PipelineCache(const PipelineCache &) = delete; PipelineCache &operator=(const PipelineCache &) = delete;
+  ipk_cache *get() const { return c_; }
+  bool contains(const std::array<uint8_t, 32> &key) const { return ipk_cache_contains(c_, key.data()) == 1; }
+  size_t bytes() const { size_t b = 0; ipk_cache_stats(c_, &b, nullptr, nullptr, nullptr, nullptr); return b; }
+ private:
+  ipk_cache *c_ = nullptr;
+};
+
+// src/pipeline.rs:246-470
 class Pipeline {
  public:
   PipelineGlobals globals; PipelineOps ops;
   bool allow_fused = true, last_used_fused = false;
+  int last_ops_run = 0xFF;                 // bit i: op i executed in the last run (0 = served from the cache)
+  uint64_t source_id = 0;                  // identifies the frame inside a shared PipelineCache (extension, see the C header)
+  static PipelineCache new_cache(size_t size) { return PipelineCache(size); }
   static Pipeline new_from_source(ImageSource img, int device = 0) { check(ipk_init(device), "ipk_init"); return Pipeline(std::move(img)); }
 
   // Pipeline::run as the reference writes it: reset, negotiate sizes, then each op's run in order (pipeline.rs:311-375)
@@ -284,22 +301,29 @@ class Pipeline {
     return buf;
   }
   // The same through the C driver, which fuses gofloat..gamma into one kernel when every op allows it
-  Buf run() {
-    ipk_pipeline_desc d = desc(); size_t dw, dh, fw, fh;
-    check(ipk_pipeline_sizes(&d, &dw, &dh, &fw, &fh), "sizes");
-    auto out = std::make_shared<OpBuffer>(fw, fh, 3, false); int fused = 0;
-    check(ipk_pipeline_run(&d, globals.image.data.get(), out->ptr(), IPK_OUT_F32, &fused, nullptr), "pipeline_run");
-    check(ipk_stream_sync(nullptr), "sync"); last_used_fused = fused != 0; return out;
+  Buf run(const PipelineCache *cache = nullptr) {
+    size_t fw, fh; std::tie(fw, fh) = final_size();
+    auto out = std::make_shared<OpBuffer>(fw, fh, 3, false);
+    drive(cache, IPK_OUT_F32, out->ptr());
+    check(ipk_stream_sync(nullptr), "sync"); return out;
   }
-  SRGBImage output_8bit() {                               // slow path, pipeline.rs:404-421
-    ipk_pipeline_desc d = desc(); size_t dw, dh, fw, fh; check(ipk_pipeline_sizes(&d, &dw, &dh, &fw, &fh), "sizes");
-    DeviceArray o(fw * fh * 3); check(ipk_pipeline_run(&d, globals.image.data.get(), o.get(), IPK_OUT_U8, nullptr, nullptr), "pipeline_run");
+  SRGBImage output_8bit(const PipelineCache *cache = nullptr) {      // slow path, pipeline.rs:404-421
+    size_t fw, fh; std::tie(fw, fh) = final_size();
+    DeviceArray o(fw * fh * 3); drive(cache, IPK_OUT_U8, o.get());
     SRGBImage img{fw, fh, std::vector<uint8_t>(fw * fh * 3)}; o.download(img.data.data()); return img;
   }
-  SRGBImage16 output_16bit() {                            // pipeline.rs:451-468
-    ipk_pipeline_desc d = desc(); size_t dw, dh, fw, fh; check(ipk_pipeline_sizes(&d, &dw, &dh, &fw, &fh), "sizes");
-    DeviceArray o(fw * fh * 6); check(ipk_pipeline_run(&d, globals.image.data.get(), o.get(), IPK_OUT_U16, nullptr, nullptr), "pipeline_run");
+  SRGBImage16 output_16bit(const PipelineCache *cache = nullptr) {   // pipeline.rs:451-468
+    size_t fw, fh; std::tie(fw, fh) = final_size();
+    DeviceArray o(fw * fh * 6); drive(cache, IPK_OUT_U16, o.get());
     SRGBImage16 img{fw, fh, std::vector<uint16_t>(fw * fh * 3)}; o.download(img.data.data()); return img;
+  }
+  // ophashes of pipeline.rs:342-361
+  std::vector<std::array<uint8_t, 32>> hashes(int out_type = IPK_OUT_F32) const {
+    ipk_pipeline_desc d = desc(); uint8_t raw[256];
+    check(ipk_pipeline_hashes(&d, out_type, source_id, raw), "hashes");
+    std::vector<std::array<uint8_t, 32>> v(8);
+    for (int i = 0; i < 8; ++i) std::memcpy(v[i].data(), raw + 32 * i, 32);
+    return v;
   }
   // size negotiation over the op objects (pipeline.rs:314-338)
   std::pair<size_t, size_t> negotiate() {
@@ -332,6 +356,15 @@ class Pipeline {
   }
  private:
   explicit Pipeline(ImageSource img) : globals{std::move(img), PipelineSettings()}, ops(globals.image) {}
+  std::pair<size_t, size_t> final_size() const {
+    ipk_pipeline_desc d = desc(); size_t dw, dh, fw, fh; check(ipk_pipeline_sizes(&d, &dw, &dh, &fw, &fh), "sizes"); return {fw, fh};
+  }
+  void drive(const PipelineCache *cache, int out_type, void *dst) {
+    ipk_pipeline_desc d = desc(); int fused = 0;
+    if (cache) check(ipk_pipeline_run_cached(&d, globals.image.data.get(), source_id, cache->get(), out_type, dst, &last_ops_run, &fused, nullptr), "pipeline_run_cached");
+    else { check(ipk_pipeline_run(&d, globals.image.data.get(), dst, out_type, &fused, nullptr), "pipeline_run"); last_ops_run = 0xFF; }
+    last_used_fused = fused != 0;
+  }
 };
 
 }  // namespace imagepipe

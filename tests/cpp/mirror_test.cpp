@@ -36,7 +36,23 @@ int main(int argc, char **argv) {
       std::fprintf(stderr, "driver and op loop disagree\n"); return 4;
     }
     auto o8 = pipe.output_8bit();
-    std::printf("%zu %zu %d %zu\n", a->width, a->height, pipe.last_used_fused ? 1 : 0, o8.data.size());
+    const bool fused_flag = pipe.last_used_fused;
+    auto same = [](const std::vector<float> &x, const std::vector<float> &y) { return x.size() == y.size() && std::memcmp(x.data(), y.data(), x.size() * 4) == 0; };
+    {  // Pipeline::run(Some(cache)): cold run, hit, edit of one op
+      auto cache = imagepipe::Pipeline::new_cache(size_t(1) << 30);
+      auto c1 = pipe.run(&cache); const int cold = pipe.last_ops_run;
+      auto c2 = pipe.run(&cache); const int warm = pipe.last_ops_run;
+      if (cold != 0xFF || warm != 0 || !same(c1->to_host(), va) || !same(c2->to_host(), va) || !cache.contains(pipe.hashes()[7]) || cache.bytes() == 0) {
+        std::fprintf(stderr, "cached run disagrees (cold %x warm %x)\n", cold, warm); return 6;
+      }
+      pipe.ops.transform.fliph = !pipe.ops.transform.fliph;
+      auto c3 = pipe.run(&cache); const int edited = pipe.last_ops_run;
+      pipe.allow_fused = false;
+      auto ref = pipe.run();
+      pipe.allow_fused = true; pipe.ops.transform.fliph = !pipe.ops.transform.fliph;
+      if (edited == 0 || !same(c3->to_host(), ref->to_host())) { std::fprintf(stderr, "cached run after edit disagrees (%x)\n", edited); return 7; }
+    }
+    std::printf("%zu %zu %d %zu\n", a->width, a->height, fused_flag ? 1 : 0, o8.data.size());
     FILE *o = std::fopen(argv[7], "wb");
     std::fwrite(va.data(), 4, va.size(), o); std::fclose(o);
   } catch (const std::exception &e) { std::fprintf(stderr, "error: %s\n", e.what()); return 5; }
