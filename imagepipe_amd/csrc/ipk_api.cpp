@@ -572,7 +572,7 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.spline = &sp;
   f.linear = p->linear;
   f.out_type = p->out_type;
-  f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
+  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
   f.num_cus = g.num_cus;
   ipk::launch_fused_bayer(f, S(stream));
   HIPCHK(hipGetLastError());

@@ -35,12 +35,20 @@ __device__ __forceinline__ uint32_t f32_as_u32_sat(float f) { return __float2uin
 // ---- TransformLookup::lookup table branch (src/color_conversions.rs:106-112) ---------------
 // Precondition: !(val < 0 || val > 1)  (NaN takes this branch too, as in the reference: key 0,
 // a = NaN -> NaN).
-__device__ __forceinline__ float lut_interp(const LutPair *__restrict__ tab, float val) {
+// A table is either {v[i], v[i+1]-v[i]} pairs (one 8-byte read per lookup) or the plain 8193 floats (two adjacent
+// 4-byte reads, ds_read2_b32, and the subtraction of :112 done per lookup: half the LDS footprint).
+__device__ __forceinline__ LutPair lut_pair_at(const LutPair *__restrict__ tab, uint32_t key) { return tab[key]; }
+__device__ __forceinline__ LutPair lut_pair_at(const float *__restrict__ tab, uint32_t key) {
+  const float v1 = tab[key], v2 = tab[key + 1];
+  return make_float2(v1, v2 - v1);
+}
+template <typename Tab>
+__device__ __forceinline__ float lut_interp(const Tab *__restrict__ tab, float val) {
   const float pos = val * kLutMaxF;
   const uint32_t key = f32_as_u32_sat(pos);
   const float base = truncf(pos);
   const float a = pos - base;
-  const LutPair p = tab[key];
+  const LutPair p = lut_pair_at(tab, key);
   return p.x + a * p.y;
 }
 
@@ -99,7 +107,8 @@ __device__ __forceinline__ float cbrtf_glibc_1to2(float x) {
 }
 
 // XYZ_LAB_TRANSFORM.lookup (src/color_conversions.rs:102-114 with the closure of :120-124)
-__device__ __forceinline__ float lab_lookup(const LutPair *__restrict__ lab, float v) {
+template <typename Tab>
+__device__ __forceinline__ float lab_lookup(const Tab *__restrict__ lab, float v) {
   if (v < 0.0f || v > 1.0f) {
     if (v > kLabE) return cbrtf_glibc(v);                // only v > 1 reaches here
     return (kLabK * v + 16.0f) / 116.0f;                 // v < 0
@@ -108,7 +117,8 @@ __device__ __forceinline__ float lab_lookup(const LutPair *__restrict__ lab, flo
 }
 
 // xyz_to_lab (src/color_conversions.rs:156-169)
-__device__ __forceinline__ void xyz_to_lab(const LutPair *__restrict__ lab, float x, float y, float z,
+template <typename Tab>
+__device__ __forceinline__ void xyz_to_lab(const Tab *__restrict__ lab, float x, float y, float z,
                                            float &ol, float &oa, float &ob) {
   const float xr = x / kWhiteX, yr = y / kWhiteY, zr = z / kWhiteZ;
   const float fx = lab_lookup(lab, xr);
@@ -138,7 +148,8 @@ __device__ __forceinline__ void lab_to_xyz(float l, float a, float b, float &ox,
 
 // camera_to_lab (src/color_conversions.rs:42-55); cm = [[f32;4];3] row-major
 struct ToLabParams { float mul[4]; float cm[12]; };
-__device__ __forceinline__ void camera_to_lab(const LutPair *__restrict__ lab, const ToLabParams &p,
+template <typename Tab>
+__device__ __forceinline__ void camera_to_lab(const Tab *__restrict__ lab, const ToLabParams &p,
                                               float p0, float p1, float p2, float p3,
                                               float &ol, float &oa, float &ob) {
   const float r = rs_min(p0 * p.mul[0], 1.0f);

@@ -525,7 +525,7 @@ struct FusedArgs {
   int has_curve, linear;
   uint32_t n_strips, n_segs;  // task grid
   uint32_t lc_base, lc_rem;   // lane-columns per strip: base (+1 for the first lc_rem strips)
-  const LutPair *lab_pairs;
+  const float *lab_table;
   const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
   SplineDev spline;
 };
@@ -660,7 +660,7 @@ __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
 struct FastBad { bool b; };
 // `par` = LDS copy of the uniform parameters (mul[0..3], cm[4..15], rgbm[16..24]): read through the LDS they end up in
 // vector registers instead of competing with the wave's many 64-bit condition masks for scalar registers.
-__device__ __forceinline__ bool pointwise2_fast(const FusedArgs &a, const float *__restrict__ par, const LutPair *__restrict__ s_lab,
+__device__ __forceinline__ bool pointwise2_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
                                                 const float4 &pa, const float4 &pb, PixOut &oa, PixOut &ob) {
   bool bad = !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
@@ -682,7 +682,7 @@ __device__ __forceinline__ bool pointwise2_fast(const FusedArgs &a, const float 
     const float pos[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
     LutPair e[6]; float w[6];
     #pragma unroll
-    for (int k = 0; k < 6; ++k) { e[k] = s_lab[f32_as_u32_sat(pos[k])]; w[k] = __builtin_amdgcn_fractf(pos[k]); }
+    for (int k = 0; k < 6; ++k) { e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k])); w[k] = __builtin_amdgcn_fractf(pos[k]); }
     #pragma unroll
     for (int k = 0; k < 6; k += 2) {
       const f2 t = F2(e[k].x, e[k + 1].x) + F2(w[k], w[k + 1]) * F2(e[k].y, e[k + 1].y);
@@ -751,7 +751,7 @@ __device__ __forceinline__ bool pointwise2_fast(const FusedArgs &a, const float 
 }
 
 // The literal per-pixel evaluation (device functions of ipk_device.hpp: true divisions, the reference's control flow).
-__device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const LutPair *__restrict__ s_lab, const float *__restrict__ s_gam,
+__device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const float *__restrict__ s_lab, const float *__restrict__ s_gam,
                                                   const float *__restrict__ s_knots, const float4 &p) {
   float l, ca, cb;
   camera_to_lab(s_lab, a.tolab, p.x, p.y, p.z, p.w, l, ca, cb);
@@ -919,6 +919,9 @@ struct RgbeStage {
 // Everything that is rare (frame-edge pixels, out-of-table Lab values, dividends outside cdiv_fast's proven
 // zone, the exact-division redo) sits behind a WAVE-UNIFORM branch (`ballot != 0`), which keeps the common
 // path straight-line code the scheduler can interleave across the lane's 4 pixels.
+// Occupancy: one 1024-thread block per CU = 4 waves per SIMD, on purpose.  Measured (tools/ubench2.hip, and this kernel's
+// u16->u8 variant, which fits two blocks in LDS): at 8 waves per SIMD the simple f32 ops lose their 2-cycle issue rate
+// (v_mul 1.0 -> 1.4 ns per wave64 instruction) and the kernel ran 23 % slower (0.79 -> 0.98 ms at 100 MP).
 template <typename SrcT, bool VEC, int OUT, bool FULL>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
@@ -927,14 +930,14 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   constexpr bool GUARD_NORM = sizeof(SrcT) == 4 && !DEMO;
   // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB), curve knots, and one 3 KB staging
   // buffer per wave that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
-  __shared__ LutPair s_lab[DEMO ? 1 : kLutPairs];
+  __shared__ float s_lab[DEMO ? 4 : kLutPairs + 4];
   __shared__ float s_gam[DEMO ? 4 : kLutPairs + 4];
   __shared__ float s_knots[5 * kSplineMaxKnots];         // base-curve knots
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
-  __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * (DEMO ? 1024 : 768) : 4];
+  constexpr int STG = DEMO ? 1024 : (OUT == 0 ? 768 : (OUT == 1 ? 192 : 384));   // dwords of staging per wave: one output row segment
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * STG : 4];
   if (!DEMO) {
-    load_lut_pairs(s_lab, a.lab_pairs);
-    for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) s_gam[i] = a.gam_table[i];
+    for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
   }
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     }
     if (DEMO) {
       if (FULL) {
-        uint32_t *stg = s_stage + (threadIdx.x >> 6) * 1024;
+        uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
         RgbeStage::stage(stg, lane, px);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         RgbeStage::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + 4u * lc0);
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       // Lane-blocked -> lane-interleaved through the wave's LDS staging buffer, then three stores per lane whose
       // addresses are contiguous across the wave (whole cache lines per instruction; a 48-byte lane stride would
       // touch every line of the 3 KB span with each of its stores).
-      uint32_t *stg = s_stage + (threadIdx.x >> 6) * 768;
+      uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
       // The compiler reasons about one lane: a lane never reads back what it staged, so without these wave-scope
       // fences it treats the staging writes as dead stores / reorders them past the reads.  Wavefront-scope fences
       // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   }
 }
 
-static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks);
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blocks_per_cu);
 
 // Staged demosaic::full for an RGGB-phase Bayer mosaic (OUT == 3 of the row-walking kernel).  Same band arguments as the
 // generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
@@ -1163,7 +1166,7 @@ void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, si
   a.row_off = (uint32_t)src_row0; a.out_r0 = (uint32_t)out_row0; a.out_r1 = (uint32_t)(out_row0 + out_rows);
   a.xoff = xoff; a.yoff = yoff; a.range0 = 1.0f; a.inv_range0 = 1.0f;
   unsigned blocks;
-  fused_task_grid(a, num_cus, blocks);
+  fused_task_grid(a, num_cus, blocks, 1);
   if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(dst4) & 15u) == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0)
     hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true>), dim3(blocks), dim3(1024), 0, s, a);
   else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false>), dim3(blocks), dim3(1024), 0, s, a);
@@ -1176,9 +1179,9 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 }
 
 // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
-static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks) {
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blocks_per_cu) {
   const uint32_t waves_per_block = 16;
-  const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
+  const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256) * (uint32_t)blocks_per_cu;
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;
   a.n_strips = (w4 + 63) / 64;
@@ -1205,11 +1208,11 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   for (int i = 0; i < 9; ++i) a.rgbm.m[i] = f.rgbm9[i];
   a.has_curve = f.has_curve; a.linear = f.linear;
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
-  a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs);
+  a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
 
   unsigned blocks;
-  fused_task_grid(a, f.num_cus, blocks);
+  fused_task_grid(a, f.num_cus, blocks, 1);
 
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
   if (!f.src_is_u16) {

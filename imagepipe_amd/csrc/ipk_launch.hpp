@@ -61,7 +61,7 @@ struct FusedLaunch {
   int has_curve, linear;
   const SplineHost *spline;
   int out_type;                  // 0 f32, 1 u8, 2 u16
-  const void *lab_pairs, *gam_table;   // Lab table as {v,dv} pairs; gamma table plain (8193 floats)
+  const void *lab_table, *gam_table;   // plain 8193-float tables (XYZ_LAB_TRANSFORM, SRGB gamma)
   int num_cus;
 };
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);
