@@ -48,6 +48,28 @@ __global__ void k_gofloat_cfa(const T *__restrict__ src, size_t owidth, size_t x
     dst[(size_t)row * width + col] = rs_min((v - min0) / range0, 1.0f);      // gofloat.rs:126 / :162
   }
 }
+// Four columns per thread (one 16-byte store, one 8/16-byte load; dword alignment is all gfx950 needs for them), rows
+// strided over gridDim.y: the op is pure streaming, 2 or 4 bytes in and 4 out per sample.
+struct __attribute__((aligned(4))) GfF4 { float x, y, z, w; };
+struct __attribute__((aligned(4))) GfU4 { uint16_t x, y, z, w; };
+struct __attribute__((aligned(2))) GfU4s { uint16_t x, y, z, w; };
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_gofloat_cfa_v4(const T *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
+                                                        float min0, float range0, float *__restrict__ dst) {
+  const uint32_t col = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (col >= width) return;                              // width % 4 == 0: a thread's four columns are all inside
+  for (uint32_t row = blockIdx.y; row < height; row += gridDim.y) {
+    const T *p = src + owidth * (row + y) + x + col;
+    float v0, v1, v2, v3;
+    if (sizeof(T) == 4) { const GfF4 t = *reinterpret_cast<const GfF4 *>(p); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+    else if (ALIGNED) { const GfU4 t = *reinterpret_cast<const GfU4 *>(p); v0 = (float)t.x; v1 = (float)t.y; v2 = (float)t.z; v3 = (float)t.w; }
+    else { const GfU4s t = *reinterpret_cast<const GfU4s *>(p); v0 = (float)t.x; v1 = (float)t.y; v2 = (float)t.z; v3 = (float)t.w; }
+    GfF4 o;
+    o.x = rs_min((v0 - min0) / range0, 1.0f); o.y = rs_min((v1 - min0) / range0, 1.0f);       // gofloat.rs:126 / :162
+    o.z = rs_min((v2 - min0) / range0, 1.0f); o.w = rs_min((v3 - min0) / range0, 1.0f);
+    *reinterpret_cast<GfF4 *>(dst + (size_t)row * width + col) = o;
+  }
+}
 template <typename T>
 __global__ void k_gofloat_mono(const T *__restrict__ src, size_t owidth, size_t x, size_t y, uint32_t width, uint32_t height,
                                float min0, float range0, float4 *__restrict__ dst) {
@@ -102,6 +124,15 @@ __global__ void k_gofloat_other_u16(const uint16_t *__restrict__ src, size_t owi
 template <typename T>
 void launch_gofloat_cfa(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float black0, float white0,
                         float *dst, hipStream_t s) {
+  if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+    const dim3 grid((unsigned)((w / 4 + 255) / 256), (unsigned)(h < 4096 ? h : 4096), 1);
+    // u16: the 8-byte load wants the first sample of every row on a dword boundary
+    if (sizeof(T) == 4 || ((owidth & 1) == 0 && (x & 1) == 0))
+      hipLaunchKernelGGL((k_gofloat_cfa_v4<T, true>), grid, dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h, black0, white0 - black0, dst);
+    else
+      hipLaunchKernelGGL((k_gofloat_cfa_v4<T, false>), grid, dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h, black0, white0 - black0, dst);
+    return;
+  }
   hipLaunchKernelGGL(k_gofloat_cfa<T>, grid_rows(w, h, 256), dim3(256), 0, s, src, owidth, x, y, (uint32_t)w, (uint32_t)h,
                      black0, white0 - black0, dst);
 }
@@ -427,7 +458,13 @@ __global__ __launch_bounds__(1024) void k_gamma(const float *__restrict__ src, s
   __shared__ LutPair s_gam[kLutPairs];
   load_lut_pairs(s_gam, gam_pairs);
   __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  // four samples per thread (16-byte accesses) while whole groups remain, then the tail one by one
+  const size_t n4 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 ? n / 4 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4 *>(src)[i];
+    reinterpret_cast<float4 *>(dst)[i] = make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w));
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = gamma_sample(s_gam, src[i]);
 }
 // rotate_buffer (src/ops/transform.rs:130-141): strided gather of 3-channel pixels
@@ -442,10 +479,20 @@ __global__ void k_rotate(const f3 *__restrict__ src, uint32_t owidth, uint32_t o
 }
 // output8bit / output16bit loops (src/pipeline.rs:408-414, :455-461)
 __global__ void k_output8(const float *__restrict__ src, size_t n, uint8_t *__restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output8bit(src[i]);
+  const size_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 3)) == 0 ? n / 4 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4 *>(src)[i];
+    reinterpret_cast<uint32_t *>(dst)[i] = (uint32_t)output8bit(v.x) | ((uint32_t)output8bit(v.y) << 8) | ((uint32_t)output8bit(v.z) << 16) | ((uint32_t)output8bit(v.w) << 24);
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output8bit(src[i]);
 }
 __global__ void k_output16(const float *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output16bit(src[i]);
+  const size_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 7)) == 0 ? n / 4 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4 *>(src)[i];
+    reinterpret_cast<uint2 *>(dst)[i] = make_uint2((uint32_t)output16bit(v.x) | ((uint32_t)output16bit(v.y) << 16), (uint32_t)output16bit(v.z) | ((uint32_t)output16bit(v.w) << 16));
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output16bit(src[i]);
 }
 
 static ToLabParams make_tolab(const float *mul4, const float *cm12) {
@@ -1174,13 +1221,24 @@ void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, si
 
 template <typename SrcT, bool VEC, int OUT>
 static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
-  if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(a.dst) & 15u) == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(1024), 0, s, a);
-  else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false>), dim3(grid), dim3(1024), 0, s, a);
+#ifdef IPK_DEV_KNOBS
+  const unsigned tpb = getenv("IPK_DEV_TPB") ? atoi(getenv("IPK_DEV_TPB")) : 1024;
+#else
+  const unsigned tpb = 1024;
+#endif
+  if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(a.dst) & 15u) == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(tpb), 0, s, a);
+  else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false>), dim3(grid), dim3(tpb), 0, s, a);
 }
 
 // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blocks_per_cu) {
+#ifdef IPK_DEV_KNOBS
+  static const int dev_tpb = getenv("IPK_DEV_TPB") ? atoi(getenv("IPK_DEV_TPB")) : 1024;
+  static const int dev_bpc = getenv("IPK_DEV_BPC") ? atoi(getenv("IPK_DEV_BPC")) : 1;
+  const uint32_t waves_per_block = dev_tpb / 64; blocks_per_cu = dev_bpc;
+#else
   const uint32_t waves_per_block = 16;
+#endif
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256) * (uint32_t)blocks_per_cu;
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;

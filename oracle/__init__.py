@@ -26,12 +26,33 @@ def build(force=False):
 _lib = None
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota.  OpenMP sizes its pool by
+    the visible CPU count; under a quota (e.g. 16 CPUs' worth on a 256-thread host) that oversubscribes the row loops
+    several hundred-fold in wall time, so the oracle pins its pool to this number."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]              # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())            # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
         _declare(_lib)
+        _lib.orc_set_num_threads(usable_cpus())
         _lib.orc_luts_init()
     return _lib
 

@@ -54,6 +54,8 @@ def main():
             o2 = pipe.run()
             r["staged_ms"] = round(timeit(lambda: pipe.run(out=o2.data), n=5), 4)
             assert torch.equal(o2.data.view(torch.int32), out.data.view(torch.int32)), "fused != staged"
+            r["staged_u8_ms"] = round(timeit(lambda: pipe.output_8bit(), n=3, warm=1), 4)
+            r["staged_u16_ms"] = round(timeit(lambda: pipe.output_16bit(), n=3, warm=1), 4)
         res[name] = r
         del pipe, img, out
         torch.cuda.empty_cache()
