@@ -581,6 +581,8 @@ struct FusedArgs {
 struct RowWin { float l, v0, v1, v2, v3, r; };
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(1))) u32u { uint32_t v; };
+struct __attribute__((packed, aligned(2))) u64u { uint32_t a, b; };
 struct __attribute__((packed, aligned(4))) us4 { uint16_t x, y, z, w; };
 struct __attribute__((packed, aligned(2))) us4u { uint16_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) u3w { uint32_t x, y, z; };
@@ -900,10 +902,10 @@ template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 store
     p[2] = make_float4(o[2].b, o[3].r, o[3].g, o[3].b);
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
-    float4 *g = reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + pix * 3);
+    f4u *g = reinterpret_cast<f4u *>(reinterpret_cast<float *>(dst) + pix * 3);          // element-aligned 16-byte stores
     const float4 *s = reinterpret_cast<const float4 *>(stg);
     const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
-    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2;
+    g[lane] = f4u{q0.x, q0.y, q0.z, q0.w}; g[64 + lane] = f4u{q1.x, q1.y, q1.z, q1.w}; g[128 + lane] = f4u{q2.x, q2.y, q2.z, q2.w};
   }
 };
 template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
@@ -917,9 +919,9 @@ template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
     p[2] = q[8] | (q[9] << 8) | (q[10] << 16) | (q[11] << 24);
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
-    uint32_t *g = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);
+    u32u *g = reinterpret_cast<u32u *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);        // byte-aligned dword stores
     const uint32_t q0 = stg[lane], q1 = stg[64 + lane], q2 = stg[128 + lane];
-    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2;
+    g[lane].v = q0; g[64 + lane].v = q1; g[128 + lane].v = q2;
   }
 };
 template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
@@ -933,10 +935,10 @@ template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
     p[2] = make_uint2(q[8] | (q[9] << 16), q[10] | (q[11] << 16));
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
-    uint2 *g = reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);
+    u64u *g = reinterpret_cast<u64u *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);      // 2-byte-aligned 8-byte stores
     const uint2 *s = reinterpret_cast<const uint2 *>(stg);
     const uint2 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
-    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2;
+    g[lane] = u64u{q0.x, q0.y}; g[64 + lane] = u64u{q1.x, q1.y}; g[128 + lane] = u64u{q2.x, q2.y};
   }
 };
 
@@ -949,10 +951,10 @@ struct RgbeStage {
     p[0] = px[0]; p[1] = px[1]; p[2] = px[2]; p[3] = px[3];
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
-    float4 *g = reinterpret_cast<float4 *>(dst) + pix;
+    f4u *g = reinterpret_cast<f4u *>(reinterpret_cast<float *>(dst) + pix * 4);
     const float4 *s = reinterpret_cast<const float4 *>(stg);
     const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane], q3 = s[192 + lane];
-    g[lane] = q0; g[64 + lane] = q1; g[128 + lane] = q2; g[192 + lane] = q3;
+    g[lane] = f4u{q0.x, q0.y, q0.z, q0.w}; g[64 + lane] = f4u{q1.x, q1.y, q1.z, q1.w}; g[128 + lane] = f4u{q2.x, q2.y, q2.z, q2.w}; g[192 + lane] = f4u{q3.x, q3.y, q3.z, q3.w};
   }
   static __device__ __forceinline__ void store_direct(void *dst, size_t pix, uint32_t nvalid, const float4 px[4]) {
     float4 *g = reinterpret_cast<float4 *>(dst) + pix;
@@ -962,7 +964,9 @@ struct RgbeStage {
   }
 };
 
-// FULL = (W % 4 == 0 and W >= 256): every lane owns 4 valid pixels, so the hot path has no per-lane size logic.
+// FULL = (W >= 256): every strip is 64 lanes x 4 pixels wide, so the hot path has no per-lane size logic; strips start
+// on multiples of 256 pixels except the last, which is shifted left to end at the frame's last column (any W, any
+// alignment: gfx950 takes dword/dwordx2/dwordx4 global accesses at element alignment).
 // Everything that is rare (frame-edge pixels, out-of-table Lab values, dividends outside cdiv_fast's proven
 // zone, the exact-division redo) sits behind a WAVE-UNIFORM branch (`ballot != 0`), which keeps the common
 // path straight-line code the scheduler can interleave across the lane's 4 pixels.
@@ -1004,13 +1008,15 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each.  FULL: every strip is 64 lanes wide and the
   // last one is shifted left to stay inside the frame; the columns it shares with its neighbour are computed by
   // both waves (identical values written twice), which keeps every lane active and every access unpredicated.
-  const uint32_t w4 = (a.W + 3u) >> 2;
-  const uint32_t lc0 = FULL ? min(strip * 64u, w4 - 64u) : strip * a.lc_base + min(strip, a.lc_rem);
+  const uint32_t lc0 = FULL ? 0u : strip * a.lc_base + min(strip, a.lc_rem);
   const uint32_t nl = FULL ? 64u : a.lc_base + (strip < a.lc_rem ? 1u : 0u);
   const bool lane_on = FULL ? true : lane < nl;
+  const uint32_t pc0 = FULL ? min(strip * 256u, a.W - 256u) : 4u * lc0;   // first pixel column of the strip
   // lanes past the strip shadow its last lane: their loads stay in bounds and need no predicate
-  const uint32_t col0 = 4u * (lc0 + min(lane, nl - 1));
+  const uint32_t col0 = pc0 + 4u * min(lane, nl - 1);
   const uint32_t nvalid = FULL ? 4u : min(4u, a.W - col0);
+  // column parity of the lane's pixel j inside the RGGB tile is (j + xo) & 1: col0 - pc0 is a multiple of 4
+  const uint32_t xo = ((uint32_t)a.xoff + pc0) & 1u;
   // rows: this segment's output rows [r0, r1)
   const uint32_t nrows = a.out_r1 - a.out_r0;
   const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
@@ -1021,9 +1027,9 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
   const bool is_first = lane == 0, is_last = lane + 1 == nl;
   const bool single = FULL ? false : nl == 1;            // one lane carries both halos: second one via h2
-  const int64_t hcol_want = is_first ? (int64_t)4 * lc0 - 1 : (int64_t)4 * (lc0 + nl);
+  const int64_t hcol_want = is_first ? (int64_t)pc0 - 1 : (int64_t)pc0 + 4 * (int64_t)nl;
   const uint32_t hcol = ((is_first || is_last) && hcol_want >= 0 && hcol_want < (int64_t)a.W) ? (uint32_t)hcol_want : col0;
-  const uint32_t h2col = (single && 4u * (lc0 + nl) < a.W) ? 4u * (lc0 + nl) : col0;
+  const uint32_t h2col = (single && pc0 + 4u * nl < a.W) ? pc0 + 4u * nl : col0;
 
   const SrcT *src = reinterpret_cast<const SrcT *>(a.src);
   const float min0 = a.min0, range0 = a.range0, inv_range0 = a.inv_range0;
@@ -1093,10 +1099,10 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
     const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
     float4 px[4];
-    // interior formulas; role = (row parity, column parity) in the RGGB tile.  col0 % 4 == 0, so the
-    // column parity of pixel j is (j + xoff) & 1: wave-uniform branches only.
+    // interior formulas; role = (row parity, column parity) in the RGGB tile; the column parity of pixel j is
+    // (j + xo) & 1 with a per-strip xo: wave-uniform branches only.
     if (pr == 0) {
-      if (a.xoff == 0) {
+      if (xo == 0) {
         px[0] = demosaic_inner_px<0>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
         px[1] = demosaic_inner_px<1>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
         px[2] = demosaic_inner_px<0>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
         px[3] = demosaic_inner_px<0>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
       }
     } else {
-      if (a.xoff == 0) {
+      if (xo == 0) {
         px[0] = demosaic_inner_px<2>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
         px[1] = demosaic_inner_px<3>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
         px[2] = demosaic_inner_px<2>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
@@ -1134,7 +1140,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
             if (r == Hm1) m &= ~0x1C0u;
             if (c == 0) m &= ~0x049u;
             if (c == Wm1) m &= ~0x124u;
-            px[j] = demosaic_edge_dispatch(t, m, pr, (int)((j + (uint32_t)a.xoff) & 1u));
+            px[j] = demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
           }
         }
       }
@@ -1144,7 +1150,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
         uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
         RgbeStage::stage(stg, lane, px);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        RgbeStage::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + 4u * lc0);
+        RgbeStage::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + pc0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       } else if (lane_on) {
         RgbeStage::store_direct(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, px);
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
 #endif
 #if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
     if (OUT == 0 && FULL) {
-      float *rowp = reinterpret_cast<float *>(a.dst) + ((size_t)(r - a.out_r0) * a.W + 4u * lc0) * 3;
+      float *rowp = reinterpret_cast<float *>(a.dst) + ((size_t)(r - a.out_r0) * a.W + pc0) * 3;
       f4u q0{o[0].r, o[0].g, o[0].b, o[1].r}, q1{o[1].g, o[1].b, o[2].r, o[2].g}, q2{o[2].b, o[3].r, o[3].g, o[3].b};
       reinterpret_cast<f4u *>(rowp)[lane] = q0; reinterpret_cast<f4u *>(rowp)[64 + lane] = q1; reinterpret_cast<f4u *>(rowp)[128 + lane] = q2;
     }
@@ -1191,7 +1197,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
       OutStage<OUT>::stage(stg, lane, o);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      OutStage<OUT>::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + 4u * lc0);
+      OutStage<OUT>::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + pc0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
       if (lane_on) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
@@ -1214,7 +1220,7 @@ void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, si
   a.xoff = xoff; a.yoff = yoff; a.range0 = 1.0f; a.inv_range0 = 1.0f;
   unsigned blocks;
   fused_task_grid(a, num_cus, blocks, 1);
-  if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(dst4) & 15u) == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0)
+  if (a.W >= 256u)
     hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true>), dim3(blocks), dim3(1024), 0, s, a);
   else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false>), dim3(blocks), dim3(1024), 0, s, a);
 }
@@ -1226,7 +1232,7 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 #else
   const unsigned tpb = 1024;
 #endif
-  if ((a.W & 3u) == 0 && a.W >= 256u && (reinterpret_cast<uintptr_t>(a.dst) & 15u) == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(tpb), 0, s, a);
+  if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(tpb), 0, s, a);
   else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false>), dim3(grid), dim3(tpb), 0, s, a);
 }
 

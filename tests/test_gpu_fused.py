@@ -287,9 +287,11 @@ def test_cpp_mirror_pipeline(orc, tmp_path, cfa, shape, maxwidth, rotation):
 
 
 # ---------------------------------------------------------------------------------------------
-# strip geometry of the FULL kernel (64-lane strips, last one shifted left) x output types x source types
+# strip geometry of the FULL kernel (256-pixel strips, the last one shifted left to end at the last column: any width,
+# odd strip starts, element-aligned vector loads/stores) x output types x source types
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(10, 256), (12, 260), (23, 512), (17, 1028), (40, 2052), (11, 4096 + 8)])
+@pytest.mark.parametrize("shape", [(10, 256), (12, 257), (12, 259), (12, 260), (23, 511), (23, 512), (13, 769), (17, 1023), (17, 1028), (40, 2052),
+                                   (40, 2053), (11, 4096 + 8), (11, 4096 + 7)])
 @pytest.mark.parametrize("is_float", [False, True])
 def test_fused_full_kernel_strip_geometry_all_outputs(ipa, orc, shape, is_float):
     h, w = shape
@@ -303,6 +305,22 @@ def test_fused_full_kernel_strip_geometry_all_outputs(ipa, orc, shape, is_float)
     assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, "GBRG")))
     ww, hh, o16 = pipe.output_16bit()
     assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, "GBRG")))
+
+
+@pytest.mark.parametrize("crops", [(1, 2, 3, 5), (0, 1, 0, 1), (3, 0, 2, 7)])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_fused_full_kernel_odd_crops_and_pitch(ipa, orc, crops, is_float):
+    """sensor pitch, crop offset and cropped width all odd: the strip loads start at odd element offsets of the source"""
+    h, w = 31, 777
+    raw = util.noise_u16(util.SEED + 65, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "GRBG", is_float=is_float, crops=crops))
+    got = pipe.run(); assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, src, "GRBG", crops=crops)), "odd crops %r" % (crops,))
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, "GRBG", crops=crops)))
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, "GRBG", crops=crops)))
 
 
 def test_fused_extreme_levels_fall_back_to_true_division(ipa, orc):
