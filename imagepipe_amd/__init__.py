@@ -549,6 +549,7 @@ class Pipeline:
         d.maxwidth, d.maxheight = st.maxwidth, st.maxheight
         d.linear = int(st.linear)
         d.allow_fused = int(self.allow_fused)
+        d.use_fastpath = int(st.use_fastpath)
         return d
 
     def sizes(self):

@@ -48,7 +48,7 @@ class PipelineDesc(C.Structure):
         ("exposure", C.c_float), ("npoints", C.c_int), ("points", C.c_float * 128),
         ("rotation", C.c_int), ("fliph", C.c_int), ("flipv", C.c_int),
         ("maxwidth", _sz), ("maxheight", _sz),
-        ("linear", C.c_int), ("allow_fused", C.c_int),
+        ("linear", C.c_int), ("allow_fused", C.c_int), ("use_fastpath", C.c_int),
     ]
 
 
@@ -130,6 +130,7 @@ SIGNATURES = {
     "ipk_selftest_cbrtf": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "ipk_selftest_cache_put": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ipk_selftest_sha256": (C.c_int, [C.c_char_p, _sz, C.c_char_p]),
+    "ipk_pipeline_takes_fastpath": (C.c_int, [C.POINTER(PipelineDesc), C.c_int]),
     "ipk_pipeline_hashes": (C.c_int, [C.POINTER(PipelineDesc), C.c_int, C.c_uint64, C.c_char_p]),
     "ipk_cache_new": (C.c_int, [_sz, C.POINTER(C.c_void_p)]),
     "ipk_cache_free": (C.c_int, [_vp]),

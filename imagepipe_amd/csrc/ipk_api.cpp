@@ -647,10 +647,64 @@ int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *d
   return IPK_OK;
 }
 
+// Pipeline::default_ops (pipeline.rs:286-288) for a raster source: every user-visible op field equals PipelineOps::new(Other),
+// bit for bit (the reference compares serialised bytes).  Its OpRotateCrop also serialises negotiated state that a previous
+// slow-path run leaves behind; the descriptor is stateless, so that quirk is not reproduced.
+static bool default_ops_other(const ipk_pipeline_desc *d) {
+  auto same = [](float a, float b) { return std::memcmp(&a, &b, 4) == 0; };
+  if (d->src_type != IPK_SRC_RGB8 && d->src_type != IPK_SRC_RGB16) return false;
+  if (d->crop_top || d->crop_right || d->crop_bottom || d->crop_left || d->is_cfa || d->cfa[0]) return false;
+  for (int i = 0; i < 4; ++i) if (!same(d->blacklevels[i], 0.0f) || !same(d->whitelevels[i], 0.0f)) return false;
+  for (int i = 0; i < 5; ++i) if (!same(d->rotatecrop[i], 0.0f)) return false;
+  float m[12]; ipk::srgb_d65_43(m);
+  for (int i = 0; i < 12; ++i) if (!same(d->cam_to_xyz_normalized[i], m[i])) return false;
+  const float wb[4] = {1.0f, 1.0f, 1.0f, 0.0f};
+  for (int i = 0; i < 4; ++i) if (!same(d->wb_coeffs[i], wb[i])) return false;
+  if (!same(d->exposure, 0.0f) || d->npoints != 0) return false;
+  return d->rotation == 0 && !d->fliph && !d->flipv;
+}
+int ipk_pipeline_takes_fastpath(const ipk_pipeline_desc *d, int out_type) {
+  if (!d) return fail(IPK_ERR_INVALID, "null descriptor");
+  return (d->use_fastpath && (out_type == IPK_OUT_U8 || out_type == IPK_OUT_U16) && default_ops_other(d)) ? 1 : 0;
+}
+// output_8bit / output_16bit fast path (pipeline.rs:381-402, :428-449) on device buffers
+static int run_fastpath(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, void *stream) {
+  const size_t n = d->width * d->height * 3;
+  const ipk::Scaling sc = ipk::calculate_scaling_total(d->width, d->height, d->maxwidth, d->maxheight);      // scaling_size
+  const bool scaled = sc.width != d->width || sc.height != d->height;
+  const bool want16 = out_type == IPK_OUT_U16, have16 = d->src_type == IPK_SRC_RGB16;
+  const size_t esz = want16 ? 2 : 1;
+  Scratch tmp;
+  const void *rgb = src;
+  if (want16 != have16) {                                                  // to_rgb8 / to_rgb16
+    void *conv = dst;
+    if (scaled) { int rc = tmp.get(n * esz, &conv); if (rc) return rc; }
+    if (want16) ipk::launch_chan_8_to_16(static_cast<const uint8_t *>(src), n, static_cast<uint16_t *>(conv), g.num_cus, S(stream));
+    else ipk::launch_chan_16_to_8(static_cast<const uint16_t *>(src), n, static_cast<uint8_t *>(conv), g.num_cus, S(stream));
+    HIPCHK(hipGetLastError());
+    rgb = conv;
+  }
+  if (!scaled) {
+    if (rgb != dst) HIPCHK(hipMemcpyAsync(dst, rgb, n * esz, hipMemcpyDeviceToDevice, S(stream)));
+    return IPK_OK;
+  }
+  // scale_down_srgb / scale_down_srgb16 (scaling.rs:162-182)
+  return want16
+    ? ipk_transform_buffer_u16(static_cast<const uint16_t *>(rgb), d->width, d->height, 0, 0, (int64_t)d->width - 1, 0, 0, (int64_t)d->height - 1,
+                               sc.width, sc.height, 3, nullptr, static_cast<uint16_t *>(dst), stream)
+    : ipk_transform_buffer_u8(static_cast<const uint8_t *>(rgb), d->width, d->height, 0, 0, (int64_t)d->width - 1, 0, 0, (int64_t)d->height - 1,
+                              sc.width, sc.height, 3, nullptr, static_cast<uint8_t *>(dst), stream);
+}
+
 int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused, void *stream) {
   REQUIRE_INIT();
   if (!d || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
   if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  if (ipk_pipeline_takes_fastpath(d, out_type) == 1) {
+    if (used_fused) *used_fused = 0;
+    if (d->width < 1 || d->height < 1) return fail(IPK_ERR_INVALID, "empty source");
+    return run_fastpath(d, src, dst, out_type, stream);
+  }
   size_t dw, dh, fw, fh;
   int rc = ipk_pipeline_sizes(d, &dw, &dh, &fw, &fh); if (rc) return rc;
   // output_8bit forces linear=false (pipeline.rs:405), output_16bit linear=true (:452)
@@ -924,6 +978,11 @@ int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_
   REQUIRE_INIT();
   if (!d || !src || !dst || !cache) return fail(IPK_ERR_INVALID, "null argument");
   if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
+  if (ipk_pipeline_takes_fastpath(d, out_type) == 1) {                    // returns before the cache is consulted (pipeline.rs:381-402)
+    if (ops_run) *ops_run = 0;
+    if (used_fused) *used_fused = 0;
+    return run_fastpath(d, src, dst, out_type, stream);
+  }
   Negotiated n; int rc = negotiate(d, out_type, n); if (rc) return rc;
   ipk::BufHash hs[8]; hash_chain(d, n, source_id, hs);
   if (ops_run) *ops_run = 0;

@@ -535,6 +535,18 @@ void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t bas
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(k_output8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
 }
+__global__ void k_chan_8_to_16(const uint8_t *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint16_t)(src[i] * 257u);
+}
+__global__ void k_chan_16_to_8(const uint16_t *__restrict__ src, size_t n, uint8_t *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint8_t)(((uint32_t)src[i] + 128u) / 257u);
+}
+void launch_chan_8_to_16(const uint8_t *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_chan_8_to_16, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+}
+void launch_chan_16_to_8(const uint16_t *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
+  hipLaunchKernelGGL(k_chan_16_to_8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+}
 void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(k_output16, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
 }

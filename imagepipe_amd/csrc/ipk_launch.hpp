@@ -47,6 +47,9 @@ void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t bas
                    float *dst3, hipStream_t s);
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s);
 void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s);
+// DynamicImage::to_rgb16 / to_rgb8 channel conversion of the raster fast path (image 0.24: c*257, (c+128)/257)
+void launch_chan_8_to_16(const uint8_t *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s);
+void launch_chan_16_to_8(const uint16_t *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s);
 
 struct FusedLaunch {
   const void *src; void *dst;

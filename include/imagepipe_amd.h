@@ -274,6 +274,7 @@ typedef struct {
   size_t maxwidth, maxheight;      /* PipelineSettings */
   int linear;
   int allow_fused;                 /* 1: use ipk_raw_to_srgb when legal (cache==None); 0: always staged */
+  int use_fastpath;                /* PipelineSettings.use_fastpath (pipeline.rs:117; the reference defaults it to true) */
 } ipk_pipeline_desc;
 
 /* Size negotiation of Pipeline::run (src/pipeline.rs:314-338): demosaic_{w,h} as stored in the
@@ -287,6 +288,12 @@ IPK_API int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, s
  * *used_fused (may be NULL) reports which path ran. */
 IPK_API int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type,
                              int *used_fused, void *stream);
+/* Raster fast path of output_8bit / output_16bit (pipeline.rs:381-402, :428-449): when d->use_fastpath is set, the
+ * source is RGB8/RGB16, out_type is U8/U16 and the ops are the defaults for a raster source (Pipeline::default_ops,
+ * :286-288, compared bitwise), ipk_pipeline_run / _cached skip the float pipeline: DynamicImage::to_rgb8/16 channel
+ * conversion if the depths differ (image 0.24: c*257, (c+128)/257 -- crate absent, parity unpinned) and
+ * scale_down_srgb / scale_down_srgb16 (scaling.rs:162-182) if a size limit applies.  Returns 1 / 0. */
+IPK_API int ipk_pipeline_takes_fastpath(const ipk_pipeline_desc *d, int out_type);
 /* Same with HOST source and destination buffers; synchronous. */
 IPK_API int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused);
 

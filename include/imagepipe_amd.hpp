@@ -351,7 +351,7 @@ class Pipeline {
     d.exposure = ops.basecurve.exposure; d.npoints = (int)ops.basecurve.points.size();
     for (size_t i = 0; i < ops.basecurve.points.size() && i < 64; ++i) { d.points[2 * i] = ops.basecurve.points[i].first; d.points[2 * i + 1] = ops.basecurve.points[i].second; }
     d.rotation = ops.transform.rotation; d.fliph = ops.transform.fliph; d.flipv = ops.transform.flipv;
-    d.maxwidth = globals.settings.maxwidth; d.maxheight = globals.settings.maxheight; d.linear = globals.settings.linear; d.allow_fused = allow_fused;
+    d.maxwidth = globals.settings.maxwidth; d.maxheight = globals.settings.maxheight; d.linear = globals.settings.linear; d.allow_fused = allow_fused; d.use_fastpath = globals.settings.use_fastpath;
     return d;
   }
  private:

@@ -78,7 +78,7 @@ class PipelineDesc(C.Structure):
         ("cam_to_xyz_normalized", C.c_float * 12), ("wb_coeffs", C.c_float * 4),
         ("exposure", C.c_float), ("npoints", C.c_int), ("points", C.c_float * 128),
         ("rotation", C.c_int), ("fliph", C.c_int), ("flipv", C.c_int),
-        ("maxwidth", _sz), ("maxheight", _sz), ("linear", C.c_int),
+        ("maxwidth", _sz), ("maxheight", _sz), ("linear", C.c_int), ("use_fastpath", C.c_int),
     ]
 
 
@@ -463,7 +463,7 @@ def rotatecrop_run(params5, buf):
 def make_pipeline(data, *, source_kind=None, cfa="", is_cfa=None, cpp=1, crops=(0, 0, 0, 0),
                   blacklevels=(0, 0, 0, 0), whitelevels=(0, 0, 0, 0), rotatecrop=(0, 0, 0, 0, 0),
                   cam_to_xyz_normalized=None, wb_coeffs=(1.0, 1.0, 1.0, 0.0), exposure=0.0, points=None,
-                  rotation=ROT_NORMAL, fliph=False, flipv=False, maxwidth=0, maxheight=0, linear=False):
+                  rotation=ROT_NORMAL, fliph=False, flipv=False, maxwidth=0, maxheight=0, linear=False, use_fastpath=False):
     """Builds the descriptor a `Pipeline::new_from_source` would hold.  For raw sources pass the
     already-cropped CFA string (`cropped_cfa()`), crops = (top, right, bottom, left)."""
     data = np.ascontiguousarray(data)
@@ -495,6 +495,7 @@ def make_pipeline(data, *, source_kind=None, cfa="", is_cfa=None, cpp=1, crops=(
         d.points[i] = v
     d.rotation = rotation; d.fliph = int(fliph); d.flipv = int(flipv)
     d.maxwidth = maxwidth; d.maxheight = maxheight; d.linear = int(linear)
+    d.use_fastpath = int(use_fastpath)          # the reference's default is true; tests of the slow path say so explicitly
     return d
 
 

@@ -1156,6 +1156,7 @@ typedef struct {
   /* settings */
   size_t maxwidth, maxheight;
   int linear;
+  int use_fastpath;           /* PipelineSettings.use_fastpath (pipeline.rs:117) */
 } orc_pipeline;
 
 ORC_API size_t orc_pipeline_sizeof(void) { return sizeof(orc_pipeline); }
@@ -1272,8 +1273,45 @@ ORC_API float *orc_pipeline_run(const orc_pipeline *p, size_t *out_w, size_t *ou
 }
 ORC_API void orc_free(void *p) { free(p); }
 
-/* Pipeline::output_8bit slow path (pipeline.rs:404-421): linear=false, run, serial quantise */
+/* Pipeline::default_ops (pipeline.rs:286-288) for a raster source: the ops equal PipelineOps::new(Other), compared
+ * bitwise as the reference's serialise-and-hash equality does (-0.0 != 0.0).  The reference also serialises
+ * OpRotateCrop's negotiated state, which a previous slow-path run leaves behind; this stateless restatement
+ * compares the user-visible fields only. */
+static int bits_eq(float a, float b) { return memcmp(&a, &b, 4) == 0; }
+ORC_API int orc_pipeline_default_ops_other(const orc_pipeline *p) {
+  if (p->source_kind < 2) return 0;
+  if (p->crop_top || p->crop_right || p->crop_bottom || p->crop_left || p->is_cfa || p->cfa[0]) return 0;
+  for (int i = 0; i < 4; i++) if (!bits_eq(p->blacklevels[i], 0.0f) || !bits_eq(p->whitelevels[i], 0.0f)) return 0;
+  for (int i = 0; i < 5; i++) if (!bits_eq(p->rc[i], 0.0f)) return 0;
+  float m[12]; orc_const_srgb_d65_43(m);
+  for (int i = 0; i < 12; i++) if (!bits_eq(p->cam_to_xyz_normalized[i], m[i])) return 0;
+  const float wb[4] = {1.0f, 1.0f, 1.0f, 0.0f};
+  for (int i = 0; i < 4; i++) if (!bits_eq(p->wb_coeffs[i], wb[i])) return 0;
+  if (!bits_eq(p->exposure, 0.0f) || p->npoints != 0) return 0;
+  if (p->rotation != 0 || p->fliph || p->flipv) return 0;
+  return 1;
+}
+/* image 0.24 DynamicImage::to_rgb8 / to_rgb16 channel conversions (crate absent from /root/reference; its published
+ * FromPrimitive impls): u8 -> u16 = c * 257, u16 -> u8 = (c + 128) / 257.  Parity unpinned. */
+static uint16_t chan_8_to_16(uint8_t c) { return (uint16_t)(c * 257u); }
+static uint8_t chan_16_to_8(uint16_t c) { return (uint8_t)(((uint32_t)c + 128u) / 257u); }
+
+/* Pipeline::output_8bit: raster fast path (pipeline.rs:381-402), else the slow path (:404-421: linear=false, run, serial quantise) */
 ORC_API uint8_t *orc_pipeline_output_8bit(orc_pipeline *p, size_t *out_w, size_t *out_h) {
+  if (p->use_fastpath && orc_pipeline_default_ops_other(p)) {
+    const size_t n = p->width * p->height * 3;
+    uint8_t *rgb = (uint8_t *)malloc(n ? n : 1);
+    if (p->source_kind == 2) memcpy(rgb, p->data, n);
+    else for (size_t i = 0; i < n; i++) rgb[i] = chan_16_to_8(((const uint16_t *)p->data)[i]);
+    float scale; size_t nw, nh;
+    orc_calculate_scaling_total(p->width, p->height, p->maxwidth, p->maxheight, &scale, &nw, &nh);     /* scaling_size */
+    *out_w = nw; *out_h = nh;
+    if (nw == p->width && nh == p->height) return rgb;
+    uint8_t *out = (uint8_t *)calloc(nw * nh * 3, 1);
+    orc_scale_down_srgb(rgb, p->width, p->height, nw, nh, out);
+    free(rgb);
+    return out;
+  }
   p->linear = 0;
   float *buf = orc_pipeline_run(p, out_w, out_h);
   if (!buf) return NULL;
@@ -1283,8 +1321,22 @@ ORC_API uint8_t *orc_pipeline_output_8bit(orc_pipeline *p, size_t *out_w, size_t
   free(buf);
   return img;
 }
-/* Pipeline::output_16bit slow path (pipeline.rs:451-468): linear=true */
+/* Pipeline::output_16bit: raster fast path (pipeline.rs:428-449), else the slow path (:451-468: linear=true) */
 ORC_API uint16_t *orc_pipeline_output_16bit(orc_pipeline *p, size_t *out_w, size_t *out_h) {
+  if (p->use_fastpath && orc_pipeline_default_ops_other(p)) {
+    const size_t n = p->width * p->height * 3;
+    uint16_t *rgb = (uint16_t *)malloc(n ? n * 2 : 2);
+    if (p->source_kind == 3) memcpy(rgb, p->data, n * 2);
+    else for (size_t i = 0; i < n; i++) rgb[i] = chan_8_to_16(((const uint8_t *)p->data)[i]);
+    float scale; size_t nw, nh;
+    orc_calculate_scaling_total(p->width, p->height, p->maxwidth, p->maxheight, &scale, &nw, &nh);
+    *out_w = nw; *out_h = nh;
+    if (nw == p->width && nh == p->height) return rgb;
+    uint16_t *out = (uint16_t *)calloc(nw * nh * 3, 2);
+    orc_scale_down_srgb16(rgb, p->width, p->height, nw, nh, out);
+    free(rgb);
+    return out;
+  }
   p->linear = 1;
   float *buf = orc_pipeline_run(p, out_w, out_h);
   if (!buf) return NULL;

@@ -210,3 +210,23 @@ def test_const_matrices_and_mirror_temp(L, orc):
     assert np.array_equal(np.array(op.wb_coeffs, np.float32).view(np.uint32), want.view(np.uint32))
     t, ti = op.get_temp()
     assert abs(t - 5000.0) < 3.0 and abs(ti - 1.0) < 2e-3
+
+
+def test_fastpath_decision(L):
+    """Pipeline::default_ops for a raster source (pipeline.rs:286-288, :381-383): bitwise equality with PipelineOps::new(Other)"""
+    def d(**kw):
+        x = _desc(**{k: v for k, v in kw.items() if k not in ("wb_coeffs", "cam")}); x.use_fastpath = kw.get("use_fastpath", 1)
+        m = (C.c_float * 12)(); L.ipk_const_matrix(2, m); x.cam_to_xyz_normalized[:] = m[:]
+        x.wb_coeffs[:] = [1.0, 1.0, 1.0, 0.0]
+        for k, v in kw.items():
+            if k in ("wb_coeffs", "cam"):
+                (x.wb_coeffs if k == "wb_coeffs" else x.cam_to_xyz_normalized)[:] = v
+        return x
+    for out_type, want in [(0, 0), (1, 1), (2, 1)]:
+        assert L.ipk_pipeline_takes_fastpath(C.byref(d()), out_type) == want
+    assert L.ipk_pipeline_takes_fastpath(C.byref(d(src_type=3)), 2) == 1          # RGB16
+    for kw in [dict(use_fastpath=0), dict(src_type=0), dict(crop_left=1), dict(rotation=1), dict(fliph=1), dict(exposure=0.1), dict(exposure=-0.0),
+               dict(rotatecrop=[0.0, 0.0, 0.0, 0.0, -0.0]), dict(rotatecrop=[0.1, 0.0, 0.0, 0.0, 0.0]), dict(wb_coeffs=[1.0, 1.0, 1.0, 1.0]), dict(is_cfa=1),
+               dict(npoints=1)]:
+        assert L.ipk_pipeline_takes_fastpath(C.byref(d(**kw)), 1) == 0, kw
+    assert L.ipk_pipeline_takes_fastpath(C.byref(d(maxwidth=64, maxheight=10)), 1) == 1      # settings are not ops

@@ -174,20 +174,24 @@ def test_staged_pipeline_vs_oracle(ipa, orc, case):
 
 
 # ---------------------------------------------------------------------------------------------
-# tests/roundtrip_test.rs on the GPU: all 2^24 RGB8 colours through output_8bit (slow path)
+# tests/roundtrip_test.rs on the GPU: all 2^24 RGB8 colours through output_8bit, fast path and slow path
 # ---------------------------------------------------------------------------------------------
-def test_roundtrip_8bit_slowpath_gpu(ipa):
+@pytest.mark.parametrize("fast", [True, False])
+def test_roundtrip_8bit_gpu(ipa, fast):
     import torch
     a = np.arange(256, dtype=np.uint8)
     r, g, b = np.meshgrid(a, a, a, indexing="ij")
     img = np.stack([r.ravel(), g.ravel(), b.ravel()], axis=1).reshape(4096, 4096, 3)
     pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(4096, 4096, torch.from_numpy(img.ravel()).cuda(), bits=8))
+    pipe.globals.settings.use_fastpath = fast
+    assert bool(ipa.lib().ipk_pipeline_takes_fastpath(pipe.desc(), ipa.OUT_U8)) == fast
     w, h, o8 = pipe.output_8bit()
     assert (w, h) == (4096, 4096)
     assert np.array_equal(o8.cpu().numpy().reshape(4096, 4096, 3), img)
 
 
-def test_roundtrip_16bit_slowpath_gpu(ipa):
+@pytest.mark.parametrize("fast", [True, False])
+def test_roundtrip_16bit_gpu(ipa, fast):
     """strided 16-bit colours (89/97/101) through output_16bit: identity (tests/roundtrip_test.rs:37-84)"""
     r16 = np.arange(0, 65536, 89, dtype=np.uint32).astype(np.uint16)
     g16 = np.arange(0, 65536, 97, dtype=np.uint32).astype(np.uint16)
@@ -203,8 +207,36 @@ def test_roundtrip_16bit_slowpath_gpu(ipa):
         img = np.zeros((hgt * wdt, 3), np.uint16); img[:n] = t
         img = img.reshape(hgt, wdt, 3)
         pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(wdt, hgt, ipa.upload_u16(img), bits=16))
+        pipe.globals.settings.use_fastpath = fast
         w, h, o16 = pipe.output_16bit()
         assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hgt, wdt, 3), img)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("maxwidth", [0, 100, 37])
+def test_raster_fastpath_vs_oracle(ipa, orc, bits, maxwidth):
+    """output_8bit / output_16bit of a raster source with default ops (pipeline.rs:381-402, :428-449): no float pipeline, integer
+    resampling (scale_down_srgb/16), channel-depth conversion when the depths differ; and the slow path beside it"""
+    import torch
+    h, w = 150, 211
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256 if bits == 8 else 65536, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+    data = torch.from_numpy(img.ravel()).cuda() if bits == 8 else ipa.upload_u16(img)
+    for fast in (True, False):
+        pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(w, h, data, bits=bits))
+        pipe.globals.settings.maxwidth = maxwidth; pipe.globals.settings.use_fastpath = fast
+        ww, hh, o8 = pipe.output_8bit()
+        want = orc.pipeline_output_8bit(orc.make_pipeline(img, maxwidth=maxwidth, use_fastpath=fast))
+        assert (hh, ww) == want.shape[:2] and np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), want), ("8", fast)
+        ww, hh, o16 = pipe.output_16bit()
+        want = orc.pipeline_output_16bit(orc.make_pipeline(img, maxwidth=maxwidth, use_fastpath=fast))
+        assert (hh, ww) == want.shape[:2] and np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), want), ("16", fast)
+    # an edited op leaves the fast path (default_ops() false)
+    pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(w, h, data, bits=bits))
+    pipe.ops.basecurve.exposure = 0.5
+    assert ipa.lib().ipk_pipeline_takes_fastpath(pipe.desc(), ipa.OUT_U8) == 0
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(orc.make_pipeline(img, exposure=0.5, use_fastpath=True)))
 
 
 # ---------------------------------------------------------------------------------------------
