@@ -579,6 +579,44 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   return IPK_OK;
 }
 
+// OpToLab::run + OpBaseCurve::run + OpFromLab::run + OpGamma::run (colorspaces.rs:89-112, curves.rs:33-49, colorspaces.rs:127-137,
+// gamma.rs:16-26) in one pass: what Pipeline::run computes between rotatecrop and transform when no cache needs the
+// intermediate buffers.
+int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs, const float *cam_to_xyz_normalized,
+                        float exposure, const float *points, int npoints, int linear, float *dst3, void *stream) {
+  REQUIRE_INIT();
+  if (!src4 || !dst3 || !wb_coeffs || !cam_to_xyz_normalized || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad pointwise_chain arguments");
+  if (npoints < 0 || npoints > 64 || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "npoints out of range");
+  float mul[4], cm[12];
+  if (monochrome) { ipk::srgb_d65_43(cm); mul[0] = mul[1] = mul[2] = mul[3] = 1.0f; }                     // colorspaces.rs:90-101
+  else { std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul); }
+  ipk::FusedLaunch f;
+  std::memset(&f, 0, sizeof(f));
+  f.src = src4; f.dst = dst3;
+  f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33;
+  {
+    auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
+    for (int i = 0; i < 12; ++i) ok = ok && sane(cm[i]);
+    f.fast_ok = ok ? 1 : 0;
+  }
+  ipk::Spline sp;
+  f.has_curve = !curve_is_noop(exposure, npoints);
+  if (f.has_curve) {
+    int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
+    for (int i = 0; i < sp.npoints; ++i) if (!(std::fabs(sp.px[i]) <= 0x1p20f && std::fabs(sp.py[i]) <= 0x1p20f && std::fabs(sp.c1[i]) <= 0x1p40f)) f.fast_ok = 0;
+    for (int i = 0; i < sp.nseg; ++i) if (!(std::fabs(sp.c2[i]) <= 0x1p40f && std::fabs(sp.c3[i]) <= 0x1p40f)) f.fast_ok = 0;
+  }
+  f.spline = &sp;
+  f.linear = linear;
+  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
+  f.num_cus = g.num_cus;
+  ipk::launch_pointwise_chain(f, width * height, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // self-test hooks
 // ------------------------------------------------------------------------------------------
@@ -810,17 +848,28 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       sc.release(buf); buf = o; w = ow; h = oh;
     }
   }
+  const size_t n3 = w * h * 3 * sizeof(float);
+  const bool f32_out0 = out_type == IPK_OUT_F32;
+  bool chained = false;
+  if (d->allow_fused && colors == 4) {
+    // tolab + basecurve + fromlab + gamma in one pass (no cache wants the three intermediates)
+    void *o = nullptr;
+    if (f32_out0 && transform_noop) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }
+    rc = ipk_pointwise_chain(static_cast<const float *>(buf), w, h, monochrome, d->wb_coeffs, d->cam_to_xyz_normalized, d->exposure, d->points, d->npoints,
+                             linear, static_cast<float *>(o), stream);
+    if (rc < 0) return rc;
+    sc.release(buf); buf = o; colors = 3; chained = true;
+  }
   // tolab
-  {
+  if (!chained) {
     void *o = nullptr;
     rc = sc.get(w * h * 3 * sizeof(float), &o); if (rc) return rc;
     rc = ipk_tolab(static_cast<const float *>(buf), w, h, monochrome, d->wb_coeffs, d->cam_to_xyz_normalized, static_cast<float *>(o), stream);
     if (rc < 0) return rc;
     sc.release(buf); buf = o; colors = 3;
   }
-  const size_t n3 = w * h * 3 * sizeof(float);
   // basecurve
-  {
+  if (!chained) {
     void *o = nullptr;
     rc = sc.get(n3, &o); if (rc) return rc;
     rc = ipk_basecurve(static_cast<const float *>(buf), w, h, d->exposure, d->points, d->npoints, static_cast<float *>(o), stream);
@@ -831,7 +880,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   const bool gamma_runs = !linear;
   const bool f32_out = out_type == IPK_OUT_F32;
   // fromlab
-  {
+  if (!chained) {
     void *o = nullptr;
     const bool last = f32_out && !gamma_runs && transform_noop;
     if (last) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }
@@ -840,7 +889,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     sc.release(buf); buf = o;
   }
   // gamma
-  if (gamma_runs) {
+  if (gamma_runs && !chained) {
     void *o = nullptr;
     const bool last = f32_out && transform_noop;
     if (last) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }

@@ -1309,6 +1309,82 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 
 
 // ------------------------------------------------------------------------------------------
+// OpToLab + OpBaseCurve + OpFromLab + OpGamma in one pass over a 4-channel OpBuffer (the ops between demosaic /
+// rotatecrop and transform): 16 bytes in, 12 out per pixel, HBM-bound.  Same per-pixel code as the fused raw kernel
+// (pointwise2_fast, literal redo behind a wave-uniform branch).  A wave takes 256 consecutive pixels per step; lane L
+// owns pixels L, 64+L, 128+L, 192+L of the chunk, so every load (16 B per lane) and store (12 B per lane) is contiguous
+// across the wave and nothing needs staging.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) {
+  __shared__ float s_lab[kLutPairs + 4];
+  __shared__ float s_gam[kLutPairs + 4];
+  __shared__ float s_knots[5 * kSplineMaxKnots];
+  __shared__ float s_par[32];
+  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
+  if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
+  else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
+  else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
+  if (threadIdx.x < kSplineMaxKnots) {
+    const int i = threadIdx.x;
+    s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
+    s_knots[3 * kSplineMaxKnots + i] = a.spline.c2[i]; s_knots[4 * kSplineMaxKnots + i] = a.spline.c3[i];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const uint64_t nchunks = (npix + 255) / 256;
+  const float4 *src = reinterpret_cast<const float4 *>(a.src);
+  f3 *dst = reinterpret_cast<f3 *>(a.dst);
+  for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const uint64_t base = chunk * 256 + lane;
+    float4 px[4];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t i = base + 64u * j;
+      px[j] = src[i < npix ? i : npix - 1];               // clamped, unpredicated: the tail lanes recompute the last pixel
+    }
+    PixOut o[4];
+    // the fast form drops the E term (e * cm[i][3]): legal while the fourth channel is +0.0, as every producer on this
+    // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
+    bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
+    if (a.fast_ok) {
+      bad |= pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[0], px[1], o[0], o[1]);
+      bad |= pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[2], px[3], o[2], o[3]);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
+        if (bad) o[j] = e;
+      }
+    }
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t i = base + 64u * j;
+      if (i < npix) dst[i] = f3{o[j].r, o[j].g, o[j].b};
+    }
+  }
+}
+int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
+  FusedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.src = f.src; a.dst = f.dst;
+  a.fast_ok = f.fast_ok;
+  a.tolab = make_tolab(f.mul4, f.cm12);
+  for (int i = 0; i < 9; ++i) a.rgbm.m[i] = f.rgbm9[i];
+  a.has_curve = f.has_curve; a.linear = f.linear;
+  if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
+  a.lab_table = reinterpret_cast<const float *>(f.lab_table);
+  a.gam_table = reinterpret_cast<const float *>(f.gam_table);
+  const size_t chunks = (npix + 255) / 256;
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
+  const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
+  hipLaunchKernelGGL(k_pointwise_chain, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Self-test kernels: exhaustive on-device proofs of the arithmetic shortcuts the fused kernel uses
 // (tests/test_gpu_selftest.py).  Each compares a shortcut with the plain IEEE expression over every
 // f32 bit pattern and reports the mismatches.

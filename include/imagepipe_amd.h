@@ -252,6 +252,14 @@ typedef struct {
  * (callers then run the staged ops). */
 IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
 
+/* OpToLab::run + OpBaseCurve::run + OpFromLab::run + OpGamma::run (src/ops/colorspaces.rs:89-112, src/ops/curves.rs:33-49,
+ * src/ops/colorspaces.rs:127-137, src/ops/gamma.rs:16-26) in one pass over a 4-channel OpBuffer: the ops Pipeline::run applies
+ * between rotatecrop and transform, for callers that do not need the three intermediate buffers (cache == None).
+ * Arguments as for the four stage entry points; bit-identical to running them one after the other. */
+IPK_API int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs,
+                                const float *cam_to_xyz_normalized, float exposure, const float *points, int npoints, int linear,
+                                float *dst3, void *stream);
+
 /* ---------------------------------------------------------------------------------------- */
 /* Pipeline driver: Pipeline::run / output_8bit / output_16bit for one source                */
 /* (src/pipeline.rs:311-375, :377-422, :424-469), cache == None                              */

@@ -299,6 +299,31 @@ def _rgbe_inputs(n, seed):
 
 
 @pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("npix", [1, 63, 256, 257, 64 * 96, 100003])
+def test_pointwise_chain_equals_the_four_ops(ipa, orc, mono, npix):
+    """ipk_pointwise_chain = OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma in one kernel: bit-identical to the oracle's four
+    stages, specials and a nonzero / NaN E channel included, any pixel count, with and without curve and gamma"""
+    import ctypes as C
+    import torch
+    n = max(npix, 3 * util.SPECIALS.size)
+    buf = _rgbe_inputs(n, util.SEED + 24)[:max(npix, 8)]
+    if npix < 8:
+        buf = buf[5:5 + npix]                                # keeps the rows with E = 0.7 / NaN
+    npix = buf.shape[0]
+    buf = np.ascontiguousarray(buf).reshape(1, npix, 4)
+    src = torch.from_numpy(buf.ravel()).cuda()
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    for exposure, points, linear in [(0.0, [(0.5, 0.6)], False), (0.3, [(0.2, 0.1), (0.7, 0.9)], False), (0.0, [], True), (0.0, [], False)]:
+        dst = torch.full((npix * 3,), -7.0, dtype=torch.float32, device="cuda")
+        pts = [c for p in points for c in p] or [0.0, 0.0]
+        rc = ipa.lib().ipk_pointwise_chain(src.data_ptr(), npix, 1, int(mono), fa(util.WB), fa(util.cam_matrix().ravel()), exposure, fa(pts), len(points),
+                                           int(linear), dst.data_ptr(), None)
+        assert rc == 0, ipa.lib().ipk_last_error()
+        want = orc.gamma(orc.fromlab(orc.basecurve(orc.tolab(buf, util.WB, util.cam_matrix(), monochrome=mono), exposure, points)), linear)
+        assert_bits_equal(dst.cpu().numpy().reshape(1, npix, 3), want, "chain mono=%s npix=%d exposure=%r linear=%s" % (mono, npix, exposure, linear))
+
+
+@pytest.mark.parametrize("mono", [False, True])
 def test_tolab_vs_oracle(ipa, orc, mono):
     h, w = 64, 96
     buf = _rgbe_inputs(h * w, util.SEED + 20).reshape(h, w, 4)
