@@ -30,7 +30,7 @@ int fail(int code, const char *fmt, ...) {
   do { hipError_t e_ = (expr);                                                                     \
        if (e_ != hipSuccess) return fail(IPK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
-struct DevCfa { uint32_t *lookups = nullptr; uint8_t *cfa48 = nullptr; };
+struct DevCfa { uint32_t *lookups = nullptr; uint8_t *cfa48 = nullptr; float *gen_cells = nullptr; int gen_pw = 0, gen_ph = 0; };   // gen_cells: null for filters with a fourth colour
 
 struct Context {
   bool ready = false;
@@ -78,6 +78,12 @@ int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&d.cfa48), 48 * 48));
   HIPCHK(hipMemcpy(d.lookups, lookups, sizeof(lookups), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.cfa48, &cfa.pattern[0][0], 48 * 48, hipMemcpyHostToDevice));
+  std::vector<float> cells;
+  if (cfa.gen_cells(cells)) {                                            // arithmetic form of demosaic::full for the row-walking kernel
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d.gen_cells), cells.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(d.gen_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+    d.gen_pw = cfa.width; d.gen_ph = cfa.height;
+  }
   g.cfa_cache[pat] = d;
   dev = d;
   return IPK_OK;
@@ -113,6 +119,20 @@ struct Scratch {                       // RAII: returns its buffers to the pool
 // The kernel-side proof obligations (ipk_device.hpp): range positive and ordinary, the fast quotient equal to the
 // true one on the dividends this source can produce, and (u16 sources, which the kernel does not guard) every
 // nonzero dividend inside [2^-100, 2^100].  Anything else makes the kernel use true divisions.
+// Generic-CFA mode, u16 sources: is every normalised sample (v - black) / range zero or inside [2^-60, 2^60]?
+bool gen_levels_ok_u16(float black, float range) {
+  static thread_local struct { uint32_t b, r; int ok; bool set; } memo = {0, 0, 0, false};
+  uint32_t bb, rb; std::memcpy(&bb, &black, 4); std::memcpy(&rb, &range, 4);
+  if (memo.set && memo.b == bb && memo.r == rb) return memo.ok != 0;
+  bool ok = true;
+  for (uint32_t v = 0; v < 65536 && ok; ++v) {
+    const float q = ((float)v - black) / range;
+    const float a = std::fabs(q);
+    ok = (q == 0.0f) || (a >= 0x1p-60f && a <= 0x1p60f);
+  }
+  memo = {bb, rb, ok ? 1 : 0, true};
+  return ok;
+}
 bool validate_cdiv_for_range_uncached(float black, float range, bool src_is_u16);
 bool validate_cdiv_for_range(float black, float range, bool src_is_u16) {
   // one-entry memo: a pipeline is launched many times with the same levels
@@ -204,7 +224,7 @@ void ipk_shutdown(void) {
   if (!g.ready) return;
   (void)hipDeviceSynchronize();
   for (int t = 0; t < 3; ++t) { if (g.lut_pairs[t]) (void)hipFree(g.lut_pairs[t]); g.lut_pairs[t] = nullptr; if (g.lut_plain[t]) (void)hipFree(g.lut_plain[t]); g.lut_plain[t] = nullptr; }
-  for (auto &kv : g.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); }
+  for (auto &kv : g.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); if (kv.second.gen_cells) (void)hipFree(kv.second.gen_cells); }
   g.cfa_cache.clear();
   for (auto &b : g.pool) (void)hipFree(b.p);
   g.pool.clear();
@@ -345,7 +365,9 @@ int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, si
   int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
   int xoff, yoff;
   if (cfa.bayer_phase(xoff, yoff))       // the four RGGB phases: row-walking kernel (coalesced loads, register window, staged stores)
-    ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, dst4, g.num_cus, S(stream));
+    ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, nullptr, 0, 0, dst4, g.num_cus, S(stream));
+  else if (dev.gen_cells)                // any other three-colour filter (X-Trans ...): same kernel, generic-CFA mode
+    ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, 0, 0, dev.gen_cells, dev.gen_pw, dev.gen_ph, dst4, g.num_cus, S(stream));
   else ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
@@ -525,10 +547,11 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   if (p->src_type != IPK_SRC_U16 && p->src_type != IPK_SRC_F32) return fail(IPK_ERR_INVALID, "fused path takes u16 or f32 CFA data");
   if (!dims_ok(p->width, p->height) || p->owidth < p->x + p->width) return fail(IPK_ERR_INVALID, "bad geometry");
   if (p->out_type < 0 || p->out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
-  ipk::Cfa cfa;
-  if (!ipk::Cfa::parse(p->cfa, cfa) || !cfa.valid()) return fail(IPK_ERR_INVALID, "invalid CFA pattern");
-  int xoff, yoff;
-  if (!cfa.bayer_phase(xoff, yoff)) return fail(IPK_ERR_UNSUPPORTED, "CFA \"%s\" is not an RGGB-phase Bayer tile; run the staged ops", p->cfa);
+  ipk::Cfa cfa; DevCfa dev;
+  { int rc = get_cfa(p->cfa, cfa, dev); if (rc) return rc; }
+  int xoff = 0, yoff = 0;
+  const bool bayer = cfa.bayer_phase(xoff, yoff);
+  if (!bayer && !dev.gen_cells) return fail(IPK_ERR_UNSUPPORTED, "CFA \"%s\" has a fourth colour; run the staged ops", p->cfa);
 
   ipk::FusedLaunch f;
   const size_t esz = p->src_type == IPK_SRC_U16 ? 2 : 4;
@@ -551,6 +574,10 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.black0 = p->black0; f.white0 = p->white0;
   f.exact_norm = validate_cdiv_for_range(p->black0, p->white0 - p->black0, f.src_is_u16) ? 0 : 1;
   f.xoff = xoff; f.yoff = yoff;
+  f.gen_cells = bayer ? nullptr : dev.gen_cells; f.gen_pw = dev.gen_pw; f.gen_ph = dev.gen_ph;
+  // generic-CFA mode sums up to nine normalised samples and divides by a constant: u16 kernels check their samples only
+  // when the levels allow one outside [2^-60, 2^60] (f32 kernels always check)
+  f.gen_check = (!bayer && f.src_is_u16 && !gen_levels_ok_u16(p->black0, p->white0 - p->black0)) ? 1 : 0;
   float mul[4];
   ipk::normalize_wbs(p->wb_coeffs, mul);                                                                   // colorspaces.rs:100
   f.mul4 = mul; f.cm12 = p->cam_to_xyz_normalized; f.rgbm9 = g.xyz_d65_33;
@@ -762,7 +789,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   if (d->allow_fused && cfa_branch && d->cpp == 1 && rcop.noop() && transform_noop) {
     const float scale = ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale;
     ipk::Cfa cfa; int xo, yo;
-    if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && cfa.bayer_phase(xo, yo)) {
+    if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && (cfa.bayer_phase(xo, yo) || cfa.three_colour())) {
       ipk_fused_params fp;
       std::memset(&fp, 0, sizeof(fp));
       fp.src_type = d->src_type; fp.owidth = d->width; fp.x = r.x; fp.y = r.y; fp.width = r.width; fp.height = r.height;
@@ -1052,7 +1079,7 @@ int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_
   if (startpos == 0 && d->allow_fused && cfa_branch && d->cpp == 1 && n.rc.noop() && n.transform_noop) {
     const float scale = ipk::calculate_scaling_total(w0, h0, n.dw, n.dh).scale;
     ipk::Cfa cfa; int xo, yo;
-    if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && cfa.bayer_phase(xo, yo)) {
+    if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && (cfa.bayer_phase(xo, yo) || cfa.three_colour())) {
       ipk_pipeline_desc d2 = *d; d2.linear = n.linear;
       CBufP o; rc = cbuf_new(n.fw, n.fh, 3, 0, o); if (rc) return rc;
       int fused = 0;

@@ -139,6 +139,43 @@ struct Cfa {
         out[row * 48 + col] = w;
       }
   }
+  // demosaic::full restated as arithmetic for the row-walking kernel's generic-CFA mode (any filter without an E/fourth
+  // colour): per pattern cell 36 floats = tap weights {0,1} for R, G, B (9 each, the reference's tap order), the packed
+  // tap-colour word of demosaic_lookups(), and RN(1/count) as a hi/lo pair per colour (count = contributing taps of an
+  // interior pixel; 1 when a colour has none, so that 0/1 = 0 reproduces "stays 0.0").  An interior pixel is then
+  //   sum_c = 0.0 + t0*w_c0 + ... + t8*w_c8   (a non-contributing tap adds +-0.0, which never changes a sum that starts at +0.0)
+  //   out_c = fma(sum_c, rc_hi, sum_c*rc_lo)  (== sum_c / count for every finite sum in [2^-100, 2^100] and for 0:
+  //                                           proven on all f32 for counts 1..9, tests/test_gpu_selftest.py)
+  // Returns false when the pattern has a fourth colour.
+  bool three_colour() const { for (int r = 0; r < height; ++r) for (int c = 0; c < width; ++c) if (pattern[r][c] > 2) return false; return valid(); }
+  static constexpr int kGenCellFloats = 36;
+  bool gen_cells(std::vector<float> &out) const {
+    static const int off[9][2] = {{-1,-1},{-1,0},{-1,1},{0,-1},{0,0},{0,1},{1,-1},{1,0},{1,1}};
+    out.assign(size_t(width) * height * kGenCellFloats, 0.0f);
+    for (int y = 0; y < height; ++y)
+      for (int x = 0; x < width; ++x) {
+        float *cell = &out[(size_t(y) * width + x) * kGenCellFloats];
+        const int pix = color_at(size_t(y), size_t(x));
+        if (pix > 2) return false;
+        uint32_t word = 0; int cnt[3] = {0, 0, 0};
+        for (int i = 0; i < 9; ++i) {
+          const int dy = off[i][0], dx = off[i][1];
+          const int o = color_at(size_t(48 + dy + y), size_t(48 + dx + x));
+          if (o > 2) return false;
+          const int code = (o != pix || (dx == 0 && dy == 0)) ? o : 4;
+          word |= uint32_t(code) << (3 * i);
+          if (code < 3) { cell[code * 9 + i] = 1.0f; ++cnt[code]; }
+        }
+        std::memcpy(&cell[27], &word, 4);
+        for (int c = 0; c < 3; ++c) {
+          const float n = float(cnt[c] > 0 ? cnt[c] : 1);
+          const float hi = 1.0f / n;
+          cell[28 + c] = hi;
+          cell[31 + c] = float(1.0 / double(n) - double(hi));
+        }
+      }
+    return true;
+  }
   // Is this one of the four phases of the RGGB Bayer tile?  color_at(r,c) == RGGB[(r+yoff)&1][(c+xoff)&1]
   bool bayer_phase(int &xoff, int &yoff) const {
     if (width != 2 || height != 2) return false;

@@ -586,6 +586,9 @@ struct FusedArgs {
   uint32_t lc_base, lc_rem;   // lane-columns per strip: base (+1 for the first lc_rem strips)
   const float *lab_table;
   const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
+  const float *gen_cells;     // generic-CFA mode: gen_pw*gen_ph cells of 36 floats (ipk_host.hpp Cfa::gen_cells), else null
+  uint32_t gen_pw, gen_ph;    // pattern width / height (both divide 48)
+  int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not bound the normalised samples
   SplineDev spline;
 };
 
@@ -648,6 +651,47 @@ __device__ __forceinline__ float4 demosaic_inner_px(float nw, float n, float ne,
   if (ROLE == 1) return make_float4(horiz, own, vert, 0.0f);
   if (ROLE == 2) return make_float4(vert, own, horiz, 0.0f);
   return make_float4(diag, cross, own, 0.0f);
+}
+
+// ---- generic-CFA mode (X-Trans and any other filter without a fourth colour) --------------------------------------
+// Interior pixel from the pattern cell's record (see Cfa::gen_cells): masked sums in the reference's tap order, then the
+// proven two-step division by the tap count.  `cell` points at 36 floats, 16-byte aligned, in LDS.
+constexpr int kGenCellFloats = 36;
+constexpr int kGenMaxCells = 144;                        // 12 x 12
+__device__ __forceinline__ float4 demosaic_gen_px(const float *__restrict__ cell, const float t[9]) {
+  float w[kGenCellFloats];
+  #pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const float4 v = reinterpret_cast<const float4 *>(cell)[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  #pragma unroll
+  for (int i = 0; i < 9; ++i) { s0 = s0 + t[i] * w[i]; s1 = s1 + t[i] * w[9 + i]; s2 = s2 + t[i] * w[18 + i]; }
+  return make_float4(__builtin_fmaf(s0, w[28], s0 * w[31]), __builtin_fmaf(s1, w[29], s1 * w[32]), __builtin_fmaf(s2, w[30], s2 * w[33]), 0.0f);
+}
+// The literal form (demosaic.rs:99-114) from the packed tap colours: frame-edge pixels (taps outside the image are
+// skipped) and rows whose samples are outside the zone where the arithmetic form is proven.
+__device__ __forceinline__ float4 demosaic_gen_literal_px(uint32_t lk, const float t[9], uint32_t valid_mask) {
+  float s[3] = {0.0f, 0.0f, 0.0f}, n[3] = {0.0f, 0.0f, 0.0f};
+  #pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint32_t code = (lk >> (3 * i)) & 7u;
+    const bool ok = (valid_mask >> i) & 1u;
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool hit = ok && code == (uint32_t)k;
+      s[k] = hit ? s[k] + t[i] : s[k];
+      n[k] = hit ? n[k] + 1.0f : n[k];
+    }
+  }
+  return make_float4(n[0] > 0.0f ? s[0] / n[0] : 0.0f, n[1] > 0.0f ? s[1] / n[1] : 0.0f, n[2] > 0.0f ? s[2] / n[2] : 0.0f, 0.0f);
+}
+// A sample the arithmetic form may see: zero, or finite with 2^-60 <= |v| <= 2^60 (sums of nine such stay inside the
+// division's proven zone and their products with 0.0 are +-0.0, never NaN)
+__device__ __forceinline__ bool gen_sample_bad(float v) {
+  const float a = __builtin_fabsf(v);
+  return !(a <= 0x1p60f) || (a < 0x1p-60f && v != 0.0f);
 }
 
 struct PixOut { float r, g, b; };
@@ -985,7 +1029,7 @@ struct RgbeStage {
 // Occupancy: one 1024-thread block per CU = 4 waves per SIMD, on purpose.  Measured (tools/ubench2.hip, and this kernel's
 // u16->u8 variant, which fits two blocks in LDS): at 8 waves per SIMD the simple f32 ops lose their 2-cycle issue rate
 // (v_mul 1.0 -> 1.4 ns per wave64 instruction) and the kernel ran 23 % slower (0.79 -> 0.98 ms at 100 MP).
-template <typename SrcT, bool VEC, int OUT, bool FULL>
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
@@ -997,6 +1041,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   __shared__ float s_gam[DEMO ? 4 : kLutPairs + 4];
   __shared__ float s_knots[5 * kSplineMaxKnots];         // base-curve knots
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
+  __shared__ __attribute__((aligned(16))) float s_cells[GEN ? kGenMaxCells * kGenCellFloats : 4];   // generic-CFA cell records
+  if (GEN) for (uint32_t i = threadIdx.x; i < a.gen_pw * a.gen_ph * kGenCellFloats; i += blockDim.x) s_cells[i] = a.gen_cells[i];
   constexpr int STG = DEMO ? 1024 : (OUT == 0 ? 768 : (OUT == 1 ? 192 : 384));   // dwords of staging per wave: one output row segment
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * STG : 4];
   if (!DEMO) {
@@ -1029,6 +1075,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   const uint32_t nvalid = FULL ? 4u : min(4u, a.W - col0);
   // column parity of the lane's pixel j inside the RGGB tile is (j + xo) & 1: col0 - pc0 is a multiple of 4
   const uint32_t xo = ((uint32_t)a.xoff + pc0) & 1u;
+  // generic-CFA mode: the lane's four pattern-cell columns (float offsets into a row of cell records) never change
+  uint32_t cxo[4] = {0, 0, 0, 0};
+  if (GEN) {
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) cxo[j] = ((col0 + j) % a.gen_pw) * kGenCellFloats;
+  }
+  const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
   // rows: this segment's output rows [r0, r1)
   const uint32_t nrows = a.out_r1 - a.out_r0;
   const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
@@ -1059,7 +1112,9 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     t.h2 = single ? (float)rp[h2col] : 0.0f;
     return t;
   };
-  auto finish_row = [&](const RawRowT &t) -> RowWin {
+  // `flag` (generic-CFA mode): some sample of this row is outside the zone of the arithmetic demosaic form (wave-uniform)
+  auto finish_row = [&](const RawRowT &t, bool &flag) -> RowWin {
+    flag = false;
     // OpGoFloat: ((v - black) / range).min(1.0)  (gofloat.rs:126).  The division is cdiv_fast unless the host
     // could not validate it for this range, or a dividend of this wave is outside the proven zone.
     const float d0 = t.v0 - min0, d1 = t.v1 - min0, d2 = t.v2 - min0, d3 = t.v3 - min0, dh = t.h - min0, dh2 = t.h2 - min0;
@@ -1070,6 +1125,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       w.l = dpp_wave_shr1(t.h, w.v3);
       const float rr0 = dpp_wave_shl1(t.h, w.v0);
       w.r = is_last ? (single ? t.h2 : t.h) : rr0;
+      if (gen_guard) flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(t.v0) | gen_sample_bad(t.v1) | gen_sample_bad(t.v2) | gen_sample_bad(t.v3) |
+                                                        gen_sample_bad(t.h) | gen_sample_bad(t.h2)) != 0;
       return w;
     }
     bool redo = exact_norm;
@@ -1085,6 +1142,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       h = rs_min(dh / range0, 1.0f);
       if (single) h2 = rs_min(dh2 / range0, 1.0f);
     }
+    if (gen_guard) flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(w.v0) | gen_sample_bad(w.v1) | gen_sample_bad(w.v2) | gen_sample_bad(w.v3) |
+                                                      gen_sample_bad(h) | gen_sample_bad(h2)) != 0;
     w.l = dpp_wave_shr1(h, w.v3);                        // lane 0 keeps its halo (left column)
     const float rr = dpp_wave_shl1(h, w.v0);             // lane 63 keeps its halo
     w.r = is_last ? (single ? h2 : h) : rr;
@@ -1097,14 +1156,16 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
 
   const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
-  if (r0 > 0) P = finish_row(issue_row(r0 - 1));
-  C = finish_row(issue_row(r0));
+  bool fP = false, fC = false, fN = false;
+  if (r0 > 0) P = finish_row(issue_row(r0 - 1), fP);
+  C = finish_row(issue_row(r0), fC);
+  uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
   // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
   // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
   (void)zero_raw;
   RawRowT raw_next = issue_row(min(r0 + 1, Hm1));
   for (uint32_t r = r0; r < r1; ++r) {
-    N = finish_row(raw_next);                            // row r+1 (a copy of row H-1 past the frame: masked as an edge)
+    N = finish_row(raw_next, fN);                        // row r+1 (a copy of row H-1 past the frame: masked as an edge)
     raw_next = issue_row(min(r + 2, Hm1));
     const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
     const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
@@ -1113,7 +1174,18 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     float4 px[4];
     // interior formulas; role = (row parity, column parity) in the RGGB tile; the column parity of pixel j is
     // (j + xo) & 1 with a per-strip xo: wave-uniform branches only.
-    if (pr == 0) {
+    const float *rowcells = s_cells + ry * a.gen_pw * kGenCellFloats;
+    if (GEN) {
+      // any filter without a fourth colour: masked sums + proven division, or the literal form for a row window that
+      // holds a sample outside the proven zone
+      const bool literal = fP | fC | fN;
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
+        if (!literal) px[j] = demosaic_gen_px(rowcells + cxo[j], t);
+        else px[j] = demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, 0x1FFu);
+      }
+    } else if (pr == 0) {
       if (xo == 0) {
         px[0] = demosaic_inner_px<0>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
         px[1] = demosaic_inner_px<1>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
@@ -1152,7 +1224,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
             if (r == Hm1) m &= ~0x1C0u;
             if (c == 0) m &= ~0x049u;
             if (c == Wm1) m &= ~0x124u;
-            px[j] = demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
+            px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, m) : demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
           }
         }
       }
@@ -1167,7 +1239,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       } else if (lane_on) {
         RgbeStage::store_direct(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, px);
       }
-      P = C; C = N;
+      P = C; C = N; fP = fC; fC = fN;
+      if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
       continue;
     }
     PixOut o[4];
@@ -1215,7 +1288,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       if (lane_on) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
     }
 #endif
-    P = C; C = N;
+    P = C; C = N; fP = fC; fC = fN;
+    if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
   }
 }
 
@@ -1223,18 +1297,24 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blo
 
 // Staged demosaic::full for an RGGB-phase Bayer mosaic (OUT == 3 of the row-walking kernel).  Same band arguments as the
 // generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
+// gen_cells != null: generic-CFA mode (pattern gen_pw x gen_ph, no fourth colour) instead of the RGGB phase (xoff, yoff).
 void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
-                           int xoff, int yoff, float *dst4, int num_cus, hipStream_t s) {
+                           int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
   a.src = src; a.dst = dst4; a.W = (uint32_t)width; a.H = (uint32_t)img_height; a.owidth = width;
   a.row_off = (uint32_t)src_row0; a.out_r0 = (uint32_t)out_row0; a.out_r1 = (uint32_t)(out_row0 + out_rows);
   a.xoff = xoff; a.yoff = yoff; a.range0 = 1.0f; a.inv_range0 = 1.0f;
+  a.gen_cells = gen_cells; a.gen_pw = (uint32_t)gen_pw; a.gen_ph = (uint32_t)gen_ph;
   unsigned blocks;
   fused_task_grid(a, num_cus, blocks, 1);
-  if (a.W >= 256u)
-    hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true>), dim3(blocks), dim3(1024), 0, s, a);
-  else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false>), dim3(blocks), dim3(1024), 0, s, a);
+  if (gen_cells) {
+    if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, true>), dim3(blocks), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, true>), dim3(blocks), dim3(1024), 0, s, a);
+  } else {
+    if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, false>), dim3(blocks), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, false>), dim3(blocks), dim3(1024), 0, s, a);
+  }
 }
 
 template <typename SrcT, bool VEC, int OUT>
@@ -1244,8 +1324,14 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 #else
   const unsigned tpb = 1024;
 #endif
-  if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true>), dim3(grid), dim3(tpb), 0, s, a);
-  else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false>), dim3(grid), dim3(tpb), 0, s, a);
+  if (a.gen_cells) {                                     // generic-CFA mode: one load flavour per source type
+    constexpr bool V = sizeof(SrcT) == 4;
+    if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, false, true>), dim3(grid), dim3(tpb), 0, s, a);
+    return;
+  }
+  if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true, false>), dim3(grid), dim3(tpb), 0, s, a);
+  else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false, false>), dim3(grid), dim3(tpb), 0, s, a);
 }
 
 // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
@@ -1286,6 +1372,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
+  a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check;
 
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks, 1);

@@ -27,7 +27,7 @@ void launch_demosaic_full(const float *src, size_t width, size_t img_height, siz
                           const uint32_t *lookups_dev, float *dst4, hipStream_t s);
 
 void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
-                           int xoff, int yoff, float *dst4, int num_cus, hipStream_t s);
+                           int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s);
 
 template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
@@ -65,6 +65,7 @@ struct FusedLaunch {
   const SplineHost *spline;
   int out_type;                  // 0 f32, 1 u8, 2 u16
   const void *lab_table, *gam_table;   // plain 8193-float tables (XYZ_LAB_TRANSFORM, SRGB gamma)
+  const float *gen_cells; int gen_pw, gen_ph, gen_check;   // generic-CFA mode (device cell records) or null: RGGB phase (xoff, yoff)
   int num_cus;
 };
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);

@@ -124,11 +124,80 @@ def test_fused_row_bands_equal_whole_frame(ipa, orc):
         assert_bits_equal(out.cpu().numpy().reshape(r1 - r0, w, 3), want[r0:r1], "band %d..%d" % (r0, r1))
 
 
-def test_fused_rejects_non_bayer(ipa):
+def test_fused_rejects_four_colour_filters(ipa):
+    """the fused kernel covers every three-colour filter; RGBE-style mosaics (the fast point-wise form drops the E term) run staged"""
     import torch
     src = torch.zeros(36 * 36, dtype=torch.float32, device="cuda")
     with pytest.raises(ipa.IpkError):
-        ipa.raw_to_srgb(src, width=36, height=36, cfa="GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG")
+        ipa.raw_to_srgb(src, width=36, height=36, cfa="RGBE")
+    with pytest.raises(ipa.IpkError):
+        ipa.raw_to_srgb(src, width=36, height=36, cfa="RGXB")
+
+
+# ---------------------------------------------------------------------------------------------
+# generic-CFA mode of the fused kernel: X-Trans and other three-colour filters
+# ---------------------------------------------------------------------------------------------
+XT = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+W8X2 = "RGGBGRBGGBRGBGGR"                                   # an 8x2 three-colour tile
+W12 = (XT[0:6] + XT[18:24] + XT[6:12] + XT[24:30] + XT[12:18] + XT[30:36]) * 2 + (XT[18:24] + XT[0:6] + XT[24:30] + XT[6:12] + XT[30:36] + XT[12:18]) * 2
+W12 = (W12 * 2)[:144]
+
+
+@pytest.mark.parametrize("cfa", [XT, W8X2, W12])
+@pytest.mark.parametrize("shape", [(10, 10), (13, 37), (48, 257), (61, 530), (30, 1100)])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_fused_generic_cfa_vs_oracle(ipa, orc, cfa, shape, is_float):
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 80 + h * w, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    crops = (1, 0, 2, 5) if w > 40 else (0, 0, 0, 0)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, src, cfa, crops=crops)), "generic cfa fused")
+    pipe.allow_fused = False
+    assert_bits_equal(pipe.run().numpy(), got.numpy(), "generic cfa staged == fused")
+    pipe.allow_fused = True
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, crops=crops)))
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, cfa, crops=crops)))
+
+
+def test_fused_generic_cfa_specials_take_the_literal_form(ipa, orc):
+    """NaN / inf / denormal / huge samples in an X-Trans mosaic: the arithmetic demosaic form is not proven there, the row
+    windows that hold them use the literal form; results stay bit-identical"""
+    h, w = 40, 300
+    raw = util.noise_u16(util.SEED + 83, h, w).astype(np.float32) + util.uniform_f32(util.SEED + 84, h * w).reshape(h, w)
+    sp = util.SPECIALS * np.float32(16383.0)
+    raw[7, 5: 5 + sp.size] = sp; raw[21, 290: 300] = sp[:10]; raw[0, :3] = [np.nan, np.inf, -np.inf]; raw[39, 297:] = [1e-38, -1e-42, 3e38]
+    for black, white in [(util.BLACK, util.WHITE), (0.0, 1.0), (1e-30, 16383.0)]:
+        kw = dict(blacklevels=[black] * 4, whitelevels=[white] * 4)
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, XT, is_float=True, **kw))
+        got = pipe.run(); assert pipe.last_used_fused
+        assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, XT, **kw)), "xtrans specials %r" % ((black, white),))
+    # u16 levels that let a normalised sample leave [2^-60, 2^60]: the u16 kernel switches its sample check on
+    raw16 = util.noise_u16(util.SEED + 85, h, w)
+    for black, white in [(1e-30, 16383.0), (0.0, 1e-30), (100.0, 100.0 + 2.0 ** -40)]:
+        kw = dict(blacklevels=[black] * 4, whitelevels=[white] * 4)
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw16, XT, **kw))
+        got = pipe.run(); assert pipe.last_used_fused
+        assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw16, XT, **kw)), "xtrans u16 levels %r" % ((black, white),))
+
+
+def test_fused_generic_cfa_row_bands_equal_whole_frame(ipa, orc):
+    import torch
+    h, w = 90, 300
+    raw = util.noise_u16(util.SEED + 86, h, w)
+    want = orc.pipeline_run(_oracle_desc(orc, raw, XT))
+    dev = ipa.upload_u16(raw)
+    for r0, r1 in [(0, 30), (30, 66), (66, 90), (7, 8)]:
+        s0, s1 = max(0, r0 - 1), min(h, r1 + 1)
+        band = dev[s0 * w: s1 * w].clone()
+        out = ipa.raw_to_srgb(band, width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa=XT,
+                              wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix(), band=(s0, s1 - s0, r0, r1 - r0))
+        torch.cuda.synchronize()
+        assert_bits_equal(out.cpu().numpy().reshape(r1 - r0, w, 3), want[r0:r1], "xtrans band %d..%d" % (r0, r1))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -167,9 +236,11 @@ def test_staged_pipeline_vs_oracle(ipa, orc, case):
     assert pipe.negotiate() == orc.pipeline_sizes(desc)
     want = orc.pipeline_run(desc)
     got = pipe.run()
-    assert not pipe.last_used_fused
+    assert pipe.last_used_fused == (cfa == XTRANS and not okw)           # full-scale three-colour mosaics are fused; the rest runs staged
     assert (got.height, got.width) == want.shape[:2]
-    assert_bits_equal(got.numpy(), want, "staged driver")
+    assert_bits_equal(got.numpy(), want, "driver")
+    pipe.allow_fused = False
+    assert_bits_equal(pipe.run().numpy(), want, "staged driver")
     assert_bits_equal(pipe.run_ops().numpy(), want, "op loop")
 
 

@@ -68,6 +68,14 @@ def test_clamp_med3(L):
     assert n.value == 0, "v_med3(v,0,1) differs from v.max(0).min(1) at bits 0x%08x" % first.value
 
 
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_cdiv_two_step_by_tap_counts(L, count):
+    """generic-CFA demosaic (ipk_kernels.hip demosaic_gen_px): sum / count as fma(sum, rc_hi, sum*rc_lo) for every tap count a 3x3
+    window can produce, every finite f32 sum in [2^-100, 2^100] (a zero sum gives zero in both forms)"""
+    bad, first = _cdiv(L, float(count), 2, 2.0 ** -100, 2.0 ** 100, 0)
+    assert bad == 0, "count=%d: %d mismatches, first x bits 0x%08x" % (count, bad, first)
+
+
 def _device_cbrt(L, x, variant):
     import torch
     d = torch.from_numpy(x).cuda(); o = torch.empty_like(d)

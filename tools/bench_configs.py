@@ -39,7 +39,8 @@ def main():
     res = {}
     for name, (h, w, cfa, maxw, is_float) in {"C2_24MP_rggb_f32": (4000, 6000, "RGGB", 0, True), "C2_24MP_rggb_u16": (4000, 6000, "RGGB", 0, False),
                                                  "C3_100MP_rggb_f32": (10000, 10000, "RGGB", 0, True),
-                                                 "C5_50MP_xtrans_to_2160": (5760, 8640, XTRANS, 2160, True)}.items():
+                                                 "C5_50MP_xtrans_to_2160": (5760, 8640, XTRANS, 2160, True),
+                                                 "C5b_50MP_xtrans_fullres": (5760, 8640, XTRANS, 0, True)}.items():
         if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
             continue
         img = ipa.RawImage(width=w, height=h, data=frame(h, w, 7, is_float), cfa=cfa, is_float=is_float, blacklevels=[util.BLACK] * 4,
