@@ -248,8 +248,8 @@ typedef struct {
 
 /* src: device pointer to the sensor data (element (0,0) of the uncropped frame, or of the band's
  * first source row); dst: device pointer to width*rows*3 elements of out_type.
- * Fails with IPK_ERR_UNSUPPORTED for CFA patterns that are not one of the four 2x2 Bayer phases
- * (callers then run the staged ops). */
+ * Any colour filter without a fourth colour is accepted (the four RGGB phases, X-Trans, 8x2, 12x12 ...); fails with
+ * IPK_ERR_UNSUPPORTED for RGBE-style filters (callers then run the staged ops). */
 IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
 
 /* OpToLab::run + OpBaseCurve::run + OpFromLab::run + OpGamma::run (src/ops/colorspaces.rs:89-112, src/ops/curves.rs:33-49,
