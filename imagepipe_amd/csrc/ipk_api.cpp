@@ -119,16 +119,17 @@ struct Scratch {                       // RAII: returns its buffers to the pool
 // The kernel-side proof obligations (ipk_device.hpp): range positive and ordinary, the fast quotient equal to the
 // true one on the dividends this source can produce, and (u16 sources, which the kernel does not guard) every
 // nonzero dividend inside [2^-100, 2^100].  Anything else makes the kernel use true divisions.
-// Generic-CFA mode, u16 sources: is every normalised sample (v - black) / range zero or inside [2^-60, 2^60]?
+// u16 sources: is every normalised sample min((v - black) / range, 1.0) "ordinary" (zero or inside [2^-20, 2^20], the
+// device's gen_sample_bad)?  Then the kernels need no sample checks at all.
 bool gen_levels_ok_u16(float black, float range) {
   static thread_local struct { uint32_t b, r; int ok; bool set; } memo = {0, 0, 0, false};
   uint32_t bb, rb; std::memcpy(&bb, &black, 4); std::memcpy(&rb, &range, 4);
   if (memo.set && memo.b == bb && memo.r == rb) return memo.ok != 0;
   bool ok = true;
   for (uint32_t v = 0; v < 65536 && ok; ++v) {
-    const float q = ((float)v - black) / range;
+    const float q = std::fmin(((float)v - black) / range, 1.0f);
     const float a = std::fabs(q);
-    ok = (q == 0.0f) || (a >= 0x1p-60f && a <= 0x1p60f);
+    ok = (q == 0.0f) || (a >= 0x1p-20f && a <= 0x1p20f);
   }
   memo = {bb, rb, ok ? 1 : 0, true};
   return ok;

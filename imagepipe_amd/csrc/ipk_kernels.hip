@@ -588,7 +588,7 @@ struct FusedArgs {
   const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
   const float *gen_cells;     // generic-CFA mode: gen_pw*gen_ph cells of 36 floats (ipk_host.hpp Cfa::gen_cells), else null
   uint32_t gen_pw, gen_ph;    // pattern width / height (both divide 48)
-  int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not bound the normalised samples
+  int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not show that every normalised sample is ordinary
   SplineDev spline;
 };
 
@@ -687,11 +687,14 @@ __device__ __forceinline__ float4 demosaic_gen_literal_px(uint32_t lk, const flo
   }
   return make_float4(n[0] > 0.0f ? s[0] / n[0] : 0.0f, n[1] > 0.0f ? s[1] / n[1] : 0.0f, n[2] > 0.0f ? s[2] / n[2] : 0.0f, 0.0f);
 }
-// A sample the arithmetic form may see: zero, or finite with 2^-60 <= |v| <= 2^60 (sums of nine such stay inside the
-// division's proven zone and their products with 0.0 are +-0.0, never NaN)
+// An "ordinary" normalised sample: zero, or finite with 2^-20 <= |v| <= 2^20 (every real sensor value is: the smallest
+// nonzero (v - black)/range of a 16-bit sensor is about 2^-16).  The generic-CFA demosaic needs its rows made of such
+// samples: sums of nine stay inside the division's proven zone, products with 0.0 are +-0.0, never NaN.
+// (Tried and measured: using the same row check to drop pointwise2_fast's per-pixel guards -- 18 slow-class instructions
+// per pixel pair -- left the u16 kernels unchanged and made the f32 kernels 3.7 % slower; the guards stay.)
 __device__ __forceinline__ bool gen_sample_bad(float v) {
   const float a = __builtin_fabsf(v);
-  return !(a <= 0x1p60f) || (a < 0x1p-60f && v != 0.0f);
+  return !(a <= 0x1p20f) || (a < 0x1p-20f && v != 0.0f);
 }
 
 struct PixOut { float r, g, b; };
@@ -1081,6 +1084,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     #pragma unroll
     for (int j = 0; j < 4; ++j) cxo[j] = ((col0 + j) % a.gen_pw) * kGenCellFloats;
   }
+  // generic-CFA mode checks its rows for ordinary samples (gen_sample_bad); u16 sources skip the check when the host did it
+  // for all 65 536 values
   const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
   // rows: this segment's output rows [r0, r1)
   const uint32_t nrows = a.out_r1 - a.out_r0;
@@ -1130,8 +1135,10 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       return w;
     }
     bool redo = exact_norm;
-    if (GUARD_NORM) redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
-                                                                cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
+    // a dividend outside cdiv_fast's zone either clips to 1.0 (huge positive: exact in both forms) or gives a sample the row
+    // check below rejects, which then redoes the row with true divisions -- so the row check replaces this one when it runs
+    if (GUARD_NORM && !gen_guard) redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
+                                                                              cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
     if (!redo) {
       w.v0 = rs_min(cdiv_fast(d0, range0, inv_range0), 1.0f); w.v1 = rs_min(cdiv_fast(d1, range0, inv_range0), 1.0f);
       w.v2 = rs_min(cdiv_fast(d2, range0, inv_range0), 1.0f); w.v3 = rs_min(cdiv_fast(d3, range0, inv_range0), 1.0f);
@@ -1142,8 +1149,15 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       h = rs_min(dh / range0, 1.0f);
       if (single) h2 = rs_min(dh2 / range0, 1.0f);
     }
-    if (gen_guard) flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(w.v0) | gen_sample_bad(w.v1) | gen_sample_bad(w.v2) | gen_sample_bad(w.v3) |
-                                                      gen_sample_bad(h) | gen_sample_bad(h2)) != 0;
+    if (gen_guard) {
+      flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(w.v0) | gen_sample_bad(w.v1) | gen_sample_bad(w.v2) | gen_sample_bad(w.v3) |
+                                         gen_sample_bad(h) | gen_sample_bad(h2)) != 0;
+      if (flag && !redo) {                               // rare: the row's samples again, literally
+        w.v0 = rs_min(d0 / range0, 1.0f); w.v1 = rs_min(d1 / range0, 1.0f); w.v2 = rs_min(d2 / range0, 1.0f); w.v3 = rs_min(d3 / range0, 1.0f);
+        h = rs_min(dh / range0, 1.0f);
+        if (single) h2 = rs_min(dh2 / range0, 1.0f);
+      }
+    }
     w.l = dpp_wave_shr1(h, w.v3);                        // lane 0 keeps its halo (left column)
     const float rr = dpp_wave_shl1(h, w.v0);             // lane 63 keeps its halo
     w.r = is_last ? (single ? h2 : h) : rr;
@@ -1163,10 +1177,15 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
   // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
   (void)zero_raw;
-  RawRowT raw_next = issue_row(min(r0 + 1, Hm1));
+  // Software pipeline: while row r is computed its window (P, C, N = rows r-1, r, r+1) is already in registers; row r+2
+  // is *finished* (the wait for its loads) after the arithmetic of row r and BEFORE that row's stores are issued, and row
+  // r+3 is *issued* after them.  gfx9 counts loads and stores in one vmcnt and the compiler must assume they complete
+  // out of order, so a wait for loads with younger stores in flight becomes vmcnt(0) and exposes the full store latency
+  // every iteration (it was 24 % of the wave's time); here the only stores older than the awaited loads are a whole
+  // iteration old.
+  N = finish_row(issue_row(min(r0 + 1, Hm1)), fN);
+  RawRowT raw_next = issue_row(min(r0 + 2, Hm1));
   for (uint32_t r = r0; r < r1; ++r) {
-    N = finish_row(raw_next, fN);                        // row r+1 (a copy of row H-1 past the frame: masked as an edge)
-    raw_next = issue_row(min(r + 2, Hm1));
     const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
     const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
     const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
@@ -1178,7 +1197,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     if (GEN) {
       // any filter without a fourth colour: masked sums + proven division, or the literal form for a row window that
       // holds a sample outside the proven zone
-      const bool literal = fP | fC | fN;
+      const bool literal = gen_guard && (fP | fC | fN);
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
@@ -1230,6 +1249,9 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       }
     }
     if (DEMO) {
+      bool fNN;
+      const RowWin NN = finish_row(raw_next, fNN);       // row r+2 (clamped past the frame: those rows are masked as edges)
+      __builtin_amdgcn_sched_barrier(0);
       if (FULL) {
         uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
         RgbeStage::stage(stg, lane, px);
@@ -1239,7 +1261,9 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       } else if (lane_on) {
         RgbeStage::store_direct(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, px);
       }
-      P = C; C = N; fP = fC; fC = fN;
+      __builtin_amdgcn_sched_barrier(0);
+      raw_next = issue_row(min(r + 3, Hm1));
+      P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
       continue;
     }
@@ -1263,6 +1287,9 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       }
     }
 #endif
+    bool fNN;
+    const RowWin NN = finish_row(raw_next, fNN);         // row r+2: the wait for its loads sits before this row's stores
+    __builtin_amdgcn_sched_barrier(0);
 #if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
     if (OUT == 0 && FULL) {
       float *rowp = reinterpret_cast<float *>(a.dst) + ((size_t)(r - a.out_r0) * a.W + pc0) * 3;
@@ -1288,7 +1315,9 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       if (lane_on) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
     }
 #endif
-    P = C; C = N; fP = fC; fC = fN;
+    __builtin_amdgcn_sched_barrier(0);
+    raw_next = issue_row(min(r + 3, Hm1));
+    P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
     if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
   }
 }
@@ -1343,7 +1372,11 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blo
 #else
   const uint32_t waves_per_block = 16;
 #endif
-  const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256) * (uint32_t)blocks_per_cu;
+  // blocks_per_cu > 1 oversubscribes the CUs with shorter tasks: only one 1024-thread block is resident per CU, the
+  // rest queue and the hardware hands them out as blocks finish -- which evens out frames whose saturated regions (the
+  // out-of-table cbrtf branch) would otherwise make some waves' tasks much longer than others' (diagonal-gradient test
+  // frame: 0.81 -> 0.74 ms at 4; uniform noise: unchanged).  Tasks keep at least 24 rows so the 2 halo rows stay cheap.
+  const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;
   a.n_strips = (w4 + 63) / 64;
@@ -1351,6 +1384,10 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blo
   const uint32_t nrows = a.out_r1 - a.out_r0;
   uint32_t segs = total_waves / a.n_strips;
   if (segs < 1) segs = 1;
+  if (blocks_per_cu > 1) {
+    const uint32_t most = std::max(segs, nrows / 24u);
+    segs = std::min(segs * (uint32_t)blocks_per_cu, most);
+  }
   if (segs > nrows) segs = nrows;
   a.n_segs = segs;
   const uint32_t tasks = a.n_strips * a.n_segs;
@@ -1375,7 +1412,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check;
 
   unsigned blocks;
-  fused_task_grid(a, f.num_cus, blocks, 1);
+  fused_task_grid(a, f.num_cus, blocks, 4);
 
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
   if (!f.src_is_u16) {
