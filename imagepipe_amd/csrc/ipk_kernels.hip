@@ -577,7 +577,7 @@ struct FusedArgs {
   float min0, range0;         // blacklevels[0], whitelevels[0]-blacklevels[0]
   float inv_range0;           // RN(1/range0) for the 4-instruction division
   int exact_norm;             // 1: normalise with true divisions (host could not validate the fast form for range0)
-  int fast_ok;                // 1: parameters are finite and ordinary, pointwise2_fast may run (else literal path only)
+  int fast_ok;                // 1: parameters are finite and ordinary, pointwise4_fast may run (else literal path only)
   int xoff, yoff;             // Bayer phase: color_at(r,c) = RGGB[(r+yoff)&1][(c+xoff)&1]
   ToLabParams tolab;
   Mat9 rgbm;                  // XYZ_D65_33
@@ -690,7 +690,7 @@ __device__ __forceinline__ float4 demosaic_gen_literal_px(uint32_t lk, const flo
 // An "ordinary" normalised sample: zero, or finite with 2^-20 <= |v| <= 2^20 (every real sensor value is: the smallest
 // nonzero (v - black)/range of a 16-bit sensor is about 2^-16).  The generic-CFA demosaic needs its rows made of such
 // samples: sums of nine stay inside the division's proven zone, products with 0.0 are +-0.0, never NaN.
-// (Tried and measured: using the same row check to drop pointwise2_fast's per-pixel guards -- 18 slow-class instructions
+// (Tried and measured: using the same row check to drop pointwise4_fast's per-pixel guards -- 18 slow-class instructions
 // per pixel pair -- left the u16 kernels unchanged and made the f32 kernels 3.7 % slower; the guards stay.)
 __device__ __forceinline__ bool gen_sample_bad(float v) {
   const float a = __builtin_fabsf(v);
@@ -748,7 +748,7 @@ __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
   return cbrtf_glibc_sel(v);
 }
 
-// OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma for TWO pixels of a lane, fast form.  Bit-identical to the literal
+// OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma for the FOUR pixels of a lane, fast form.  Bit-identical to the literal
 // form (pointwise_exact) whenever it returns false; returns true ("bad") for a lane whose inputs leave the zone where
 // that equivalence is proven, and the caller then recomputes the lane's pixels literally.
 //
@@ -768,93 +768,109 @@ __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
 struct FastBad { bool b; };
 // `par` = LDS copy of the uniform parameters (mul[0..3], cm[4..15], rgbm[16..24]): read through the LDS they end up in
 // vector registers instead of competing with the wave's many 64-bit condition masks for scalar registers.
-__device__ __forceinline__ bool pointwise2_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
+// Written for the lane's FOUR pixels (two pairs) stage by stage, so that each table stage issues its 12 LDS reads
+// together and pays their latency once (the wave-uniform branches of the out-of-table patch keep the compiler from
+// interleaving two separate two-pixel evaluations: same speed on most boxes, 22 % faster on one with slow LDS/clock).
+__device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
-                                                const float4 &pa, const float4 &pb, PixOut &oa, PixOut &ob) {
-  bool bad = !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
-  // camera_to_lab (color_conversions.rs:42-55)
-  const f2 r = min2(F2(pa.x, pb.x) * S2(par[0]), 1.0f);
-  const f2 g = min2(F2(pa.y, pb.y) * S2(par[1]), 1.0f);
-  const f2 b = min2(F2(pa.z, pb.z) * S2(par[2]), 1.0f);
-  const f2 x = r * S2(par[4]) + g * S2(par[5]) + b * S2(par[6]);
-  const f2 y = r * S2(par[8]) + g * S2(par[9]) + b * S2(par[10]);
-  const f2 z = r * S2(par[12]) + g * S2(par[13]) + b * S2(par[14]);
-  bad |= cdiv_guard(x.x) | cdiv_guard(x.y) | cdiv_guard(z.x) | cdiv_guard(z.y);
-  // xyz_to_lab (color_conversions.rs:156-169)
-  const f2 xr = cdiv2s(x, rc_hi(kWhiteX), rc_lo(kWhiteX));
-  const f2 zr = cdiv2s(z, rc_hi(kWhiteZ), rc_lo(kWhiteZ));
-  float v[6] = {xr.x, xr.y, y.x, y.y, zr.x, zr.y};
-  float f[6];
+                                                const float4 px[4], PixOut o[4]) {
+  bool bad = false;
+  float v[12], f[12];
+  f2 y[2];
+  #pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
+    bad |= !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
+    const f2 r = min2(F2(pa.x, pb.x) * S2(par[0]), 1.0f);
+    const f2 gc = min2(F2(pa.y, pb.y) * S2(par[1]), 1.0f);
+    const f2 b = min2(F2(pa.z, pb.z) * S2(par[2]), 1.0f);
+    const f2 x = r * S2(par[4]) + gc * S2(par[5]) + b * S2(par[6]);
+    y[g] = r * S2(par[8]) + gc * S2(par[9]) + b * S2(par[10]);
+    const f2 z = r * S2(par[12]) + gc * S2(par[13]) + b * S2(par[14]);
+    bad |= cdiv_guard(x.x) | cdiv_guard(x.y) | cdiv_guard(z.x) | cdiv_guard(z.y);
+    const f2 xr = cdiv2s(x, rc_hi(kWhiteX), rc_lo(kWhiteX));
+    const f2 zr = cdiv2s(z, rc_hi(kWhiteZ), rc_lo(kWhiteZ));
+    v[6 * g] = xr.x; v[6 * g + 1] = xr.y; v[6 * g + 2] = y[g].x; v[6 * g + 3] = y[g].y; v[6 * g + 4] = zr.x; v[6 * g + 5] = zr.y;
+  }
   {
-    const f2 p0 = xr * S2(kLutMaxF), p1 = y * S2(kLutMaxF), p2 = zr * S2(kLutMaxF);
-    const float pos[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-    LutPair e[6]; float w[6];
+    float pos[12]; LutPair e[12];
     #pragma unroll
-    for (int k = 0; k < 6; ++k) { e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k])); w[k] = __builtin_amdgcn_fractf(pos[k]); }
+    for (int k = 0; k < 12; ++k) pos[k] = v[k] * kLutMaxF;
     #pragma unroll
-    for (int k = 0; k < 6; k += 2) {
-      const f2 t = F2(e[k].x, e[k + 1].x) + F2(w[k], w[k + 1]) * F2(e[k].y, e[k + 1].y);
-      f[k] = t.x; f[k + 1] = t.y;
-    }
+    for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k]));
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) f[k] = e[k].x + __builtin_amdgcn_fractf(pos[k]) * e[k].y;
   }
 #if IPK_ABLATE < 1
   #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 12; ++k) {
     const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
     if (__builtin_amdgcn_ballot_w64(oor) != 0) {
-      const bool hi = v[k] > 1.0f, lo = oor && !hi;                     // lo: negative (or -0 / NaN: the linear form gives the table's answer / NaN)
+      const bool hi = v[k] > 1.0f, lo = oor && !hi;
       if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
       if (__builtin_amdgcn_ballot_w64(lo) != 0) { const float t = (kLabK * v[k] + 16.0f) / 116.0f; f[k] = lo ? t : f[k]; }
     }
   }
 #endif
-  const f2 fx = F2(f[0], f[1]), fy = F2(f[2], f[3]), fz = F2(f[4], f[5]);
-  const f2 l = S2(116.0f) * fy - S2(16.0f);
-  const f2 a0 = S2(500.0f) * (fx - fy);
-  const f2 b0 = S2(200.0f) * (fy - fz);
-  f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
-  const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-  const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-  // OpBaseCurve (curves.rs:44-48)
-  if (a.has_curve && IPK_ABLATE < 3) L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
-  // lab_to_xyz (color_conversions.rs:172-191)
-  const f2 cl = L * S2(100.0f);
-  const f2 ca = (A * S2(255.0f)) - S2(127.0f);
-  const f2 cb = (B * S2(255.0f)) - S2(127.0f);
-  const f2 gy = cdiv2s(cl + S2(16.0f), rc_hi(116.0f), rc_lo(116.0f));
-  const f2 gx = cdiv2s(ca, rc_hi(500.0f), rc_lo(500.0f)) + gy;
-  const f2 gz = gy - cdiv2s(cb, rc_hi(200.0f), rc_lo(200.0f));
-  const f2 gx3 = gx * gx * gx, gy3 = gy * gy * gy, gz3 = gz * gz * gz;
-  const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
-  const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
-  // cl / k keeps the fix-up: a curve may hand over L = -0.0
-  const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
-  const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
-  const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
-  if (a.has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
-  const f2 xq = F2(gx3.x > kLabE ? gx3.x : lx.x, gx3.y > kLabE ? gx3.y : lx.y);
-  const f2 yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
-  const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
-  const f2 X = xq * S2(kWhiteX), Y = yq /* * 1.0 */, Z = zq * S2(kWhiteZ);
-  // lab_to_rgb (color_conversions.rs:61-63)
-  f2 rr = X * S2(par[16]) + Y * S2(par[17]) + Z * S2(par[18]);
-  f2 gg = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);
-  f2 bb = X * S2(par[22]) + Y * S2(par[23]) + Z * S2(par[24]);
-  // OpGamma (gamma.rs:17-23)
-  if (!a.linear && IPK_ABLATE < 2) {
-    const float c[6] = {__builtin_amdgcn_fmed3f(rr.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(rr.y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gg.x, 0.0f, 1.0f),
-                        __builtin_amdgcn_fmed3f(gg.y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb.y, 0.0f, 1.0f)};
-    const f2 q0 = F2(c[0], c[1]) * S2(kLutMaxF), q1 = F2(c[2], c[3]) * S2(kLutMaxF), q2 = F2(c[4], c[5]) * S2(kLutMaxF);
-    const float pos[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
-    float v1[6], v2[6], w[6];
-    #pragma unroll
-    for (int k = 0; k < 6; ++k) { const uint32_t key = f32_as_u32_sat(pos[k]); v1[k] = s_gam[key]; v2[k] = s_gam[key + 1]; w[k] = __builtin_amdgcn_fractf(pos[k]); }
-    rr = F2(v1[0], v1[1]) + F2(w[0], w[1]) * (F2(v2[0], v2[1]) - F2(v1[0], v1[1]));
-    gg = F2(v1[2], v1[3]) + F2(w[2], w[3]) * (F2(v2[2], v2[3]) - F2(v1[2], v1[3]));
-    bb = F2(v1[4], v1[5]) + F2(w[4], w[5]) * (F2(v2[4], v2[5]) - F2(v1[4], v1[5]));
+  f2 rr[2], gg[2], bb[2];
+  #pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
+    const f2 l = S2(116.0f) * fy - S2(16.0f);
+    const f2 a0 = S2(500.0f) * (fx - fy);
+    const f2 b0 = S2(200.0f) * (fy - fz);
+    f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
+    const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+    const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+    if (a.has_curve && IPK_ABLATE < 3) L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
+    const f2 cl = L * S2(100.0f);
+    const f2 ca = (A * S2(255.0f)) - S2(127.0f);
+    const f2 cb = (B * S2(255.0f)) - S2(127.0f);
+    const f2 gy = cdiv2s(cl + S2(16.0f), rc_hi(116.0f), rc_lo(116.0f));
+    const f2 gx = cdiv2s(ca, rc_hi(500.0f), rc_lo(500.0f)) + gy;
+    const f2 gz = gy - cdiv2s(cb, rc_hi(200.0f), rc_lo(200.0f));
+    const f2 gx3 = gx * gx * gx, gy3 = gy * gy * gy, gz3 = gz * gz * gz;
+    const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
+    const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
+    const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
+    const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
+    const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
+    if (a.has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
+    const f2 xq = F2(gx3.x > kLabE ? gx3.x : lx.x, gx3.y > kLabE ? gx3.y : lx.y);
+    const f2 yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
+    const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
+    const f2 X = xq * S2(kWhiteX), Y = yq, Z = zq * S2(kWhiteZ);
+    rr[g] = X * S2(par[16]) + Y * S2(par[17]) + Z * S2(par[18]);
+    gg[g] = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);
+    bb[g] = X * S2(par[22]) + Y * S2(par[23]) + Z * S2(par[24]);
   }
-  oa.r = rr.x; oa.g = gg.x; oa.b = bb.x;
-  ob.r = rr.y; ob.g = gg.y; ob.b = bb.y;
+  if (!a.linear && IPK_ABLATE < 2) {
+    float pos[12], v1[12], v2[12];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float c[6] = {__builtin_amdgcn_fmed3f(rr[g].x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(rr[g].y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gg[g].x, 0.0f, 1.0f),
+                          __builtin_amdgcn_fmed3f(gg[g].y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb[g].x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb[g].y, 0.0f, 1.0f)};
+      #pragma unroll
+      for (int k = 0; k < 6; ++k) pos[6 * g + k] = c[k] * kLutMaxF;
+    }
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) { const uint32_t key = f32_as_u32_sat(pos[k]); v1[k] = s_gam[key]; v2[k] = s_gam[key + 1]; }
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float w[6];
+      #pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_fractf(pos[6 * g + k]);
+      const float *p1 = v1 + 6 * g, *p2 = v2 + 6 * g;
+      rr[g] = F2(p1[0], p1[1]) + F2(w[0], w[1]) * (F2(p2[0], p2[1]) - F2(p1[0], p1[1]));
+      gg[g] = F2(p1[2], p1[3]) + F2(w[2], w[3]) * (F2(p2[2], p2[3]) - F2(p1[2], p1[3]));
+      bb[g] = F2(p1[4], p1[5]) + F2(w[4], w[5]) * (F2(p2[4], p2[5]) - F2(p1[4], p1[5]));
+    }
+  }
+  #pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    o[2 * g].r = rr[g].x; o[2 * g].g = gg[g].x; o[2 * g].b = bb[g].x;
+    o[2 * g + 1].r = rr[g].y; o[2 * g + 1].g = gg[g].y; o[2 * g + 1].b = bb[g].y;
+  }
   return bad;
 }
 
@@ -1275,10 +1291,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
     bool bad = a.fast_ok == 0;
-    if (a.fast_ok) {
-      bad = pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[0], px[1], o[0], o[1]);
-      bad |= pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[2], px[3], o[2], o[3]);
-    }
+    if (a.fast_ok) bad = pointwise4_fast(a, s_par, s_lab, s_gam, s_knots, px, o);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1435,7 +1448,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // OpToLab + OpBaseCurve + OpFromLab + OpGamma in one pass over a 4-channel OpBuffer (the ops between demosaic /
 // rotatecrop and transform): 16 bytes in, 12 out per pixel, HBM-bound.  Same per-pixel code as the fused raw kernel
-// (pointwise2_fast, literal redo behind a wave-uniform branch).  A wave takes 256 consecutive pixels per step; lane L
+// (pointwise4_fast, literal redo behind a wave-uniform branch).  A wave takes 256 consecutive pixels per step; lane L
 // owns pixels L, 64+L, 128+L, 192+L of the chunk, so every load (16 B per lane) and store (12 B per lane) is contiguous
 // across the wave and nothing needs staging.
 // ------------------------------------------------------------------------------------------
@@ -1473,8 +1486,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
     bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
     if (a.fast_ok) {
-      bad |= pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[0], px[1], o[0], o[1]);
-      bad |= pointwise2_fast(a, s_par, s_lab, s_gam, s_knots, px[2], px[3], o[2], o[3]);
+      bad |= pointwise4_fast(a, s_par, s_lab, s_gam, s_knots, px, o);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
