@@ -29,6 +29,12 @@ static inline dim3 grid_rows(size_t width, size_t height, int bx, int cols_per_t
   size_t gy = height < 65535 ? height : 65535;
   return dim3((unsigned)gx, (unsigned)gy, 1);
 }
+// row-looping kernels that set up a per-block LDS table: a bounded number of blocks, each walking many rows
+static inline dim3 grid_rows_few(size_t width, size_t height, int bx, unsigned total_blocks) {
+  const size_t gx = (width + size_t(bx) - 1) / size_t(bx);
+  size_t gy = total_blocks / gx; if (gy < 1) gy = 1; if (gy > height) gy = height; if (gy > 65535) gy = 65535;
+  return dim3((unsigned)gx, (unsigned)gy, 1);
+}
 static inline unsigned grid_1d(size_t n, int bx, unsigned cap) {
   size_t g = (n + bx - 1) / bx;
   if (g < 1) g = 1;
@@ -229,6 +235,7 @@ struct TransformArgs {
   int has_cfa;
   // optional fused OpGoFloat (CFA branch, gofloat.rs:122-130/158-166): the source is the raw sensor frame
   int norm; float min0, range0; uint64_t src_pitch, src_x, src_y;
+  int norm_fast; float inv_range0;    // fused OpGoFloat: the host validated cdiv_fast for range0 (else IEEE division)
 };
 // (v - center) / skip  (scaling.rs:104-105): cdiv_fast when the host validated the divisor and the dividend is in the proven
 // zone, the IEEE division otherwise (zero or negative skips of degenerate / rotated transforms, absurd centres)
@@ -339,8 +346,8 @@ void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t 
   a.inv_skip_x_x = 1.0f / a.skip_x_x; a.inv_skip_y_y = 1.0f / a.skip_y_y;
   a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
   a.has_cfa = cfa48_dev != nullptr;
-  a.norm = 0; a.min0 = 0.0f; a.range0 = 1.0f; a.src_pitch = width; a.src_x = 0; a.src_y = 0;
-  hipLaunchKernelGGL(k_transform_buffer<T>, grid_rows(nwidth, nheight, 128), dim3(128), 0, s, src, a, cfa48_dev, dst);
+  a.norm = 0; a.min0 = 0.0f; a.range0 = 1.0f; a.src_pitch = width; a.src_x = 0; a.src_y = 0; a.norm_fast = 0; a.inv_range0 = 1.0f;
+  hipLaunchKernelGGL(k_transform_buffer<T>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst);
 }
 
 // OpGoFloat (CFA branch) + scaling::scaled_demosaic in one pass over the raw sensor frame: dst4 = scaled_demosaic(gofloat(src)).
@@ -395,9 +402,119 @@ __global__ void k_raw_scaled_demosaic(const T *__restrict__ src, TransformArgs a
     reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
   }
 }
+// The same for windows of at most 8 x 8 source samples (every scale up to 7, i.e. all previews larger than 1/7 size).
+// One lane per output pixel as before, but a source row of the window arrives as ONE 8-sample vector load per lane
+// (element-aligned dwordx4 pairs / one dwordx4 for u16) instead of one dependent 4-byte load per tap -- the per-tap loads
+// at a 16-byte lane stride were what held the kernel (21 L1 accesses per load instruction) -- the column part of the weight
+// (1 - dx*dx; scaling.rs:104-106 evaluates (1 - dx*dx) - dy*dy) is computed once per pixel, the colours of the 8 columns come
+// from one 16-bit LDS read per row, and the colour bins are filled by selects (a non-matching bin adds +0.0, which cannot
+// change a sum that started at +0.0).  Same taps, same order (y outer, x inner), same arithmetic per tap.
+template <typename T> struct Row8;
+struct __attribute__((packed, aligned(4))) Row8F4 { float x, y, z, w; };
+template <> struct Row8<float> {
+  static __device__ __forceinline__ void load(const float *p, float d[8]) {
+    const Row8F4 lo = *reinterpret_cast<const Row8F4 *>(p), hi = *reinterpret_cast<const Row8F4 *>(p + 4);
+    d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+  }
+};
+struct __attribute__((packed, aligned(2))) us8u { uint16_t v[8]; };
+template <> struct Row8<uint16_t> {
+  static __device__ __forceinline__ void load(const uint16_t *p, float d[8]) {
+    const us8u t = *reinterpret_cast<const us8u *>(p);
+    #pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = (float)t.v[k];
+  }
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
+                                                               float *__restrict__ dst) {
+  // colours of the 8 columns starting at (y % 48, x % 48), 2 bits each: built once per block, 9 entries per thread, so a
+  // block keeps working on rows (gridDim.y is a few blocks per CU, not one per row)
+  __shared__ uint16_t s_bits[48 * 48];
+  for (int i = threadIdx.x; i < 48 * 48; i += blockDim.x) {
+    const int y = i / 48, x = i % 48;
+    uint32_t bits = 0;
+    #pragma unroll
+    for (int k = 0; k < 8; ++k) { const int xx = x + k; bits |= (uint32_t)(cfa48[y * 48 + (xx >= 48 ? xx - 48 : xx)] & 3u) << (2 * k); }
+    s_bits[i] = (uint16_t)bits;
+  }
+  __syncthreads();
+  const uint32_t col_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool lane_in = col_raw < a.nwidth;
+  const uint32_t col = min(col_raw, a.nwidth - 1);       // lanes past the row shadow its last pixel: every lane stays active
+  // column window (scaling.rs:84-89 with skip_x_y = skip_y_x = 0, tlx = tly = 0 as scale_down_buffer sets them); the host
+  // launches this kernel only when no window is wider or taller than 8
+  const uint32_t from_x = min(a.width - 1, f32_as_u32_sat(floorf(a.tlx + (a.skip_x_x * (float)col))));
+  const uint32_t to_x = min(a.width - 1, f32_as_u32_sat(floorf(a.tlx + (a.skip_x_x * (float)(col + 1)))));
+  const float center_x = a.tlx + (a.skip_y_x / 2.0f) - 0.5f + (a.skip_x_x * (float)col) + (a.skip_x_x / 2.0f);
+  const uint32_t nx = to_x - from_x + 1;
+  // the 8-sample load must stay inside the source row; the few pixels whose window touches the last columns start it
+  // earlier and shift their taps (kshift)
+  const uint32_t lx = min(from_x, a.width - 8);
+  const uint32_t kshift = from_x - lx;
+  float ax[8];                                           // 1 - dx*dx of sample lx + k (meaningful for kshift <= k < kshift + nx)
+  #pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const float delta_x = tb_div((float)(lx + k) - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
+    ax[k] = 1.0f - (delta_x * delta_x);
+  }
+  const uint32_t xm0 = lx % 48;
+  uint32_t kend = 0;                                     // one past the last sample index any lane of the wave uses
+  #pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) if (__builtin_amdgcn_ballot_w64(kshift + nx > k) != 0) kend = k + 1;
+  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+    const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)row)));
+    const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)(row + 1))));
+    const float center_y = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    for (uint32_t y = from_y; y <= to_y; ++y) {         // wave-uniform bounds
+      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
+      const float dy2 = delta_y * delta_y;
+      float d[8];
+      Row8<T>::load(src + (size_t)(y + a.src_y) * a.src_pitch + a.src_x + lx, d);
+      const uint32_t bits = s_bits[(y % 48) * 48 + xm0];
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = d[k] - a.min0;
+      bool fastdiv = a.norm_fast != 0;
+      if (sizeof(T) == 4 && fastdiv) {
+        bool g = false;
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) g |= cdiv_guard(d[k]);
+        fastdiv = __builtin_amdgcn_ballot_w64(g) == 0;
+      }
+      float q[8];                                         // gofloat.rs:126; one uniform branch, not a select per tap
+      if (fastdiv) {
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = cdiv_fast(d[k], a.range0, a.inv_range0);
+      } else {
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = d[k] / a.range0;
+      }
+      #pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        if (k < kend) {                                   // wave-uniform
+          const bool in = (k - kshift) < nx;              // unsigned: kshift <= k < kshift + nx
+          float factor = ax[k] - dy2;                     // scaling.rs:106
+          factor = (factor < 0.0f) ? 0.0f : factor;
+          factor = in ? factor : 0.0f;
+          float t = rs_min(q[k], 1.0f) * factor;
+          t = in ? t : 0.0f;                              // a sample outside the window contributes nothing, whatever it holds
+          const uint32_t c = (bits >> (2 * k)) & 3u;
+          s0 += (c == 0) ? t : 0.0f; n0 += (c == 0) ? factor : 0.0f;
+          s1 += (c == 1) ? t : 0.0f; n1 += (c == 1) ? factor : 0.0f;
+          s2 += (c == 2) ? t : 0.0f; n2 += (c == 2) ? factor : 0.0f;
+          if (a.components > 3) { s3 += (c == 3) ? t : 0.0f; n3 += (c == 3) ? factor : 0.0f; }
+        }
+      }
+    }
+    float4 o;
+    o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
+    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
+  }
+}
 template <typename T>
 void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0,
-                                size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, float *dst4, hipStream_t s) {
+                                int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, float *dst4, hipStream_t s) {
   TransformArgs a;
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
@@ -408,10 +525,21 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   a.inv_skip_x_x = 1.0f / a.skip_x_x; a.inv_skip_y_y = 1.0f / a.skip_y_y;
   a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
   a.has_cfa = 1; a.norm = 1; a.min0 = black0; a.range0 = white0 - black0; a.src_pitch = owidth; a.src_x = x; a.src_y = y;
-  hipLaunchKernelGGL(k_raw_scaled_demosaic<T>, grid_rows(nwidth, nheight, 128), dim3(128), 0, s, src, a, cfa48_dev, dst4);
+  a.norm_fast = norm_fast; a.inv_range0 = 1.0f / a.range0;
+  a.components = has_fourth_colour ? 4 : 3;               // the w8 kernel skips the fourth bin for three-colour filters (it stays 0.0)
+  // windows of at most 8 x 8 samples: floor(skip*(c+1)) - floor(skip*c) + 1 <= ceil(skip) + 1
+  if (a.skip_x_x >= 1.0f && a.skip_x_x <= 7.0f && a.skip_y_y >= 1.0f && a.skip_y_y <= 7.0f && width >= 8 &&
+      (reinterpret_cast<uintptr_t>(dst4) & 15) == 0) {
+    const unsigned gx = (unsigned)((nwidth + 255) / 256);
+    const unsigned want = std::max(1u, 4096u / gx);                          // ~16 blocks of 256 threads per CU in total
+    const dim3 grid(gx, (unsigned)std::min<size_t>(nheight, want), 1);
+    hipLaunchKernelGGL(k_raw_scaled_demosaic_w8<T>, grid, dim3(256), 0, s, src, a, cfa48_dev, dst4);
+    return;
+  }
+  hipLaunchKernelGGL(k_raw_scaled_demosaic<T>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst4);
 }
-template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, size_t, size_t, const uint8_t *, float *, hipStream_t);
-template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, size_t, size_t, const uint8_t *, float *, hipStream_t);
+template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, float *, hipStream_t);
+template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, float *, hipStream_t);
 template void launch_transform_buffer<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, float *, hipStream_t);
 template void launch_transform_buffer<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint8_t *, hipStream_t);
 template void launch_transform_buffer<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint16_t *, hipStream_t);
