@@ -183,6 +183,37 @@ def test_scaled_demosaic_vs_oracle(ipa, orc, cfa, shape, nshape):
     assert_bits_equal(got, orc.scaled_demosaic(cfa, buf, nw, nh), "scaled_demosaic")
 
 
+XT36 = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+
+
+@pytest.mark.parametrize("case", [
+    # (h, w, nh, nw, cfa, crop x, crop y): window-8 kernel (scale <= 7) incl. non-integer scales, the last-column shift, odd source
+    # offsets, a four-colour filter; and scales above 7 / sources under 8 columns (general kernel)
+    (96, 144, 24, 36, XT36, 0, 0), (97, 151, 31, 47, XT36, 3, 1), (60, 300, 13, 131, "RGGB", 1, 0), (120, 90, 18, 13, "GBRG", 0, 2),
+    (64, 64, 9, 10, "RGBE", 0, 0), (33, 1000, 11, 333, XT36, 5, 0), (200, 200, 28, 29, "BGGR", 0, 0), (80, 96, 10, 12, "RGGB", 0, 0),
+    (30, 7, 10, 3, "RGGB", 0, 0), (12, 9, 12, 9, XT36, 0, 0)])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_raw_scaled_demosaic_vs_oracle(ipa, orc, case, is_float):
+    """ipk_raw_scaled_demosaic = scaled_demosaic(gofloat(raw)) in one pass (gofloat.rs:122-130 + scaling.rs:132-145), every window shape"""
+    import ctypes as C
+    import torch
+    h, w, nh, nw, cfa, cx, cy = case
+    oh, ow = h + cy + 2, w + cx + 3
+    raw = util.noise_u16(util.SEED + 90 + h * w, oh, ow)
+    src = raw.astype(np.float32) if is_float else raw
+    if is_float:
+        src = src + util.uniform_f32(util.SEED + 91, oh * ow).reshape(oh, ow)
+        sp = util.SPECIALS * np.float32(16383.0)
+        src[cy + 2, cx: cx + min(w, sp.size)] = sp[: min(w, sp.size)]                      # NaN / inf / denormals inside the frame
+    dev = torch.from_numpy(np.ascontiguousarray(src).ravel()).cuda() if is_float else ipa.upload_u16(src)
+    dst = torch.full((nh * nw * 4,), -5.0, dtype=torch.float32, device="cuda")
+    rc = ipa.lib().ipk_raw_scaled_demosaic(dev.data_ptr(), 1 if is_float else 0, ow, cx, cy, w, h, util.BLACK, util.WHITE, cfa.encode(), nw, nh,
+                                           dst.data_ptr(), None)
+    assert rc == 0, ipa.lib().ipk_last_error()
+    want = orc.scaled_demosaic(cfa, orc.gofloat_cfa(src, cx, cy, w, h, util.BLACK, util.WHITE), nw, nh)
+    assert_bits_equal(dst.cpu().numpy().reshape(nh, nw, 4), want, "raw scaled demosaic %r" % (case,))
+
+
 def test_scaled_demosaic_constant_planes(ipa):
     """Hand-derived: a mosaic that is constant per colour scales to those constants (up to the rounding of the
     weighted mean); a window that holds no sample of a colour leaves 0.0 (scaling.rs:122-126) -- here the last
