@@ -317,20 +317,21 @@ def _tile_frame(tile, reps_y, reps_x):
     return np.tile(tile, (reps_y, reps_x))
 
 
-@pytest.mark.parametrize("H,W", [(4000, 6000), (10000, 10000)])
-def test_full_size_frame_is_periodic_like_its_input(ipa, orc, H, W):
-    """A frame built by tiling an even-sized tile is periodic, so the output interior must repeat the oracle's
-    output of a 3x3 tiling of that tile (every interior pixel sees the same 3x3 neighbourhood), at 24 MP and 100 MP."""
+@pytest.mark.parametrize("H,W,cfa,th,tw", [(4000, 6000, "RGGB", 50, 40), (10000, 10000, "RGGB", 50, 40),
+                                          (5760, 8640, "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 60, 48)])
+def test_full_size_frame_is_periodic_like_its_input(ipa, orc, H, W, cfa, th, tw):
+    """A frame built by tiling a tile whose sides are multiples of the CFA period is periodic, so the output interior must
+    repeat the oracle's output of a 3x3 tiling of that tile (every interior pixel sees the same 3x3 neighbourhood): the
+    BASELINE.json frame sizes, 24 MP and 100 MP Bayer and the 50 MP X-Trans frame (generic-CFA mode)."""
     import torch
-    th, tw = 50, 40
     tile = util.noise_u16(util.SEED + 38, th, tw)
     frame = _tile_frame(tile, H // th, W // tw)
     assert frame.shape == (H, W)
-    pipe = ipa.Pipeline.new_from_source(_raw(ipa, frame))
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, frame, cfa))
     out = pipe.run()
     assert pipe.last_used_fused
     got = out.data.view(H, W, 3)
-    small = orc.pipeline_run(_oracle_desc(orc, _tile_frame(tile, 3, 3)))
+    small = orc.pipeline_run(_oracle_desc(orc, _tile_frame(tile, 3, 3), cfa))
     centre = torch.from_numpy(small[th:2 * th, tw:2 * tw].copy()).cuda()
     # interior tiles: compare a spread of them bit-for-bit on the device
     ys = sorted(set([1, 2, H // th // 2, H // th - 2]))
@@ -344,7 +345,7 @@ def test_full_size_frame_is_periodic_like_its_input(ipa, orc, H, W):
     ref = inner[0:1, :, 0:1]
     assert bool((inner.view(torch.int32) == ref.view(torch.int32)).all())
     # frame edges: the first/last tile rows and columns against the oracle's 3x3 result edges
-    edge = orc.pipeline_run(_oracle_desc(orc, _tile_frame(tile, 3, 3)))
+    edge = small
     assert torch.equal(got[:th, :tw].view(torch.int32), torch.from_numpy(edge[:th, :tw].copy()).cuda().view(torch.int32))
     assert torch.equal(got[H - th:, W - tw:].view(torch.int32), torch.from_numpy(edge[2 * th:, 2 * tw:].copy()).cuda().view(torch.int32))
     assert torch.equal(got[:th, W - tw:].view(torch.int32), torch.from_numpy(edge[:th, 2 * tw:].copy()).cuda().view(torch.int32))
