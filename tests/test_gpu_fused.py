@@ -317,6 +317,38 @@ def _tile_frame(tile, reps_y, reps_x):
     return np.tile(tile, (reps_y, reps_x))
 
 
+@pytest.mark.parametrize("H,W,is_float", [(4000, 6000, False), (4000, 6000, True), (10000, 10000, True)])
+def test_config2_config3_full_size_vs_oracle(ipa, orc, H, W, is_float):
+    """BASELINE.json configs[1] (24 MP, u16 and f32 mosaic) and configs[2] (100 MP f32, the bench workload) at their real sizes:
+    every output sample of the fused kernel against the oracle's unfused pipeline (the oracle takes a few seconds per frame)"""
+    import torch
+    raw = util.noise_u16(util.SEED + 40 + H, H, W)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "RGGB", is_float=is_float))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    want = torch.from_numpy(orc.pipeline_run(_oracle_desc(orc, src, "RGGB")).reshape(-1))
+    same = torch.equal(got.data.cpu().view(torch.int32), want.view(torch.int32))
+    if not same:                                             # NaN payloads aside, report where
+        assert_bits_equal(got.numpy(), want.numpy().reshape(H, W, 3), "full-size frame")
+
+
+def test_config5_full_size_vs_oracle(ipa, orc):
+    """BASELINE.json configs[4] at its real size: 8640x5760 X-Trans mosaic, maxwidth 2160 -> 2160x1440 through the one-pass
+    gofloat+scaled-demosaic kernel and the point-wise chain; the whole output against the oracle (the oracle needs a few seconds)"""
+    H, W = 5760, 8640
+    xt = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+    raw = util.noise_u16(util.SEED + 39, H, W)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, xt))
+    pipe.globals.settings.maxwidth = 2160
+    got = pipe.run()
+    assert (got.width, got.height) == (2160, 1440) and not pipe.last_used_fused
+    want = orc.pipeline_run(_oracle_desc(orc, raw, xt, maxwidth=2160))
+    assert_bits_equal(got.numpy(), want, "config 5 full size")
+    w, h, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(h, w, 3), orc.pipeline_output_8bit(_oracle_desc(orc, raw, xt, maxwidth=2160)))
+
+
 @pytest.mark.parametrize("H,W,cfa,th,tw", [(4000, 6000, "RGGB", 50, 40), (10000, 10000, "RGGB", 50, 40),
                                           (5760, 8640, "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 60, 48)])
 def test_full_size_frame_is_periodic_like_its_input(ipa, orc, H, W, cfa, th, tw):
