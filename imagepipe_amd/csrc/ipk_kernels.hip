@@ -717,6 +717,7 @@ struct FusedArgs {
   const float *gen_cells;     // generic-CFA mode: gen_pw*gen_ph cells of 36 floats (ipk_host.hpp Cfa::gen_cells), else null
   uint32_t gen_pw, gen_ph;    // pattern width / height (both divide 48)
   int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not show that every normalised sample is ordinary
+  int px_guard;               // 0: u16 source with host-checked levels and parameters -> the variant without per-pixel input guards
   SplineDev spline;
 };
 
@@ -899,6 +900,15 @@ struct FastBad { bool b; };
 // Written for the lane's FOUR pixels (two pairs) stage by stage, so that each table stage issues its 12 LDS reads
 // together and pays their latency once (the wave-uniform branches of the out-of-table patch keep the compiler from
 // interleaving two separate two-pixel evaluations: same speed on most boxes, 22 % faster on one with slow LDS/clock).
+//
+// PXG = false drops the two input guards (the channel sanity check and the exponent guards on x and z; 18 slow-class
+// instructions per pixel pair, 4.6 % of the u16 kernel).  Legal when the caller knows every sample is "ordinary"
+// (gen_sample_bad: zero, or 2^-20 <= |v| <= 2^20) and the host checked the multipliers are in [2^-10, 2^10] and the nonzero
+// matrix entries in [2^-20, 2^20]: the samples are then multiples of 2^-43, demosaic averages of 2^-45 (2^-46/9 in
+// generic-CFA mode), white-balanced channels at least 2^-57, their matrix products at least 2^-77 and hence multiples of
+// 2^-100, so a nonzero x or z has 2^-100 <= |.| <= 2^42 -- inside the proven zone of the constant divisions; nothing is
+// below -2^20 or non-finite.  The launcher selects it for u16 sources whose 65 536 normalised values the host has checked.
+template <bool PXG>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
                                                 const float4 px[4], PixOut o[4]) {
@@ -908,14 +918,14 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
-    bad |= !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
+    if (PXG) bad |= !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
     const f2 r = min2(F2(pa.x, pb.x) * S2(par[0]), 1.0f);
     const f2 gc = min2(F2(pa.y, pb.y) * S2(par[1]), 1.0f);
     const f2 b = min2(F2(pa.z, pb.z) * S2(par[2]), 1.0f);
     const f2 x = r * S2(par[4]) + gc * S2(par[5]) + b * S2(par[6]);
     y[g] = r * S2(par[8]) + gc * S2(par[9]) + b * S2(par[10]);
     const f2 z = r * S2(par[12]) + gc * S2(par[13]) + b * S2(par[14]);
-    bad |= cdiv_guard(x.x) | cdiv_guard(x.y) | cdiv_guard(z.x) | cdiv_guard(z.y);
+    if (PXG) bad |= cdiv_guard(x.x) | cdiv_guard(x.y) | cdiv_guard(z.x) | cdiv_guard(z.y);
     const f2 xr = cdiv2s(x, rc_hi(kWhiteX), rc_lo(kWhiteX));
     const f2 zr = cdiv2s(z, rc_hi(kWhiteZ), rc_lo(kWhiteZ));
     v[6 * g] = xr.x; v[6 * g + 1] = xr.y; v[6 * g + 2] = y[g].x; v[6 * g + 3] = y[g].y; v[6 * g + 4] = zr.x; v[6 * g + 5] = zr.y;
@@ -1176,7 +1186,7 @@ struct RgbeStage {
 // Occupancy: one 1024-thread block per CU = 4 waves per SIMD, on purpose.  Measured (tools/ubench2.hip, and this kernel's
 // u16->u8 variant, which fits two blocks in LDS): at 8 waves per SIMD the simple f32 ops lose their 2-cycle issue rate
 // (v_mul 1.0 -> 1.4 ns per wave64 instruction) and the kernel ran 23 % slower (0.79 -> 0.98 ms at 100 MP).
-template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN>
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
@@ -1230,7 +1240,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   }
   // generic-CFA mode checks its rows for ordinary samples (gen_sample_bad); u16 sources skip the check when the host did it
   // for all 65 536 values
-  const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
+  // (f32 sources without per-pixel guards, PXG == false, rely on the same row check)
+  const bool gen_guard = (GEN || (!PXG && !DEMO)) && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
   // rows: this segment's output rows [r0, r1)
   const uint32_t nrows = a.out_r1 - a.out_r0;
   const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
@@ -1341,7 +1352,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     if (GEN) {
       // any filter without a fourth colour: masked sums + proven division, or the literal form for a row window that
       // holds a sample outside the proven zone
-      const bool literal = gen_guard && (fP | fC | fN);
+      const bool literal = fP | fC | fN;
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
@@ -1418,8 +1429,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
 #if IPK_ABLATE >= 4
     for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
-    bool bad = a.fast_ok == 0;
-    if (a.fast_ok) bad = pointwise4_fast(a, s_par, s_lab, s_gam, s_knots, px, o);
+    bool bad = a.fast_ok == 0 || (!PXG && gen_guard && (fP | fC | fN));   // PXG == false: a row window with an out-of-the-ordinary sample
+    if (a.fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1500,6 +1511,12 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
+  // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards.  (The f32
+  // counterpart, which has to check its rows on the device instead, measured only 0.4 % faster and is not instantiated.)
+  if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
+    hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false>), dim3(grid), dim3(tpb), 0, s, a);
+    return;
+  }
   if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true, false>), dim3(grid), dim3(tpb), 0, s, a);
   else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false, false>), dim3(grid), dim3(tpb), 0, s, a);
 }
@@ -1550,7 +1567,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
-  a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check;
+  a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check; a.px_guard = f.px_guard;
 
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks, 4);
@@ -1614,7 +1631,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
     bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
     if (a.fast_ok) {
-      bad |= pointwise4_fast(a, s_par, s_lab, s_gam, s_knots, px, o);
+      bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
