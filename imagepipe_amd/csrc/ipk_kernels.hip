@@ -911,7 +911,7 @@ struct FastBad { bool b; };
 template <bool PXG>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
-                                                const float4 px[4], PixOut o[4]) {
+                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear) {
   bool bad = false;
   float v[12], f[12];
   f2 y[2];
@@ -960,7 +960,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
     const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
     const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-    if (a.has_curve && IPK_ABLATE < 3) L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
+    if (has_curve && IPK_ABLATE < 3) L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
     const f2 cl = L * S2(100.0f);
     const f2 ca = (A * S2(255.0f)) - S2(127.0f);
     const f2 cb = (B * S2(255.0f)) - S2(127.0f);
@@ -973,7 +973,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
     const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
     const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
-    if (a.has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
+    if (has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
     const f2 xq = F2(gx3.x > kLabE ? gx3.x : lx.x, gx3.y > kLabE ? gx3.y : lx.y);
     const f2 yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
     const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
@@ -982,7 +982,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     gg[g] = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);
     bb[g] = X * S2(par[22]) + Y * S2(par[23]) + Z * S2(par[24]);
   }
-  if (!a.linear && IPK_ABLATE < 2) {
+  if (!linear && IPK_ABLATE < 2) {
     float pos[12], v1[12], v2[12];
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -1186,7 +1186,10 @@ struct RgbeStage {
 // Occupancy: one 1024-thread block per CU = 4 waves per SIMD, on purpose.  Measured (tools/ubench2.hip, and this kernel's
 // u16->u8 variant, which fits two blocks in LDS): at 8 waves per SIMD the simple f32 ops lose their 2-cycle issue rate
 // (v_mul 1.0 -> 1.4 ns per wave64 instruction) and the kernel ran 23 % slower (0.79 -> 0.98 ms at 100 MP).
-template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true>
+// CMN = the common parameter set is compiled in: fast point-wise form allowed, a base curve present, the validated fast
+// normalisation, gamma on unless the output is 16-bit (output_16bit forces linear).  Runtime-uniform flags cost scalar
+// branches in the row loop; with them folded away the f32 kernel is 4 % faster.  Anything else runs the CMN = false variant.
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
@@ -1241,7 +1244,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // generic-CFA mode checks its rows for ordinary samples (gen_sample_bad); u16 sources skip the check when the host did it
   // for all 65 536 values
   // (f32 sources without per-pixel guards, PXG == false, rely on the same row check)
-  const bool gen_guard = (GEN || (!PXG && !DEMO)) && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
+  // (a compile-time false for the u16 Bayer variants, so that they carry no trace of it)
+  const bool gen_guard = (GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0)) || (!PXG && !DEMO && sizeof(SrcT) == 4);
   // rows: this segment's output rows [r0, r1)
   const uint32_t nrows = a.out_r1 - a.out_r0;
   const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
@@ -1258,7 +1262,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
 
   const SrcT *src = reinterpret_cast<const SrcT *>(a.src);
   const float min0 = a.min0, range0 = a.range0, inv_range0 = a.inv_range0;
-  const bool exact_norm = a.exact_norm != 0;
+  const bool exact_norm = CMN ? false : a.exact_norm != 0;
+  const bool fast_ok = CMN ? true : a.fast_ok != 0, has_curve = CMN ? true : a.has_curve != 0, linear = CMN ? (OUT == 2) : a.linear != 0;
 
   // One image row is fetched in two steps so that the global loads of row r+2 are in flight while row r is
   // being computed: issue_row() only loads, finish_row() normalises (OpGoFloat) and gathers the horizontal
@@ -1429,8 +1434,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
 #if IPK_ABLATE >= 4
     for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
-    bool bad = a.fast_ok == 0 || (!PXG && gen_guard && (fP | fC | fN));   // PXG == false: a row window with an out-of-the-ordinary sample
-    if (a.fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o);
+    bool bad = !fast_ok || (!PXG && gen_guard && (fP | fC | fN));   // PXG == false: a row window with an out-of-the-ordinary sample
+    if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1513,8 +1518,14 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
   }
   // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards.  (The f32
   // counterpart, which has to check its rows on the device instead, measured only 0.4 % faster and is not instantiated.)
+  const bool common = a.fast_ok && a.has_curve && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u;
   if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
-    hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false>), dim3(grid), dim3(tpb), 0, s, a);
+    if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, false>), dim3(grid), dim3(tpb), 0, s, a);
+    return;
+  }
+  if (common) {
+    hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, true, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
   if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, true, false>), dim3(grid), dim3(tpb), 0, s, a);
@@ -1631,7 +1642,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
     bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
     if (a.fast_ok) {
-      bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o);
+      bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
