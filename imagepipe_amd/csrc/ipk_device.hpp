@@ -267,6 +267,21 @@ __device__ __forceinline__ float spline_interpolate_lds(const float *__restrict_
 
 // Branch-free forms of the 2- and 3-knot cases for the fused kernel (same decisions as the literal
 // search above, applied as selects in reverse priority order); any other knot count takes the loop.
+// The 3-knot form alone (no dispatch on the knot count): for callers that know the curve has 3 knots, or 2 knots padded by
+// the host to (x0, x1, x1) / (y0, y1, y1) -- then `up` implies val >= x2, so the unused second segment is never evaluated
+// into the result and every decision is the 2-knot one.
+__device__ __forceinline__ float spline_interpolate_3(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
+  const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
+  const bool up = x1 < val, down = x1 > val;
+  const int i = up ? 1 : 0;
+  const float bx = lds_knots[i], by = lds_knots[kSplineMaxKnots + i];
+  const float k1 = lds_knots[2 * kSplineMaxKnots + i], k2 = lds_knots[3 * kSplineMaxKnots + i], k3 = lds_knots[4 * kSplineMaxKnots + i];
+  float r = spline_poly(by, k1, k2, k3, val - bx);
+  r = (!up && !down) ? s.py[1] : r;                    // exact knot hit
+  r = !(val > x0) ? s.py[0] : r;                       // val <= first, or NaN
+  r = (val >= x2) ? s.py[2] : r;                       // val >= end
+  return r;
+}
 __device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
   const int np = s.npoints;
   if (np == 3) {

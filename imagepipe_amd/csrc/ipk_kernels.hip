@@ -911,7 +911,7 @@ struct FastBad { bool b; };
 template <bool PXG>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
-                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear) {
+                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false) {
   bool bad = false;
   float v[12], f[12];
   f2 y[2];
@@ -960,7 +960,10 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
     const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
     const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-    if (has_curve && IPK_ABLATE < 3) L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
+    if (has_curve && IPK_ABLATE < 3) {
+      if (curve3) L = F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
+      else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
+    }
     const f2 cl = L * S2(100.0f);
     const f2 ca = (A * S2(255.0f)) - S2(127.0f);
     const f2 cb = (B * S2(255.0f)) - S2(127.0f);
@@ -1186,7 +1189,7 @@ struct RgbeStage {
 // Occupancy: one 1024-thread block per CU = 4 waves per SIMD, on purpose.  Measured (tools/ubench2.hip, and this kernel's
 // u16->u8 variant, which fits two blocks in LDS): at 8 waves per SIMD the simple f32 ops lose their 2-cycle issue rate
 // (v_mul 1.0 -> 1.4 ns per wave64 instruction) and the kernel ran 23 % slower (0.79 -> 0.98 ms at 100 MP).
-// CMN = the common parameter set is compiled in: fast point-wise form allowed, a base curve present, the validated fast
+// CMN = the common parameter set is compiled in: fast point-wise form allowed, a base curve of 2 or 3 knots, the validated fast
 // normalisation, gamma on unless the output is 16-bit (output_16bit forces linear).  Runtime-uniform flags cost scalar
 // branches in the row loop; with them folded away the f32 kernel is 4 % faster.  Anything else runs the CMN = false variant.
 template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false>
@@ -1435,7 +1438,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
     bool bad = !fast_ok || (!PXG && gen_guard && (fP | fC | fN));   // PXG == false: a row window with an out-of-the-ordinary sample
-    if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear);
+    if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1518,7 +1521,7 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
   }
   // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards.  (The f32
   // counterpart, which has to check its rows on the device instead, measured only 0.4 % faster and is not instantiated.)
-  const bool common = a.fast_ok && a.has_curve && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u;
+  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u;
   if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, false>), dim3(grid), dim3(tpb), 0, s, a);
@@ -1576,6 +1579,12 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   for (int i = 0; i < 9; ++i) a.rgbm.m[i] = f.rgbm9[i];
   a.has_curve = f.has_curve; a.linear = f.linear;
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
+  if (f.has_curve && a.spline.npoints == 2) {             // 2 knots padded to (x0, x1, x1): same decisions through the 3-knot form (ipk_device.hpp)
+    a.spline.npoints = 3; a.spline.nseg = 2;
+    a.spline.px[2] = a.spline.px[1]; a.spline.py[2] = a.spline.py[1];
+    a.spline.c1[1] = a.spline.c1[0]; a.spline.c2[1] = a.spline.c2[0]; a.spline.c3[1] = a.spline.c3[0];
+    a.spline.c1[2] = a.spline.c1[1];
+  }
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
   a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check; a.px_guard = f.px_guard;

@@ -124,6 +124,24 @@ def test_fused_row_bands_equal_whole_frame(ipa, orc):
         assert_bits_equal(out.cpu().numpy().reshape(r1 - r0, w, 3), want[r0:r1], "band %d..%d" % (r0, r1))
 
 
+@pytest.mark.parametrize("points,exposure", [([], 0.5), ([], -1.0), ([(0.5, 0.6)], 0.0), ([(0.0, 0.1)], 0.0), ([(1.0, 0.9)], 0.2), ([(0.3, 0.2), (0.6, 0.8)], 0.0),
+                                             ([(0.2, 0.9), (0.4, 0.1), (0.6, 0.95), (0.8, 0.05)], 0.0), ([], 0.0)])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_fused_curve_shapes(ipa, orc, points, exposure, is_float):
+    """2-knot (padded to 3 for the compiled-in 3-knot form), 3-knot, many-knot and no-op base curves; samples land exactly on knots"""
+    h, w = 24, 512
+    raw = util.noise_u16(util.SEED + 66, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "RGGB", is_float=is_float))
+    pipe.ops.basecurve.points = list(points); pipe.ops.basecurve.exposure = exposure
+    for linear in (False, True):
+        pipe.globals.settings.linear = linear
+        got = pipe.run(); assert pipe.last_used_fused
+        assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, src, "RGGB", points=points, exposure=exposure, linear=linear)), "curve %r" % (points,))
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, "RGGB", points=points, exposure=exposure)))
+
+
 def test_fused_rejects_four_colour_filters(ipa):
     """the fused kernel covers every three-colour filter; RGBE-style mosaics (the fast point-wise form drops the E term) run staged"""
     import torch
