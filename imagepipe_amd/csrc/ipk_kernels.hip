@@ -1513,15 +1513,16 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 #else
   const unsigned tpb = 1024;
 #endif
+  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u;
   if (a.gen_cells) {                                     // generic-CFA mode: one load flavour per source type
     constexpr bool V = sizeof(SrcT) == 4;
-    if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    else if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true>), dim3(grid), dim3(tpb), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
   // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards.  (The f32
   // counterpart, which has to check its rows on the device instead, measured only 0.4 % faster and is not instantiated.)
-  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u;
   if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, false>), dim3(grid), dim3(tpb), 0, s, a);
