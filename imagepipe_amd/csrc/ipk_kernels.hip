@@ -1300,8 +1300,17 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
     bool redo = exact_norm;
     // a dividend outside cdiv_fast's zone either clips to 1.0 (huge positive: exact in both forms) or gives a sample the row
     // check below rejects, which then redoes the row with true divisions -- so the row check replaces this one when it runs
-    if (GUARD_NORM && !gen_guard) redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
-                                                                              cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
+    if (GUARD_NORM && !gen_guard) {
+      if (CMN) {
+        // CMN implies |black| >= 2^-70 (host-checked), so a nonzero v - black is at least half an ulp of black: no tiny
+        // dividends.  A huge positive one clips to 1.0 whatever the division does; inf and NaN are v_div_fixup's.  That
+        // leaves dividends below -2^100, one comparison on the minimum of the six.
+        redo = __builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(dh, dh2)) >= -0x1p100f)) != 0;
+      } else {
+        redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
+                                                    cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
+      }
+    }
     if (!redo) {
       w.v0 = rs_min(cdiv_fast(d0, range0, inv_range0), 1.0f); w.v1 = rs_min(cdiv_fast(d1, range0, inv_range0), 1.0f);
       w.v2 = rs_min(cdiv_fast(d2, range0, inv_range0), 1.0f); w.v3 = rs_min(cdiv_fast(d3, range0, inv_range0), 1.0f);
@@ -1513,7 +1522,8 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 #else
   const unsigned tpb = 1024;
 #endif
-  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u;
+  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
+                      std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
   if (a.gen_cells) {                                     // generic-CFA mode: one load flavour per source type
     constexpr bool V = sizeof(SrcT) == 4;
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true, true, true>), dim3(grid), dim3(tpb), 0, s, a);
