@@ -590,11 +590,14 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
     for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
     for (int i = 0; i < 12; ++i) ok = ok && sane(p->cam_to_xyz_normalized[i]);
     f.fast_ok = ok ? 1 : 0;
-    // u16 sources: when all 65 536 normalised samples, the multipliers and the matrix are ordinary (see pointwise4_fast), the
-    // kernel variant without per-pixel input guards is legal
-    bool plain = ok && bayer && f.src_is_u16 && gen_levels_ok_u16(p->black0, p->white0 - p->black0);
-    for (int i = 0; i < 3; ++i) plain = plain && mul[i] >= 0x1p-10f && mul[i] <= 0x1p10f;
-    for (int i = 0; i < 12; ++i) { const float c = std::fabs(p->cam_to_xyz_normalized[i]); plain = plain && (c == 0.0f || (c >= 0x1p-20f && c <= 0x1p20f)); }
+    // when the samples (u16: all 65 536 walked here; f32: bounded below through the black level), the multipliers and the matrix
+    // are ordinary (see pointwise4_fast in ipk_kernels.hip), the kernel variant without per-pixel input guards is legal
+    const float range = p->white0 - p->black0;
+    bool plain = ok && bayer && range > 0.0f;
+    if (f.src_is_u16) plain = plain && gen_levels_ok_u16(p->black0, range);                       // every nonzero sample >= 2^-20 in magnitude
+    else plain = plain && std::fabs(p->black0) >= range * 0x1p-6f && std::fabs(p->black0) <= 0x1p70f;   // every nonzero sample >= 2^-31
+    for (int i = 0; i < 3; ++i) plain = plain && mul[i] >= 0x1p-4f && mul[i] <= 0x1p10f;
+    for (int i = 0; i < 12; ++i) { const float c = std::fabs(p->cam_to_xyz_normalized[i]); plain = plain && (c == 0.0f || (c >= 0x1p-12f && c <= 0x1p20f)); }
     f.px_guard = plain ? 0 : 1;
   }
   ipk::Spline sp;

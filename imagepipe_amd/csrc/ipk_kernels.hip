@@ -902,12 +902,14 @@ struct FastBad { bool b; };
 // interleaving two separate two-pixel evaluations: same speed on most boxes, 22 % faster on one with slow LDS/clock).
 //
 // PXG = false drops the two input guards (the channel sanity check and the exponent guards on x and z; 18 slow-class
-// instructions per pixel pair, 4.6 % of the u16 kernel).  Legal when the caller knows every sample is "ordinary"
-// (gen_sample_bad: zero, or 2^-20 <= |v| <= 2^20) and the host checked the multipliers are in [2^-10, 2^10] and the nonzero
-// matrix entries in [2^-20, 2^20]: the samples are then multiples of 2^-43, demosaic averages of 2^-45 (2^-46/9 in
-// generic-CFA mode), white-balanced channels at least 2^-57, their matrix products at least 2^-77 and hence multiples of
-// 2^-100, so a nonzero x or z has 2^-100 <= |.| <= 2^42 -- inside the proven zone of the constant divisions; nothing is
-// below -2^20 or non-finite.  The launcher selects it for u16 sources whose 65 536 normalised values the host has checked.
+// instructions per pixel pair, 4.6 % of the u16 kernel).  Legal when every sample v is zero or 2^-31 <= |v|, v >= -2^20
+// (clipped above at 1.0; NaN clips to 1.0 as in Rust's min), the multipliers are in [2^-4, 2^10] and the nonzero matrix
+// entries in [2^-12, 2^20] (host-checked): samples of 2^-31 or more are multiples of 2^-54, Bayer demosaic averages of
+// 2^-56, white-balanced channels are at least 2^-60, their matrix products at least 2^-72 and hence multiples of 2^-95,
+// so a nonzero x or z has 2^-95 <= |.| <= 2^42 -- inside the proven zone [2^-100, 2^100] of the constant divisions.
+// Where the sample bounds come from: u16 sources -- the host walks all 65 536 values; f32 sources (CMN variants only) --
+// |black| >= range/64 makes a nonzero v - black at least |black| * 2^-25 >= range * 2^-31, and finish_row's single
+// comparison flags a row with a dividend below -2^20 * range; a row window holding a flagged row takes the literal form.
 template <bool PXG>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
@@ -1246,9 +1248,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   }
   // generic-CFA mode checks its rows for ordinary samples (gen_sample_bad); u16 sources skip the check when the host did it
   // for all 65 536 values
-  // (f32 sources without per-pixel guards, PXG == false, rely on the same row check)
-  // (a compile-time false for the u16 Bayer variants, so that they carry no trace of it)
-  const bool gen_guard = (GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0)) || (!PXG && !DEMO && sizeof(SrcT) == 4);
+  // (a compile-time false for the Bayer variants, so that they carry no trace of it)
+  const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
   // rows: this segment's output rows [r0, r1)
   const uint32_t nrows = a.out_r1 - a.out_r0;
   const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
@@ -1305,7 +1306,11 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
         // CMN implies |black| >= 2^-70 (host-checked), so a nonzero v - black is at least half an ulp of black: no tiny
         // dividends.  A huge positive one clips to 1.0 whatever the division does; inf and NaN are v_div_fixup's.  That
         // leaves dividends below -2^100, one comparison on the minimum of the six.
-        redo = __builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(dh, dh2)) >= -0x1p100f)) != 0;
+        // Without per-pixel guards (PXG == false; f32 only with CMN) the same comparison also keeps every sample above -2^20,
+        // and the host has checked |black| >= range/64, which puts every nonzero sample at 2^-31 or more (see pointwise4_fast).
+        const float lowest = PXG ? -0x1p100f : -0x1p20f * range0;
+        redo = __builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(dh, dh2)) >= lowest)) != 0;
+        if (!PXG) flag = redo;
       } else {
         redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
                                                     cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
@@ -1446,7 +1451,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
 #if IPK_ABLATE >= 4
     for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
-    bool bad = !fast_ok || (!PXG && gen_guard && (fP | fC | fN));   // PXG == false: a row window with an out-of-the-ordinary sample
+    bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
     if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
       #pragma unroll
@@ -1531,14 +1536,17 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
-  // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards.  (The f32
-  // counterpart, which has to check its rows on the device instead, measured only 0.4 % faster and is not instantiated.)
+  // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards
   if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, false>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
   if (common) {
+    if constexpr (sizeof(SrcT) == 4) if (a.px_guard == 0) {   // f32: ordinary parameters and a black level of at least range/64
+      hipLaunchKernelGGL((k_fused_bayer<SrcT, true, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
+      return;
+    }
     hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, true, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
