@@ -948,7 +948,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     if (__builtin_amdgcn_ballot_w64(oor) != 0) {
       const bool hi = v[k] > 1.0f, lo = oor && !hi;
       if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
-      if (__builtin_amdgcn_ballot_w64(lo) != 0) { const float t = (kLabK * v[k] + 16.0f) / 116.0f; f[k] = lo ? t : f[k]; }
+      // the linear branch for negative ratios, evaluated for the whole slot (no third branch): / 116 as the proven two-step
+      // form -- its dividend k*v + 16 is 0 or a multiple of 2^-20 (a difference against 16) and at most 2^61 in magnitude
+      { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
     }
   }
 #endif
