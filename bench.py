@@ -71,8 +71,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # IPK_BENCH_SHARE_GPU=1 (development only): all ranks on one GPU over gloo, to exercise the N > 1 control flow on a 1-GPU box
+        share = os.environ.get("IPK_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda"
     ipa.init(local_rank)
 
     H, W = args.height, args.width
@@ -119,8 +127,11 @@ def main():
             compare(12)
             checked = "first 12 rows bit-identical to the CPU oracle (no host memory for the whole frame)"
 
+    # every rank starts its clock pre-warm together (rank 0 has just spent seconds in the parity check; a rank that warmed up
+    # early would sit idle at the barrier below and cool down again)
+    barrier()
     # The MI355X raises its shader clock over the first tens of milliseconds of sustained load (measured: the same kernel
-    # takes 0.84 ms in the first 20 launches after idle and 0.74 ms from ~50 launches on).  These launches are untimed.
+    # takes 0.78 ms in the first 20 launches after idle and 0.68 ms from ~50 launches on).  These launches are untimed.
     t_pw = time.perf_counter()
     while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
         for _ in range(16):
@@ -139,7 +150,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: avg kernel (+launch gap) per step
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -206,7 +217,7 @@ def main():
         barrier()
         eb = time.perf_counter() - tb
         if dist is not None:
-            t = torch.tensor([eb], device="cuda", dtype=torch.float64)
+            t = torch.tensor([eb], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             eb = float(t[0])
         result["band_mode"] = {"ms_per_frame": round(eb / args.steps * 1e3, 4), "value": round(args.steps * H * W / 1e6 / eb, 1), "unit": "MP/s",
