@@ -40,3 +40,13 @@ def test_bench_two_ranks_control_flow():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+
+
+@pytest.mark.parametrize("cfa,H,W,nproc", [("RGGB", 150, 600, 2), ("GBRG", 301, 258, 3), ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 180, 300, 4)])
+def test_one_frame_banded_over_ranks_matches_oracle(cfa, H, W, nproc):
+    """row-band sharding of ONE frame with the real kernel: band plan aligned to the CFA period, 1-row halo exchange between
+    neighbours (dist.batch_isend_irecv), band form of the fused kernel, all-gather of the output -- ranks share the GPU over gloo"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29540 + nproc), os.path.join("tests", "helpers", "band_worker.py"), cfa, str(H), str(W)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BANDED_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
