@@ -96,6 +96,10 @@ int pool_get(size_t bytes, void **out) {
   for (size_t i = 0; i < g.pool.size(); ++i)
     if (!g.pool[i].busy && g.pool[i].bytes >= bytes && (best < 0 || g.pool[i].bytes < g.pool[best].bytes)) best = (int)i;
   if (best >= 0) { g.pool[best].busy = true; *out = g.pool[best].p; return IPK_OK; }
+  // nothing fits: the idle blocks are all too small for this frame size, so they go before a larger one is allocated
+  // (a long-running process that moves between frame sizes keeps only what its current size needs)
+  for (size_t i = g.pool.size(); i-- > 0;)
+    if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
   void *p = nullptr;
   if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
   g.pool.push_back({p, bytes, true});
