@@ -587,7 +587,7 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   float mul[4];
   ipk::normalize_wbs(p->wb_coeffs, mul);                                                                   // colorspaces.rs:100
   f.mul4 = mul; f.cm12 = p->cam_to_xyz_normalized; f.rgbm9 = g.xyz_d65_33;
-  // the fast point-wise form assumes finite, ordinary parameters (see pointwise2_fast): |value| <= 2^20, no NaN/inf
+  // the fast point-wise form assumes finite, ordinary parameters (see pointwise4_fast): |value| <= 2^20, no NaN/inf
   {
     auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };        // false for NaN and inf
     bool ok = true;

@@ -56,7 +56,7 @@ __device__ __forceinline__ float lut_interp(const Tab *__restrict__ tab, float v
 // Rust's f32::cbrt is the platform libm's cbrtf; XYZ_LAB_TRANSFORM calls it at run time for
 // ratios > 1 (src/color_conversions.rs:103-104,123).  glibc's routine is not correctly rounded, so
 // the kernel reproduces its arithmetic (frexp, a degree-2 polynomial and one Halley step in
-// double, ldexp) rather than calling a different cbrt.  tests/test_gpu_cbrt.py checks it against
+// double, ldexp) rather than calling a different cbrt.  tests/test_gpu_selftest.py checks it against
 // the host libm over every f32 in (1, 2^64].  Called only with x > 1 (finite or +inf).
 __device__ __forceinline__ float cbrtf_glibc(float x) {
   if (__builtin_isinf(x)) return x;
@@ -311,11 +311,11 @@ __device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, cons
 // q0 = x*rc ; r = fma(-q0, c, x) ; q1 = fma(r, rc, q0) ; v_div_fixup(q1, c, x)
 // With rc = RN(1/c) the residual step returns the correctly rounded quotient (Markstein) whenever no
 // intermediate under/overflows; v_div_fixup_f32 restores the IEEE results for x = +-0, +-inf, NaN.
-// Checked EXHAUSTIVELY (all 2^31 positive f32 x, tests/test_gpu_fastdiv.py on the GPU and once on the
+// Checked EXHAUSTIVELY (all 2^31 positive f32 x, tests/test_gpu_selftest.py on the GPU and once on the
 // host) for every constant used below: the only failures are nonzero |x| < 2^-104 (all c) and
 // |x| > 2^126 (c < 1 only).  Call sites either prove their dividend is outside those zones (see the
 // comment at each) or raise `bad` through cdiv_guard(), which makes the wave redo the pixel group with
-// true divisions (FusedMath<true>), so results stay bit-identical to `x / c` for every input.
+// true divisions (pointwise_exact), so results stay bit-identical to `x / c` for every input.
 __device__ __forceinline__ float cdiv_fast(float x, float c, float rc) {
   const float q0 = x * rc;
   const float r = __builtin_fmaf(-q0, c, x);

@@ -680,20 +680,24 @@ void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hip
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused raw -> sRGB for the four RGGB Bayer phases:
+// Fused raw -> sRGB for every colour filter without a fourth colour (RGGB phases: role formulas; others: generic-CFA mode):
 //   OpGoFloat::run_raw (CFA branch) + demosaic::full + OpToLab + OpBaseCurve + OpFromLab + OpGamma
 //   [+ output8bit/output16bit], one pass: 4 (or 2) bytes in, 12 (or 3/6) bytes out per pixel.
 //
 // Structure (MI355X-first, not a restatement of the reference's row-parallel loops):
-//   * one 1024-thread workgroup per CU; both 13-bit tables live in LDS as {v, dv} pairs (128 KB);
-//   * no other LDS, no barriers after the table load: every WAVE owns a strip of up to 256 columns
-//     (4 consecutive pixels per lane => 16-byte loads, 48-byte stores, contiguous across the wave)
-//     and walks down a segment of rows, keeping a 3-row window of normalised samples in registers;
-//     horizontal neighbours come from the adjacent lane by DPP wave shifts, the two strip-edge
-//     columns from one 2-lane halo load per row;
-//   * each mosaic sample is therefore read from HBM once (plus 2 halo rows per segment and 2 halo
-//     columns per strip) and normalised once;
-//   * tasks (strip x row segment) are sized so that all waves of the grid get equal work.
+//   * one 1024-thread workgroup resident per CU (4 waves per SIMD: measured optimum); both 13-bit tables live in LDS as
+//     plain floats (64 KB) next to one staging buffer per wave and, in generic-CFA mode, the pattern-cell records;
+//   * no barriers after the table load: every WAVE owns a strip of 256 columns (4 consecutive pixels per lane => 16-byte
+//     loads contiguous across the wave) and walks down a segment of rows, keeping a 3-row window of normalised samples
+//     in registers; horizontal neighbours come from the adjacent lane by DPP wave shifts, the two strip-edge columns
+//     from one 2-lane halo load per row; output rows go through the wave's LDS staging buffer so that the stores are
+//     lane-contiguous 16-byte stores;
+//   * each mosaic sample is therefore read from HBM once (plus 3 halo rows per segment and 2 halo columns per strip) and
+//     normalised once;
+//   * tasks (strip x row segment of >= 24 rows) outnumber the resident waves 4:1 so that the block dispatcher evens out
+//     frames whose saturated regions make some tasks longer;
+//   * parameters that are the same for practically every raw file are template flags (CMN, PXG), because a
+//     runtime-uniform flag is a scalar branch per row.
 // ------------------------------------------------------------------------------------------
 struct FusedArgs {
   const void *src;            // element (row 0 of the slab, sensor column x) -- see row_off
