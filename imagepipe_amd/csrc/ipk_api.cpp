@@ -801,7 +801,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
 
   // ---- fused path: legal when every op between gofloat and gamma is point-wise or demosaic::full ----
   if (used_fused) *used_fused = 0;
-  if (d->allow_fused && cfa_branch && d->cpp == 1 && rcop.noop() && transform_noop) {
+  if (d->allow_fused && cfa_branch && d->cpp == 1 && rcop.noop()) {
     const float scale = ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale;
     ipk::Cfa cfa; int xo, yo;
     if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && (cfa.bayer_phase(xo, yo) || cfa.three_colour())) {
@@ -814,9 +814,30 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       std::memcpy(fp.cam_to_xyz_normalized, d->cam_to_xyz_normalized, sizeof(fp.cam_to_xyz_normalized));
       fp.exposure = d->exposure; fp.npoints = d->npoints; std::memcpy(fp.points, d->points, sizeof(fp.points));
       fp.linear = linear; fp.out_type = out_type;
-      rc = ipk_raw_to_srgb(&fp, src, dst, stream);
-      if (rc == IPK_OK && used_fused) *used_fused = 1;
-      return rc;
+      if (transform_noop) {
+        rc = ipk_raw_to_srgb(&fp, src, dst, stream);
+        if (rc == IPK_OK && used_fused) *used_fused = 1;
+        return rc;
+      }
+      // An orientation other than Normal (every portrait shot): OpTransform is the last op and a pure permutation of
+      // pixels, so gofloat..gamma still run as the one fused launch, into a scratch buffer, and rotate_buffer (+ the
+      // quantise loop) follows -- 2 or 3 launches instead of 7.
+      Scratch sc2;
+      void *tmp = nullptr, *rot = dst;
+      const size_t n3f = r.width * r.height * 3 * sizeof(float);
+      rc = sc2.get(n3f, &tmp); if (rc) return rc;
+      if (out_type != IPK_OUT_F32) { rc = sc2.get(n3f, &rot); if (rc) return rc; }
+      fp.out_type = IPK_OUT_F32;
+      rc = ipk_raw_to_srgb(&fp, src, tmp, stream); if (rc < 0) return rc;
+      size_t ow = 0, oh = 0;
+      rc = ipk_rotate_buffer(static_cast<const float *>(tmp), r.width, r.height, orientation, static_cast<float *>(rot), &ow, &oh, stream);
+      if (rc < 0) return rc;
+      if (ow != fw || oh != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", ow, oh, fw, fh);
+      if (out_type == IPK_OUT_U8) rc = ipk_output8bit(static_cast<const float *>(rot), ow * oh * 3, static_cast<uint8_t *>(dst), stream);
+      else if (out_type == IPK_OUT_U16) rc = ipk_output16bit(static_cast<const float *>(rot), ow * oh * 3, static_cast<uint16_t *>(dst), stream);
+      if (rc < 0) return rc;
+      if (used_fused) *used_fused = 1;
+      return IPK_OK;
     }
   }
 

@@ -655,8 +655,39 @@ void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst,
   hipLaunchKernelGGL(k_gamma, dim3(grid_1d(n, 1024, (unsigned)num_cus * 2)), dim3(1024), 0, s, src, n,
                      reinterpret_cast<const LutPair *>(gam_pairs), dst);
 }
+// The transposing orientations (Rotate90/270, Transpose, Transverse: |y_step| == 1, |x_step| == source pitch): consecutive
+// output ROWS are consecutive source pixels, so a 32 x 32 tile is read along the output rows (coalesced in the source),
+// turned through LDS, and written along the output columns (coalesced in the destination).
+__global__ __launch_bounds__(256) void k_rotate_transposed(const f3 *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
+                                                          int64_t x_step, int64_t y_step, f3 *__restrict__ dst) {
+  __shared__ float tile[32][33 * 3];
+  const uint32_t C0 = blockIdx.x * 32, R0 = blockIdx.y * 32;
+  const uint32_t a = threadIdx.x & 31u, b = threadIdx.x >> 5;          // 32 x 8 threads
+  #pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t lr = a, lc = b + 8 * i;                              // lanes run along the output rows
+    const uint32_t r = R0 + lr, c = C0 + lc;
+    if (r < oheight && c < owidth) {
+      const f3 v = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
+      tile[lc][3 * lr] = v.x; tile[lc][3 * lr + 1] = v.y; tile[lc][3 * lr + 2] = v.z;
+    }
+  }
+  __syncthreads();
+  #pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t lc = a, lr = b + 8 * i;                              // lanes run along the output columns
+    const uint32_t r = R0 + lr, c = C0 + lc;
+    if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = f3{tile[lc][3 * lr], tile[lc][3 * lr + 1], tile[lc][3 * lr + 2]};
+  }
+}
 void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
                    float *dst3, hipStream_t s) {
+  if ((y_step_px == 1 || y_step_px == -1) && x_step_px != 1 && x_step_px != -1 && (oheight + 31) / 32 <= 65535) {
+    hipLaunchKernelGGL(k_rotate_transposed, dim3((unsigned)((owidth + 31) / 32), (unsigned)((oheight + 31) / 32), 1), dim3(256), 0, s,
+                       reinterpret_cast<const f3 *>(src3), (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px,
+                       reinterpret_cast<f3 *>(dst3));
+    return;
+  }
   hipLaunchKernelGGL(k_rotate, grid_rows(owidth, oheight, 256), dim3(256), 0, s, reinterpret_cast<const f3 *>(src3),
                      (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px, reinterpret_cast<f3 *>(dst3));
 }

@@ -254,7 +254,10 @@ def test_staged_pipeline_vs_oracle(ipa, orc, case):
     assert pipe.negotiate() == orc.pipeline_sizes(desc)
     want = orc.pipeline_run(desc)
     got = pipe.run()
-    assert pipe.last_used_fused == (cfa == XTRANS and not okw)           # full-scale three-colour mosaics are fused; the rest runs staged
+    # full-scale three-colour mosaics are fused (an orientation change only adds rotate_buffer behind the fused launch); scaling,
+    # rotatecrop and four-colour filters run staged
+    fusable = cfa != "RGBE" and not any(k in okw for k in ("maxwidth", "maxheight", "rotatecrop"))
+    assert pipe.last_used_fused == fusable
     assert (got.height, got.width) == want.shape[:2]
     assert_bits_equal(got.numpy(), want, "driver")
     pipe.allow_fused = False
@@ -436,7 +439,7 @@ def test_cpp_mirror_pipeline(orc, tmp_path, cfa, shape, maxwidth, rotation):
     ow, oh, fused, n8 = [int(v) for v in out.stdout.split()]
     want = orc.pipeline_run(_oracle_desc(orc, raw, cfa, maxwidth=maxwidth, rotation=rotation))
     assert (oh, ow) == want.shape[:2] and n8 == ow * oh * 3
-    assert bool(fused) == (cfa in CFAS and maxwidth == 0 and rotation == 0)
+    assert bool(fused) == (maxwidth == 0)                   # every three-colour filter at full scale, any orientation
     assert_bits_equal(np.fromfile(tmp_path / "out.f32", np.float32).reshape(oh, ow, 3), want, "C++ mirror")
 
 
