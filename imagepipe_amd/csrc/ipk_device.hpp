@@ -87,23 +87,24 @@ __device__ __forceinline__ float cbrtf_glibc_sel(float x) {
   return __builtin_isinf(x) ? x : r;
 }
 
-// The same routine for 1 < x < 2, where frexp gives xe = 1, xm = x/2: factor[2 + 1%3] = 2^(1/3), ldexp(ym, 0) = ym,
-// and the double division runs as reciprocal + two Newton steps + one residual correction (the operands are
-// ordinary doubles near 1, so no scaling/fix-up is needed).  Equality with glibc's cbrtf for EVERY f32 in (1,2)
-// is checked on the device (tests/test_gpu_selftest.py), which is a proof since the domain is enumerable.
+// The same routine for 1 < x < 2, where frexp gives xe = 1, xm = x/2: factor[2 + 1%3] = 2^(1/3), ldexp(ym, 0) = ym.  The
+// f64 steps are cheaper than glibc's and NOT all bit-identical to them -- the polynomial is contracted into two fmas, the
+// sums with an exact product (2*dxm, 2*t2) are single fmas, and the division is reciprocal + one Newton step + one
+// multiply, not correctly rounded -- because the final rounding to f32 absorbs their last-bit differences: equality of the
+// RESULT with the host libm's cbrtf for EVERY f32 in (1,2) is checked on the device (tests/test_gpu_selftest.py), which is
+// a proof since the domain is enumerable.  (Measured on the way: dropping the Newton step fails for 627 096 inputs; the
+// variants with the residual correction, with two Newton steps, or with the literal polynomial all pass as well.)
 __device__ __forceinline__ float cbrtf_glibc_1to2(float x) {
   const float xm = x * 0.5f;                             // exact
   const double dxm = (double)xm;
-  const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * dxm) * dxm);
+  const float u = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, dxm, 0.697570460207922770), dxm, 0.492659620528969547);
   const float t2 = u * u * u;
-  const double num = (double)u * ((double)t2 + 2.0 * dxm);
-  const double den = 2.0 * (double)t2 + dxm;
+  const double du = (double)u, dt2 = (double)t2;
+  const double num = du * __builtin_fma(2.0, dxm, dt2);
+  const double den = __builtin_fma(2.0, dt2, dxm);
   double r = __builtin_amdgcn_rcp(den);
   r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  double q = num * r;
-  q = __builtin_fma(__builtin_fma(-den, q, num), r, q);
-  return (float)(q * 1.2599210498948731647672);
+  return (float)((num * r) * 1.2599210498948731647672);
 }
 
 // XYZ_LAB_TRANSFORM.lookup (src/color_conversions.rs:102-114 with the closure of :120-124)
