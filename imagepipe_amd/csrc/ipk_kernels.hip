@@ -1602,8 +1602,9 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blo
 #endif
   // blocks_per_cu > 1 oversubscribes the CUs with shorter tasks: only one 1024-thread block is resident per CU, the
   // rest queue and the hardware hands them out as blocks finish -- which evens out frames whose saturated regions (the
-  // out-of-table cbrtf branch) would otherwise make some waves' tasks much longer than others' (diagonal-gradient test
-  // frame: 0.81 -> 0.74 ms at 4; uniform noise: unchanged).  Tasks keep at least 24 rows so the 2 halo rows stay cheap.
+  // out-of-table cbrtf branch) would otherwise make some waves' tasks much longer than others'.  Measured at 100 MP with
+  // 1 / 2 / 4 tasks per wave: gradient frame 0.600 / 0.594 / 0.584 ms, photo-like frame 0.519 / 0.497 / 0.522 ms, uniform
+  // noise 0.620 / 0.628 / 0.629 ms (shorter tasks pay more halo rows) -- the launcher uses 2.  Tasks keep at least 24 rows.
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;
@@ -1646,7 +1647,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check; a.px_guard = f.px_guard;
 
   unsigned blocks;
-  fused_task_grid(a, f.num_cus, blocks, 4);
+  fused_task_grid(a, f.num_cus, blocks, 2);
 
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
   if (!f.src_is_u16) {
