@@ -50,3 +50,12 @@ def test_one_frame_banded_over_ranks_matches_oracle(cfa, H, W, nproc):
                         "--master-port", str(29540 + nproc), os.path.join("tests", "helpers", "band_worker.py"), cfa, str(H), str(W)],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BANDED_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("n_frames,nproc", [(7, 2), (8, 4)])
+def test_frame_batch_sharded_over_ranks(n_frames, nproc):
+    """BASELINE.json configs[3] in small: a batch of frames, frame i -> rank i % N, no data-path collective; every frame equals the oracle"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29550 + nproc), os.path.join("tests", "helpers", "batch_worker.py"), str(n_frames), "200", "600"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BATCH_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
