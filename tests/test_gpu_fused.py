@@ -1,6 +1,8 @@
 """GPU parity of the fused raw->sRGB kernel and of the Pipeline driver (fused and staged) against the CPU oracle's
 Pipeline::run restatement, at sizes the oracle finishes in seconds; plus size-independent properties at the
 BASELINE.json frame sizes.  Bar: bit-exact (0 ULP; BASELINE.json allows 1 ULP f32)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -525,12 +527,13 @@ def test_errors_are_reported_not_computed(ipa):
 # ---------------------------------------------------------------------------------------------
 # randomized sweep: sizes, CFA phase, crops, levels, white balance, camera matrix, curve, output depth
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IPK_RANDOM_SEEDS", "120"))))   # IPK_RANDOM_SEEDS=1000 for a soak run
 def test_fused_randomized_configurations(ipa, orc, seed):
     rng = np.random.default_rng(1000 + seed)
     h = int(rng.integers(10, 80)); w = int(rng.choice([rng.integers(10, 300), 256, 260, 512, 4 * int(rng.integers(64, 200))]))
-    cfa = CFAS[int(rng.integers(0, 4))]
+    cfa = (CFAS + [XT, W8X2])[int(rng.integers(0, 6))]
     crops = tuple(int(v) for v in rng.integers(0, 4, 4)) if rng.integers(0, 2) else (0, 0, 0, 0)
+    orient = dict(rotation=int(rng.integers(0, 4)), fliph=bool(rng.integers(0, 2)), flipv=bool(rng.integers(0, 2))) if rng.integers(0, 3) == 0 else {}
     if h - crops[0] - crops[2] < 10 or w - crops[1] - crops[3] < 10:
         crops = (0, 0, 0, 0)
     is_float = bool(rng.integers(0, 2))
@@ -549,7 +552,9 @@ def test_fused_randomized_configurations(ipa, orc, seed):
     pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops, **kw))
     pipe.ops.basecurve.points = points; pipe.ops.basecurve.exposure = exposure
     pipe.globals.settings.linear = linear
-    d = lambda: _oracle_desc(orc, src, cfa, crops=crops, points=points, exposure=exposure, linear=linear, **kw)
+    for k, v in orient.items():
+        setattr(pipe.ops.transform, k, v)
+    d = lambda: _oracle_desc(orc, src, cfa, crops=crops, points=points, exposure=exposure, linear=linear, **orient, **kw)
     got = pipe.run(); assert pipe.last_used_fused
     assert_bits_equal(got.numpy(), orc.pipeline_run(d()), "randomized seed %d (%dx%d %s crops %r float %s)" % (seed, w, h, cfa, crops, is_float))
     ww, hh, o8 = pipe.output_8bit()
