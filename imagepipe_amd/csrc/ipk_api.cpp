@@ -720,10 +720,28 @@ int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *d
   ipk::transform_forward(d->rotation, w, h, w, h);
   const ipk::Scaling s = ipk::calculate_scaling_total(w, h, d->maxwidth, d->maxheight);   // :328-329
   w = s.width; h = s.height;
-  *final_w = w; *final_h = h;
   ipk::transform_forward(d->rotation, w, h, w, h);                        // reverse fold (:331-335)
   rc.transform_reverse(w, h, w, h);
   *demosaic_w = w; *demosaic_h = h;
+  // The size run() PRODUCES (what output_8bit reports and tests/maxsize_test.rs asserts on): every op sizes its output from
+  // the buffer it is handed, not from the negotiation, so behind a rotatecrop the result can differ from the forward fold by a
+  // pixel.  demosaic.rs:27-61: the demosaic size when it scales, else its input; rotatecrop.rs:39-64: calc_size of its input
+  // unless it is a no-op or rejects its crops; transform.rs:56-73: sides swapped by the transposing orientations.
+  size_t pw = r.width, ph = r.height;
+  if (ipk::calculate_scaling_total(pw, ph, w, h).scale > 1.0f) { pw = w; ph = h; }
+  {
+    ipk::RotateCrop run_rc;
+    run_rc.crop_top = d->rotatecrop[0]; run_rc.crop_right = d->rotatecrop[1]; run_rc.crop_bottom = d->rotatecrop[2];
+    run_rc.crop_left = d->rotatecrop[3]; run_rc.rotation = d->rotatecrop[4];
+    int64_t pts[6]; size_t nw, nh;
+    if (run_rc.corners(pw, ph, pts, nw, nh)) { pw = nw; ph = nh; }
+  }
+  {
+    bool transpose, fx, fy;
+    ipk::orientation_to_flips(ipk::transform_orientation(d->rotation, d->fliph != 0, d->flipv != 0), transpose, fx, fy);
+    if (transpose) std::swap(pw, ph);
+  }
+  *final_w = pw; *final_h = ph;
   return IPK_OK;
 }
 

@@ -286,7 +286,11 @@ typedef struct {
 } ipk_pipeline_desc;
 
 /* Size negotiation of Pipeline::run (src/pipeline.rs:314-338): demosaic_{w,h} as stored in the
- * settings and the final output size.  No GPU needed. */
+ * settings, and the size of the buffer run() returns.  The ops size their outputs from the buffer
+ * they are handed (demosaic.rs:60-90, rotatecrop.rs:41-57, transform.rs:46-60), so behind a
+ * rotatecrop the returned buffer can be a pixel smaller than the forward fold of
+ * transform_forward() the negotiation itself uses; final_{w,h} is what run() produces.
+ * A side that scales to 0 is reported as 0 and ipk_pipeline_run rejects it.  No GPU needed. */
 IPK_API int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h,
                                size_t *final_w, size_t *final_h);
 /* Runs the ops in the reference's fixed order (src/pipeline.rs:155-164,364-372) on a DEVICE source

@@ -1173,11 +1173,20 @@ ORC_API int orc_pipeline_sizes(const orc_pipeline *p, size_t *demosaic_w, size_t
   float scale; size_t nw, nh;
   orc_calculate_scaling_total(width, height, p->maxwidth, p->maxheight, &scale, &nw, &nh);
   width = nw; height = nh;
-  *final_w = width; *final_h = height;
   /* reverse: transform, gamma.., rotatecrop, demosaic(id), gofloat(id) */
   orc_transform_forward(p->rotation, width, height, &width, &height);
   rc_transform_reverse(&rc, width, height, &width, &height);
   *demosaic_w = width; *demosaic_h = height;
+  /* What run() then PRODUCES (the size output_8bit reports; tests/maxsize_test.rs asserts on it): the ops size their outputs
+   * from the buffer they are handed, not from the negotiation, so after a rotatecrop the result can differ from the forward
+   * fold by a pixel.  gofloat: the cropped frame; demosaic (demosaic.rs:27-61): the demosaic size when it scales, else its
+   * input; rotatecrop (rotatecrop.rs:39-64): calc_size of its input unless it is a no-op / rejects its crops; transform:
+   * swaps the sides for the transposing orientations. */
+  size_t w = sz[2], h = sz[3];
+  { float sc; size_t a, b; orc_calculate_scaling_total(w, h, *demosaic_w, *demosaic_h, &sc, &a, &b); if (sc > 1.0f) { w = *demosaic_w; h = *demosaic_h; } }
+  { int64_t pts[6]; size_t ow, oh; if (orc_rotatecrop_corners(p->rc, w, h, pts, &ow, &oh)) { w = ow; h = oh; } }
+  { int f[3]; orc_orientation_to_flips(orc_transform_orientation(p->rotation, p->fliph, p->flipv), f); if (f[0]) { size_t t = w; w = h; h = t; } }
+  *final_w = w; *final_h = h;
   return 0;
 }
 

@@ -253,7 +253,7 @@ def test_staged_pipeline_vs_oracle(ipa, orc, case):
             v = case.pop(k); setattr(pipe.globals.settings, k, v); okw[k] = v
     desc = _oracle_desc(orc, raw, cfa, crops=crops, **okw)
     assert pipe.sizes() == orc.pipeline_sizes(desc)
-    assert pipe.negotiate() == orc.pipeline_sizes(desc)
+    assert pipe.negotiate()[0] == orc.pipeline_sizes(desc)[0]           # the negotiation proper (demosaic size); run() decides the final size
     want = orc.pipeline_run(desc)
     got = pipe.run()
     # full-scale three-colour mosaics are fused (an orientation change only adds rotate_buffer behind the fused launch); scaling,
@@ -561,3 +561,63 @@ def test_fused_randomized_configurations(ipa, orc, seed):
     assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(d()))
     ww, hh, o16 = pipe.output_16bit()
     assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(d()))
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized sweep of the whole driver: every source kind, scaling, rotatecrop, orientation, cache on/off
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IPK_RANDOM_SEEDS_DRIVER", "80"))))
+def test_driver_randomized_configurations(ipa, orc, seed):
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    h, w = int(rng.integers(24, 140)), int(rng.integers(24, 400))
+    kind = int(rng.integers(0, 4))                              # 0 raw u16, 1 raw f32, 2 rgb8, 3 rgb16
+    okw = {}
+    if kind < 2:
+        cfa = (CFAS + [XT, W8X2, "RGBE"])[int(rng.integers(0, 7))]
+        crops = tuple(int(v) for v in rng.integers(0, 5, 4)) if rng.integers(0, 2) else (0, 0, 0, 0)
+        raw = rng.integers(0, 16384, size=(h, w)).astype(np.uint16)
+        src = raw.astype(np.float32) if kind == 1 else raw
+        img = _raw(ipa, src, cfa, is_float=(kind == 1), crops=crops)
+        od = lambda **kw: _oracle_desc(orc, src, cfa, crops=crops, **kw)
+    else:
+        src = rng.integers(0, 256 if kind == 2 else 65536, size=(h, w, 3)).astype(np.uint8 if kind == 2 else np.uint16)
+        data = torch.from_numpy(src.ravel()).cuda() if kind == 2 else ipa.upload_u16(src)
+        img = ipa.OtherImage(w, h, data, bits=8 if kind == 2 else 16)
+        od = lambda **kw: orc.make_pipeline(src, **kw)
+    pipe = ipa.Pipeline.new_from_source(img)
+    if rng.integers(0, 2):
+        okw["maxwidth"] = int(rng.integers(8, w + 20)); pipe.globals.settings.maxwidth = okw["maxwidth"]
+    if rng.integers(0, 4) == 0:
+        okw["maxheight"] = int(rng.integers(8, h + 20)); pipe.globals.settings.maxheight = okw["maxheight"]
+    if rng.integers(0, 3) == 0:
+        rc = [float(np.float32(v)) for v in rng.uniform(0, 0.2, 4)] + [float(np.float32(rng.choice([0.0, 0.0, rng.uniform(0.0, 0.6)])))]
+        okw["rotatecrop"] = tuple(rc)
+        pipe.ops.rotatecrop.crop_top, pipe.ops.rotatecrop.crop_right, pipe.ops.rotatecrop.crop_bottom, pipe.ops.rotatecrop.crop_left, pipe.ops.rotatecrop.rotation = rc
+    if rng.integers(0, 2):
+        okw.update(rotation=int(rng.integers(0, 4)), fliph=bool(rng.integers(0, 2)), flipv=bool(rng.integers(0, 2)))
+        pipe.ops.transform.rotation, pipe.ops.transform.fliph, pipe.ops.transform.flipv = okw["rotation"], okw["fliph"], okw["flipv"]
+    if rng.integers(0, 2):
+        okw["exposure"] = float(rng.choice([0.4, -0.5])); pipe.ops.basecurve.exposure = okw["exposure"]
+        if kind >= 2:
+            okw["points"] = []
+    okw["linear"] = bool(rng.integers(0, 2)); pipe.globals.settings.linear = okw["linear"]
+    pipe.globals.settings.use_fastpath = bool(rng.integers(0, 2)); okw["use_fastpath"] = pipe.globals.settings.use_fastpath
+    tag = "driver seed %d kind %d %dx%d %r" % (seed, kind, w, h, okw)
+    assert pipe.sizes() == orc.pipeline_sizes(od(**okw)), tag
+    if 0 in pipe.sizes()[0] + pipe.sizes()[1]:                  # an extreme aspect ratio scaled to nothing: an error, not a crash
+        with pytest.raises(ipa.IpkError):
+            pipe.run()
+        return
+    want = orc.pipeline_run(od(**okw))
+    got = pipe.run()
+    assert (got.height, got.width) == want.shape[:2], tag
+    assert_bits_equal(got.numpy(), want, tag)
+    cache = ipa.PipelineCache(1 << 28)
+    assert_bits_equal(pipe.run(cache).numpy(), want, tag + " (cached, cold)")
+    assert_bits_equal(pipe.run(cache).numpy(), want, tag + " (cached, hit)"); assert pipe.last_ops_run == 0
+    cache.close()
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(od(**okw))), tag + " 8 bit"
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(od(**okw))), tag + " 16 bit"
