@@ -30,9 +30,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=10000)
     ap.add_argument("--height", type=int, default=10000)
-    ap.add_argument("--data", choices=["noise", "smooth", "photo"], default="noise",
+    ap.add_argument("--data", choices=["noise", "smooth", "photo", "flat", "white"], default="noise",
                     help="noise: uniform 14-bit values (worst case, the headline); smooth: diagonal gradient over the full range; "
-                         "photo: low-frequency mid-tone scene with shot-like noise and ~2 %% blown highlights")
+                         "photo: low-frequency mid-tone scene with shot-like noise and ~2 %% blown highlights; flat / white: development extremes (nothing / everything saturated)")
     ap.add_argument("--src", choices=["f32", "u16"], default="f32")
     ap.add_argument("--out", choices=["f32", "u8", "u16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,6 +54,10 @@ def synth_frame(torch, h, w, kind, seed):
         return torch.randint(0, 16384, (h, w), generator=g, device="cuda", dtype=torch.int32)
     rr = torch.arange(h, device="cuda", dtype=torch.int32)[:, None]
     cc = torch.arange(w, device="cuda", dtype=torch.int32)[None, :]
+    if kind == "flat":        # development: mid-grey + noise, nothing saturates (no out-of-table Lab ratio anywhere)
+        return torch.randint(6000, 7000, (h, w), generator=g, device="cuda", dtype=torch.int32)
+    if kind == "white":       # development: everything blown (every Lab ratio out of the table)
+        return torch.full((h, w), 16383, device="cuda", dtype=torch.int32)
     if kind == "photo":       # what a sensor usually delivers: exposure well below clipping, a few saturated patches
         y = rr.to(torch.float32) / h; x = cc.to(torch.float32) / w
         scene = 0.28 + 0.18 * torch.sin(6.0 * x + 2.0 * y) * torch.cos(5.0 * y) + 0.10 * torch.sin(23.0 * x) * torch.sin(19.0 * y)

@@ -977,6 +977,11 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     for (int k = 0; k < 12; ++k) f[k] = e[k].x + __builtin_amdgcn_fractf(pos[k]) * e[k].y;
   }
 #if IPK_ABLATE < 1
+  // (Tried and measured, round 1: compacting the v > 1 lanes of all 12 slots through a per-wave LDS queue -- ballot + mbcnt
+  // ranks, cbrtf on dense groups of 64, results scattered back -- instead of one cbrtf per slot with most lanes idle.  On
+  // uniform noise, where every slot has a few such lanes, it removes 7 % of the VALU instructions and 6 % of the time
+  // (0.633 -> 0.595 ms); on fully saturated regions it costs 16 %, and every hybrid that keeps the in-place form for dense
+  // slots or rows pays ~3 % on all other data for its extra scalar bookkeeping: photo-like +3.6 %, gradient +3.3 %.  Not kept.)
   #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
@@ -1261,6 +1266,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
+  // (making the task index wave-uniform with readfirstlane moves the row/address arithmetic to the scalar unit: measured, no change)
   const uint32_t task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (task >= a.n_strips * a.n_segs) return;             // whole wave leaves together
   const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;

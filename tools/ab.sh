@@ -1,0 +1,10 @@
+#!/bin/bash
+# Development tool: same-box A/B of variant libraries (tools/build_variant.sh).  usage: VARIANTS="noq x" DATA="noise photo smooth" tools/ab.sh [bench args]
+for rep in 1 2; do
+for d in ${DATA:-noise photo smooth}; do
+  for v in main ${VARIANTS}; do
+    if [ $v = main ]; then so=""; else so="$PWD/imagepipe_amd/csrc/build/ablate/lib$v.so"; fi
+    IPK_SO_OVERRIDE=$so python bench.py --no-cpu-baseline --no-check --steps 20 --data $d "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$d $v', d['roofline']['kernel_ms'], 'ms')"
+  done
+done
+done
