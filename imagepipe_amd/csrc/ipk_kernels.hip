@@ -981,7 +981,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // ranks, cbrtf on dense groups of 64, results scattered back -- instead of one cbrtf per slot with most lanes idle.  On
   // uniform noise, where every slot has a few such lanes, it removes 7 % of the VALU instructions and 6 % of the time
   // (0.633 -> 0.595 ms); on fully saturated regions it costs 16 %, and every hybrid that keeps the in-place form for dense
-  // slots or rows pays ~3 % on all other data for its extra scalar bookkeeping: photo-like +3.6 %, gradient +3.3 %.  Not kept.)
+  // slots or rows pays ~3 % on all other data for its extra scalar bookkeeping: photo-like +3.6 %, gradient +3.3 %.  Not kept.
+  // Also measured without effect (+-1 %): one v_max3 tree + a single branch in front of the 12 per-slot checks; one explicit
+  // s_waitcnt lgkmcnt(0) per table stage instead of the compiler's one per consumer.)
   #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
