@@ -373,7 +373,8 @@ def test_config5_full_size_vs_oracle(ipa, orc):
 
 
 @pytest.mark.parametrize("H,W,cfa,th,tw", [(4000, 6000, "RGGB", 50, 40), (10000, 10000, "RGGB", 50, 40),
-                                          (5760, 8640, "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 60, 48)])
+                                          (5760, 8640, "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 60, 48),
+                                          (20000, 20000, "RGGB", 50, 40)])       # 400 MP: 4.8 GB of output, byte offsets past 2^32
 def test_full_size_frame_is_periodic_like_its_input(ipa, orc, H, W, cfa, th, tw):
     """A frame built by tiling a tile whose sides are multiples of the CFA period is periodic, so the output interior must
     repeat the oracle's output of a 3x3 tiling of that tile (every interior pixel sees the same 3x3 neighbourhood): the

@@ -60,6 +60,22 @@ def main():
         res[name] = r
         del pipe, img, out
         torch.cuda.empty_cache()
+    # raster sources: 24 MP RGB8 / RGB16 -> output_8bit / output_16bit, full float pipe vs the integer fast path
+    if not os.environ.get("ONLY") or "raster" in os.environ["ONLY"]:
+        h, w = 4000, 6000
+        rng = np.random.default_rng(11)
+        for bits in (8, 16):
+            img = rng.integers(0, 256 if bits == 8 else 65536, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+            data = torch.from_numpy(img.ravel()).cuda() if bits == 8 else ipa.upload_u16(img)
+            for maxw in (0, 1500):
+                for fast in (False, True):
+                    pipe = ipa.Pipeline.new_from_source(ipa.OtherImage(w, h, data, bits=bits))
+                    pipe.globals.settings.maxwidth = maxw; pipe.globals.settings.use_fastpath = fast
+                    key = "raster_24MP_rgb%d_maxw%d_%s" % (bits, maxw, "fastpath" if fast else "floatpipe")
+                    res[key] = {"u8_ms": round(timeit(lambda: pipe.output_8bit(), n=5, warm=1), 4), "u16_ms": round(timeit(lambda: pipe.output_16bit(), n=5, warm=1), 4)}
+                    del pipe
+            del data
+            torch.cuda.empty_cache()
     # PCIe-inclusive: the host-pointer form (upload 24 MP u16, fused kernel, download f32 RGB), pageable host memory
     import ctypes as C
     h, w = 4000, 6000
