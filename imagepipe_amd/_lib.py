@@ -112,6 +112,9 @@ SIGNATURES = {
     "ipk_pipeline_sizes": (C.c_int, [C.POINTER(PipelineDesc), _szp, _szp, _szp, _szp]),
     "ipk_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int), _vp]),
     "ipk_host_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "ipk_host_pipeline_run_batch": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_vp), C.POINTER(_vp), _sz, C.c_int, C.POINTER(C.c_int)]),
+    "ipk_host_alloc": (_vp, [_sz]),
+    "ipk_host_free": (None, [_vp]),
     "ipk_host_gofloat_cfa_u16": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_float, C.c_float, _vp]),
     "ipk_host_gofloat_cfa_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_float, C.c_float, _vp]),
     "ipk_host_demosaic_full": (C.c_int, [_vp, _sz, _sz, C.c_char_p, _vp]),

@@ -225,6 +225,8 @@ int ipk_init(int device) {
   return IPK_OK;
 }
 
+namespace { void host_lanes_release(); }   // the host-pointer driver's streams and device slots (defined with HostLanes below)
+
 void ipk_shutdown(void) {
   if (!g.ready) return;
   (void)hipDeviceSynchronize();
@@ -233,6 +235,7 @@ void ipk_shutdown(void) {
   g.cfa_cache.clear();
   for (auto &b : g.pool) (void)hipFree(b.p);
   g.pool.clear();
+  host_lanes_release();
   g.ready = false; g.device = -1; g.num_cus = 0;
 }
 int ipk_is_initialized(void) { return g.ready ? 1 : 0; }
@@ -1263,20 +1266,103 @@ size_t out_elem_size(int t) { return t == IPK_OUT_F32 ? 4 : t == IPK_OUT_U8 ? 1 
 #define HOST_TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
 
 int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused) {
+  if (!src || !dst) { REQUIRE_INIT(); return fail(IPK_ERR_INVALID, "null argument"); }
+  return ipk_host_pipeline_run_batch(d, &src, &dst, 1, out_type, used_fused);
+}
+void *ipk_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void ipk_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+namespace {
+// The streams, events and device slots of the host-pointer pipeline driver.  One set per process, grown on demand and kept
+// between calls (a fresh hipMalloc of two input and two output slots costs more than moving a frame), released by ipk_shutdown.
+struct HostLanes {
+  static constexpr int kSlots = 2;
+  std::mutex mu;                                  // one host-pointer pipeline call at a time
+  hipStream_t up = nullptr, run = nullptr, down = nullptr;
+  hipEvent_t up_done[kSlots] = {}, run_done[kSlots] = {}, down_done[kSlots] = {};
+  void *in[kSlots] = {}, *out[kSlots] = {};
+  size_t in_cap = 0, out_cap = 0;
+  bool made = false;
+  int ensure(size_t in_bytes, size_t out_bytes) {
+    if (!made) {
+      for (hipStream_t *s : {&up, &run, &down}) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+      for (int i = 0; i < kSlots; ++i)
+        for (hipEvent_t *e : {&up_done[i], &run_done[i], &down_done[i]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      made = true;
+    }
+    if (in_bytes > in_cap) {
+      for (int i = 0; i < kSlots; ++i) { if (in[i]) (void)hipFree(in[i]); in[i] = nullptr; }
+      in_cap = 0;
+      for (int i = 0; i < kSlots; ++i) if (hipMalloc(&in[i], in_bytes) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", in_bytes);
+      in_cap = in_bytes;
+    }
+    if (out_bytes > out_cap) {
+      for (int i = 0; i < kSlots; ++i) { if (out[i]) (void)hipFree(out[i]); out[i] = nullptr; }
+      out_cap = 0;
+      for (int i = 0; i < kSlots; ++i) if (hipMalloc(&out[i], out_bytes) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", out_bytes);
+      out_cap = out_bytes;
+    }
+    return IPK_OK;
+  }
+  void release() {
+    for (hipStream_t *s : {&up, &run, &down}) if (*s) { (void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr; }
+    for (int i = 0; i < kSlots; ++i) {
+      for (hipEvent_t *e : {&up_done[i], &run_done[i], &down_done[i]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+      if (in[i]) (void)hipFree(in[i]); if (out[i]) (void)hipFree(out[i]);
+      in[i] = out[i] = nullptr;
+    }
+    in_cap = out_cap = 0; made = false;
+  }
+};
+HostLanes g_lanes;
+void host_lanes_release() { std::lock_guard<std::mutex> lk(g_lanes.mu); g_lanes.release(); }
+}  // namespace
+
+int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type, int *used_fused) {
   REQUIRE_INIT();
-  if (!d || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  if (!d || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
+  for (size_t i = 0; i < n; ++i) if (!srcs[i] || !dsts[i]) return fail(IPK_ERR_INVALID, "null frame pointer at index %zu", i);
   size_t dw, dh, fw, fh;
   HOST_TRY(ipk_pipeline_sizes(d, &dw, &dh, &fw, &fh));
+  if (n == 0) return IPK_OK;
   const bool raw = d->src_type == IPK_SRC_U16 || d->src_type == IPK_SRC_F32;
   const size_t in_bytes = d->width * d->height * (raw ? (size_t)d->cpp : 3) * src_elem_size(d->src_type);
   const size_t out_bytes = fw * fh * 3 * out_elem_size(out_type);
-  DevBuf a, b;
-  HOST_TRY(a.upload(src, in_bytes));
-  HOST_TRY(b.alloc(out_bytes));
-  HOST_TRY(ipk_pipeline_run(d, a.p, b.p, out_type, used_fused, nullptr));
-  HIPCHK(hipStreamSynchronize(nullptr));
-  return b.download(dst, out_bytes);
+  std::lock_guard<std::mutex> lk(g_lanes.mu);
+  HostLanes &L = g_lanes;
+  HIPCHK(hipDeviceSynchronize());   // the lanes are non-blocking streams: nothing enqueued earlier (scratch-pool users on other streams) may still be running
+  HOST_TRY(L.ensure(in_bytes, out_bytes));
+  int rc = IPK_OK;
+  for (size_t i = 0; i < n && rc == IPK_OK; ++i) {
+    const int s = (int)(i % HostLanes::kSlots);
+    const bool reused = i >= (size_t)HostLanes::kSlots;
+    // upload i into slot s once the kernels of frame i - kSlots have consumed it
+    if (reused) HIPCHK(hipStreamWaitEvent(L.up, L.run_done[s], 0));
+    HIPCHK(hipMemcpyAsync(L.in[s], srcs[i], in_bytes, hipMemcpyHostToDevice, L.up));
+    HIPCHK(hipEventRecord(L.up_done[s], L.up));
+    // compute once the upload has landed and the slot's previous output has left
+    HIPCHK(hipStreamWaitEvent(L.run, L.up_done[s], 0));
+    if (reused) HIPCHK(hipStreamWaitEvent(L.run, L.down_done[s], 0));
+    rc = ipk_pipeline_run(d, L.in[s], L.out[s], out_type, used_fused, L.run);
+    if (rc < 0) break;
+    rc = IPK_OK;
+    HIPCHK(hipEventRecord(L.run_done[s], L.run));
+    // download
+    HIPCHK(hipStreamWaitEvent(L.down, L.run_done[s], 0));
+    HIPCHK(hipMemcpyAsync(dsts[i], L.out[s], out_bytes, hipMemcpyDeviceToHost, L.down));
+    HIPCHK(hipEventRecord(L.down_done[s], L.down));
+  }
+  // drain in every case: the caller's buffers must not be touched after the return
+  const hipError_t e0 = hipStreamSynchronize(L.up), e1 = hipStreamSynchronize(L.run), e2 = hipStreamSynchronize(L.down);
+  if (rc < 0) return rc;
+  HIPCHK(e0); HIPCHK(e1); HIPCHK(e2);
+  return IPK_OK;
 }
+
 int ipk_host_gofloat_cfa_u16(const uint16_t *src, size_t owidth, size_t oheight, size_t x, size_t y, size_t width, size_t height,
                              float black0, float white0, float *dst) {
   REQUIRE_INIT(); DevBuf a, b;

@@ -308,6 +308,16 @@ IPK_API int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *
 IPK_API int ipk_pipeline_takes_fastpath(const ipk_pipeline_desc *d, int out_type);
 /* Same with HOST source and destination buffers; synchronous. */
 IPK_API int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused);
+/* A batch of n same-shaped HOST frames through one descriptor (a caller looping Pipeline::run / output_8bit over a shoot,
+ * src/pipeline.rs:311-372, :404-421): three HIP streams (upload, compute, download) over two device slots, so frame i's kernels
+ * run while frame i+1 crosses PCIe upwards and frame i-1 downwards; per-frame cost tends to max(upload, compute, download)
+ * instead of their sum.  The copies only overlap for page-locked host memory (ipk_host_alloc below, or memory the caller has
+ * registered); pageable buffers work but serialise.  Results are what n calls of ipk_host_pipeline_run give.  Synchronous at return. */
+IPK_API int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n,
+                                        int out_type, int *used_fused);
+/* Page-locked host memory for the buffers handed to the ipk_host_* entry points (NULL on failure). */
+IPK_API void *ipk_host_alloc(size_t bytes);
+IPK_API void ipk_host_free(void *p);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Stage-boundary caching contract of Pipeline::run(Some(cache)) (src/pipeline.rs:341-372;    */

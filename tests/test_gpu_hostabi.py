@@ -153,3 +153,50 @@ def test_host_raw_to_srgb(L, orc):
     want = orc.pipeline_run(orc.make_pipeline(raw, cfa="GBRG", crops=(y, ow - x - w, raw.shape[0] - y - h, x), blacklevels=[util.BLACK] * 4,
                                               whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix()))
     assert_bits_equal(out, want, "host raw_to_srgb")
+
+
+@pytest.mark.parametrize("cfa,maxwidth,out_type,pinned", [("RGGB", 0, 0, True), ("RGGB", 0, 1, False), (XT, 0, 2, True), ("GBRG", 90, 0, True), ("RGBE", 0, 1, False)])
+def test_host_pipeline_run_batch(L, orc, cfa, maxwidth, out_type, pinned):
+    """A batch of host frames through the three-stream driver (upload / compute / download over two device slots): every frame
+    equals the oracle, with page-locked (ipk_host_alloc) and with pageable buffers, for more frames than slots"""
+    import imagepipe_amd as ipa
+    h, w, n = 100, 320, 5
+    frames = [util.noise_u16(util.SEED + 300 + i, h, w) for i in range(n)]
+    img = ipa.RawImage(width=w, height=h, data=None, cfa=cfa, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                       wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    pipe = ipa.Pipeline(img)
+    pipe.globals.settings.maxwidth = maxwidth
+    d = pipe.desc()
+    _, (fw, fh) = pipe.sizes()
+    dt = {0: np.float32, 1: np.uint8, 2: np.uint16}[out_type]
+    out_bytes = fw * fh * 3 * np.dtype(dt).itemsize
+    if pinned:
+        L.ipk_host_alloc.restype = C.c_void_p
+        sp = [L.ipk_host_alloc(h * w * 2) for _ in range(n)]
+        dp = [L.ipk_host_alloc(out_bytes) for _ in range(n)]
+        assert all(sp) and all(dp)
+        for p, f in zip(sp, frames):
+            C.memmove(p, f.ctypes.data, f.nbytes)
+        outs = [np.frombuffer((C.c_char * out_bytes).from_address(p), dtype=dt) for p in dp]
+    else:
+        outs = [np.empty(fw * fh * 3, dt) for _ in range(n)]
+        sp = [f.ctypes.data for f in frames]
+        dp = [o.ctypes.data for o in outs]
+    used = C.c_int(-1)
+    srcs = (C.c_void_p * n)(*sp); dsts = (C.c_void_p * n)(*dp)
+    assert L.ipk_host_pipeline_run_batch(C.byref(d), srcs, dsts, n, out_type, C.byref(used)) == 0, L.ipk_last_error()
+    for i in range(n):
+        od = orc.make_pipeline(frames[i], cfa=cfa, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB,
+                               cam_to_xyz_normalized=util.cam_matrix(), maxwidth=maxwidth)
+        want = [orc.pipeline_run, orc.pipeline_output_8bit, orc.pipeline_output_16bit][out_type](od)
+        if out_type == 0:
+            assert_bits_equal(outs[i].reshape(fh, fw, 3), want, "batch frame %d" % i)
+        else:
+            assert np.array_equal(outs[i].reshape(fh, fw, 3), want), i
+    assert L.ipk_host_pipeline_run_batch(C.byref(d), srcs, dsts, 0, out_type, None) == 0          # empty batch
+    bad = (C.c_void_p * n)(*([sp[0], None] + sp[2:]))
+    assert L.ipk_host_pipeline_run_batch(C.byref(d), bad, dsts, n, out_type, None) == -2         # IPK_ERR_INVALID, nothing computed
+    if pinned:
+        del outs
+        for p in sp + dp:
+            L.ipk_host_free(p)
