@@ -662,6 +662,44 @@ int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int mono
   return IPK_OK;
 }
 
+int ipk_raster_to_srgb(const void *src, int src_type, size_t width, size_t height, const float *wb_coeffs, const float *cam_to_xyz_normalized,
+                       float exposure, const float *points, int npoints, int linear, int out_type, void *dst, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst || !wb_coeffs || !cam_to_xyz_normalized || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad raster_to_srgb arguments");
+  if (src_type != IPK_SRC_RGB8 && src_type != IPK_SRC_RGB16) return fail(IPK_ERR_INVALID, "raster_to_srgb takes RGB8 or RGB16 sources");
+  if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  if (npoints < 0 || npoints > 64 || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "npoints out of range");
+  if (width * height < 256) return fail(IPK_ERR_UNSUPPORTED, "raster_to_srgb needs at least 256 pixels (use the staged ops)");
+  float mul[4], cm[12];
+  std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul);                 // colorspaces.rs:97-101
+  ipk::FusedLaunch f;
+  std::memset(&f, 0, sizeof(f));
+  f.src = src; f.dst = dst;
+  f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33;
+  {
+    auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
+    for (int i = 0; i < 12; ++i) ok = ok && sane(cm[i]);
+    f.fast_ok = ok ? 1 : 0;
+  }
+  ipk::Spline sp;
+  f.has_curve = !curve_is_noop(exposure, npoints);
+  if (f.has_curve) {
+    int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
+    for (int i = 0; i < sp.npoints; ++i) if (!(std::fabs(sp.px[i]) <= 0x1p20f && std::fabs(sp.py[i]) <= 0x1p20f && std::fabs(sp.c1[i]) <= 0x1p40f)) f.fast_ok = 0;
+    for (int i = 0; i < sp.nseg; ++i) if (!(std::fabs(sp.c2[i]) <= 0x1p40f && std::fabs(sp.c3[i]) <= 0x1p40f)) f.fast_ok = 0;
+  }
+  f.spline = &sp;
+  f.linear = linear; f.out_type = out_type;
+  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
+  f.num_cus = g.num_cus;
+  if (ipk::launch_raster_chain(f, width * height, src_type == IPK_SRC_RGB16, g.lut_pairs[ipk::kLutGammaReverse], S(stream)) != 0)
+    return fail(IPK_ERR_UNSUPPORTED, "raster_to_srgb: frame too small");
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // self-test hooks
 // ------------------------------------------------------------------------------------------
@@ -860,6 +898,16 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       if (used_fused) *used_fused = 1;
       return IPK_OK;
     }
+  }
+
+  // ---- raster sources, same idea: run_other + tolab..gamma (+ quantisation) as one launch when OpDemosaic (a 4-channel buffer at
+  // scale <= 1: pass-through, demosaic.rs:39-44), OpRotateCrop and OpTransform are no-ops ----
+  if (d->allow_fused && !raw && rcop.noop() && transform_noop && r.x == 0 && r.y == 0 && r.width == d->width && r.height == d->height &&
+      r.width * r.height >= 256 && ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale <= 1.0f) {
+    rc = ipk_raster_to_srgb(src, d->src_type, r.width, r.height, d->wb_coeffs, d->cam_to_xyz_normalized, d->exposure, d->points, d->npoints,
+                            linear, out_type, dst, stream);
+    if (rc == IPK_OK && used_fused) *used_fused = 1;
+    return rc;
   }
 
   // ---- staged path: the eight ops in the reference's order (pipeline.rs:155-164) ----

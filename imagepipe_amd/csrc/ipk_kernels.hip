@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     }
   }
 }
-int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
+static FusedArgs chain_args(const FusedLaunch &f) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
   a.src = f.src; a.dst = f.dst;
@@ -1743,10 +1743,103 @@ int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
+  return a;
+}
+int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
+  FusedArgs a = chain_args(f);
   const size_t chunks = (npix + 255) / 256;
   const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
   const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
   hipLaunchKernelGGL(k_pointwise_chain, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Raster sources in one pass: OpGoFloat::run_other (gofloat.rs:171-201) + OpToLab + OpBaseCurve + OpFromLab + OpGamma
+// (+ output8bit / output16bit) straight from the RGB8 / RGB16 bytes to the output type -- 6 B/px for RGB8 -> u8 instead of
+// the 62 B/px of the four staged kernels.  A wave takes 256 consecutive pixels per step and a lane four consecutive ones:
+// 12 (24) source bytes per lane as element-aligned dword loads, contiguous across the wave; the last chunk is shifted left
+// to end at the last pixel (its overlap is computed twice, identical values), so every lane is active; the output leaves
+// through the wave's LDS staging buffer as in the raw kernel.  Same per-pixel code as everywhere else (pointwise4_fast,
+// literal redo behind a wave-uniform branch).  npix >= 256.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) rgb8x4 { uint32_t w[3]; };
+struct __attribute__((packed, aligned(2))) rgb16x4 { uint32_t w[6]; };
+template <typename SrcT, int OUT>
+__global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npix, const LutPair *__restrict__ gamma_reverse) {
+  __shared__ float s_lab[kLutPairs + 4];
+  __shared__ float s_gam[kLutPairs + 4];
+  __shared__ float s_knots[5 * kSplineMaxKnots];
+  __shared__ float s_par[32];
+  __shared__ float s_expand[sizeof(SrcT) == 1 ? 256 : 4];              // expand_srgb_gamma(input8bit(i)), the 256 possible RGB8 samples
+  constexpr int STG = OUT == 0 ? 768 : (OUT == 1 ? 192 : 384);
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[16 * STG];
+  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
+  if (sizeof(SrcT) == 1) for (int i = threadIdx.x; i < 256; i += blockDim.x) s_expand[i] = lut_interp(gamma_reverse, input8bit((uint8_t)i));
+  if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
+  else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
+  else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
+  if (threadIdx.x < kSplineMaxKnots) {
+    const int i = threadIdx.x;
+    s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
+    s_knots[3 * kSplineMaxKnots + i] = a.spline.c2[i]; s_knots[4 * kSplineMaxKnots + i] = a.spline.c3[i];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const uint64_t nchunks = (npix + 255) / 256;
+  uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
+  const SrcT *src = reinterpret_cast<const SrcT *>(a.src);
+  for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const uint64_t base = min(chunk * 256, npix - 256);                // the last chunk ends at the last pixel
+    float4 px[4];
+    if (sizeof(SrcT) == 1) {
+      const rgb8x4 t = *reinterpret_cast<const rgb8x4 *>(src + (base + 4u * lane) * 3);
+      float e[12];
+      #pragma unroll
+      for (int k = 0; k < 12; ++k) e[k] = s_expand[(t.w[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) px[j] = make_float4(e[3 * j], e[3 * j + 1], e[3 * j + 2], 0.0f);
+    } else {
+      const rgb16x4 t = *reinterpret_cast<const rgb16x4 *>(src + (base + 4u * lane) * 3);
+      float e[12];
+      #pragma unroll
+      for (int k = 0; k < 12; ++k) e[k] = input16bit((uint16_t)((t.w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) px[j] = make_float4(e[3 * j], e[3 * j + 1], e[3 * j + 2], 0.0f);
+    }
+    PixOut o[4];
+    bool bad = a.fast_ok == 0;
+    if (a.fast_ok) bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
+        if (bad) o[j] = e;
+      }
+    }
+    OutStage<OUT>::stage(stg, lane, o);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    OutStage<OUT>::flush(stg, lane, a.dst, (size_t)base);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+template <typename SrcT>
+static void launch_raster_t(const FusedArgs &a, size_t npix, int out_type, const void *gamma_reverse, unsigned blocks, hipStream_t s) {
+  const LutPair *gr = reinterpret_cast<const LutPair *>(gamma_reverse);
+  if (out_type == 0) hipLaunchKernelGGL((k_raster_chain<SrcT, 0>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, gr);
+  else if (out_type == 1) hipLaunchKernelGGL((k_raster_chain<SrcT, 1>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, gr);
+  else hipLaunchKernelGGL((k_raster_chain<SrcT, 2>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, gr);
+}
+int launch_raster_chain(const FusedLaunch &f, size_t npix, int src_is_u16, const void *gamma_reverse_pairs, hipStream_t s) {
+  if (npix < 256) return -1;
+  FusedArgs a = chain_args(f);
+  const size_t chunks = (npix + 255) / 256;
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
+  const unsigned blocks = std::max(1u, (unsigned)std::min<size_t>(cap, (chunks + 15) / 16));
+  if (src_is_u16) launch_raster_t<uint16_t>(a, npix, f.out_type, gamma_reverse_pairs, blocks, s);
+  else launch_raster_t<uint8_t>(a, npix, f.out_type, gamma_reverse_pairs, blocks, s);
   return 0;
 }
 

@@ -72,6 +72,8 @@ struct FusedLaunch {
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);
 // OpToLab..OpGamma in one pass over a 4-channel f32 buffer (src/dst, mul4, cm12, rgbm9, curve, linear, tables, fast_ok are read)
 int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s);
+// run_other + OpToLab..OpGamma + quantisation in one pass over an RGB8 / RGB16 raster (npix >= 256; f.out_type selects the output)
+int launch_raster_chain(const FusedLaunch &f, size_t npix, int src_is_u16, const void *gamma_reverse_pairs, hipStream_t s);
 
 // exhaustive on-device checks of the arithmetic shortcuts (see ipk_kernels.hip "Self-test kernels")
 int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bits, int include_special, void *out_dev, hipStream_t s);

@@ -259,6 +259,15 @@ IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *ds
 IPK_API int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs,
                                 const float *cam_to_xyz_normalized, float exposure, const float *points, int npoints, int linear,
                                 float *dst3, void *stream);
+/* The raster-source counterpart of ipk_raw_to_srgb: OpGoFloat::run_other (src/ops/gofloat.rs:171-201; RGB8 through
+ * expand_srgb_gamma(input8bit(v)), RGB16 through input16bit(v)) + OpToLab + OpBaseCurve + OpFromLab + OpGamma (+ output8bit /
+ * output16bit, src/pipeline.rs:408-414,455-461) in one pass from the width*height*3 source samples to width*height*3 outputs of
+ * out_type.  What Pipeline::run / output_8bit / output_16bit compute for an ImageSource::Other whose ops are not the defaults
+ * (the default ops take the integer fast path) when demosaic, rotatecrop and transform are no-ops; ipk_pipeline_run uses it
+ * then (allow_fused).  At least 256 pixels. */
+IPK_API int ipk_raster_to_srgb(const void *src, int src_type, size_t width, size_t height, const float *wb_coeffs,
+                               const float *cam_to_xyz_normalized, float exposure, const float *points, int npoints, int linear,
+                               int out_type, void *dst, void *stream);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Pipeline driver: Pipeline::run / output_8bit / output_16bit for one source                */

@@ -483,3 +483,42 @@ def test_transform_op_vs_oracle(ipa, orc, rot, fh, fv):
         want = orc.rotate_buffer(buf, o)
         assert (out.height, out.width) == want.shape[:2]
         assert_bits_equal(out.numpy(), want, "transform")
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("shape", [(1, 256), (1, 257), (3, 171), (16, 16), (64, 96), (7, 100003 // 7)])
+def test_raster_to_srgb_equals_the_staged_ops(ipa, orc, bits, shape):
+    """ipk_raster_to_srgb = OpGoFloat::run_other -> OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma (-> output8bit / output16bit) in
+    one kernel: bit-identical to the oracle's stages for every output type, with and without curve and gamma, for pixel counts
+    that end inside a 256-pixel chunk (the shifted last chunk) and for every 8-bit / many 16-bit sample values"""
+    import ctypes as C
+    import torch
+    h, w = shape
+    rng = np.random.default_rng(util.SEED + 400 + bits)
+    img = rng.integers(0, 256 if bits == 8 else 65536, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+    img.ravel()[:6] = [0, 1, 255 if bits == 8 else 65535, 2, 254 if bits == 8 else 65534, 128]
+    src = torch.from_numpy(img.ravel()).cuda() if bits == 8 else ipa.upload_u16(img)
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    wb = (1.0, 1.0, 1.0, float("nan"))
+    cm12 = (C.c_float * 12)()
+    assert ipa.lib().ipk_const_matrix(2, cm12) == 0                          # SRGB_D65_43: what OpToLab::new gives a raster source
+    cm = np.array(list(cm12), np.float32).reshape(3, 4)
+    rgbe = orc.gofloat_other(img, 0, 0, w, h)
+    for exposure, points, linear in [(0.0, [(0.5, 0.6)], False), (0.4, [(0.2, 0.1), (0.7, 0.9)], False), (0.0, [], True), (0.0, [], False)]:
+        want = orc.gamma(orc.fromlab(orc.basecurve(orc.tolab(rgbe, wb, cm), exposure, points)), linear)
+        pts = [c for p in points for c in p] or [0.0, 0.0]
+        for out_type, dt in ((0, torch.float32), (1, torch.uint8), (2, torch.int16)):
+            dst = torch.zeros(h * w * 3, dtype=dt, device="cuda")
+            rc = ipa.lib().ipk_raster_to_srgb(src.data_ptr(), 2 if bits == 8 else 3, w, h, fa(wb), fa(cm.ravel()), exposure, fa(pts), len(points),
+                                              int(linear), out_type, dst.data_ptr(), None)
+            assert rc == 0, ipa.lib().ipk_last_error()
+            got = dst.cpu().numpy()
+            tag = "raster bits=%d %r exposure=%r linear=%s out=%d" % (bits, shape, exposure, linear, out_type)
+            if out_type == 0:
+                assert_bits_equal(got.reshape(h, w, 3), want, tag)
+            elif out_type == 1:
+                assert np.array_equal(got.reshape(h, w, 3), orc.output8bit(want)), tag
+            else:
+                assert np.array_equal(got.view(np.uint16).reshape(h, w, 3), orc.output16bit(want)), tag
+    small = torch.zeros(255 * 3, dtype=torch.uint8, device="cuda")
+    assert ipa.lib().ipk_raster_to_srgb(small.data_ptr(), 2, 255, 1, fa(wb), fa(cm.ravel()), 0.0, fa([0.0, 0.0]), 0, 0, 1, small.data_ptr(), None) == -5   # IPK_ERR_UNSUPPORTED
