@@ -1384,8 +1384,9 @@ int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *s
   HostLanes &L = g_lanes;
   HIPCHK(hipDeviceSynchronize());   // the lanes are non-blocking streams: nothing enqueued earlier (scratch-pool users on other streams) may still be running
   HOST_TRY(L.ensure(in_bytes, out_bytes));
-  int rc = IPK_OK;
-  for (size_t i = 0; i < n && rc == IPK_OK; ++i) {
+  // one frame's enqueues; any failure stops the batch, and the lanes are drained in every case before the return (the
+  // caller's buffers must not be touched afterwards)
+  auto enqueue = [&](size_t i) -> int {
     const int s = (int)(i % HostLanes::kSlots);
     const bool reused = i >= (size_t)HostLanes::kSlots;
     // upload i into slot s once the kernels of frame i - kSlots have consumed it
@@ -1395,16 +1396,17 @@ int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *s
     // compute once the upload has landed and the slot's previous output has left
     HIPCHK(hipStreamWaitEvent(L.run, L.up_done[s], 0));
     if (reused) HIPCHK(hipStreamWaitEvent(L.run, L.down_done[s], 0));
-    rc = ipk_pipeline_run(d, L.in[s], L.out[s], out_type, used_fused, L.run);
-    if (rc < 0) break;
-    rc = IPK_OK;
+    const int rc = ipk_pipeline_run(d, L.in[s], L.out[s], out_type, used_fused, L.run);
+    if (rc < 0) return rc;
     HIPCHK(hipEventRecord(L.run_done[s], L.run));
     // download
     HIPCHK(hipStreamWaitEvent(L.down, L.run_done[s], 0));
     HIPCHK(hipMemcpyAsync(dsts[i], L.out[s], out_bytes, hipMemcpyDeviceToHost, L.down));
     HIPCHK(hipEventRecord(L.down_done[s], L.down));
-  }
-  // drain in every case: the caller's buffers must not be touched after the return
+    return IPK_OK;
+  };
+  int rc = IPK_OK;
+  for (size_t i = 0; i < n && rc == IPK_OK; ++i) rc = enqueue(i);
   const hipError_t e0 = hipStreamSynchronize(L.up), e1 = hipStreamSynchronize(L.run), e2 = hipStreamSynchronize(L.down);
   if (rc < 0) return rc;
   HIPCHK(e0); HIPCHK(e1); HIPCHK(e2);
