@@ -422,8 +422,8 @@ int ipk_raw_scaled_demosaic(const void *src, int src_type, size_t owidth, size_t
     return fail(IPK_ERR_INVALID, "bad raw_scaled_demosaic arguments");
   ipk::Cfa cfa; DevCfa dev; int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
   const int norm_fast = validate_cdiv_for_range(black0, white0 - black0, src_type == IPK_SRC_U16) ? 1 : 0;
-  if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, dst4, S(stream));
-  else ipk::launch_raw_scaled_demosaic<float>(static_cast<const float *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, dst4, S(stream));
+  if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream));
+  else ipk::launch_raw_scaled_demosaic<float>(static_cast<const float *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }

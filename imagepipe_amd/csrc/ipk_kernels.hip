@@ -512,9 +512,124 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
     if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
   }
 }
+// The same again for filters with a short period (pw x ph cells, pw * ph <= kW8MaxCells: Bayer, X-Trans, 8x2, 12x12 ...): the
+// colour bins are filled by fused multiply-adds with {0,1} weights instead of selects.  Per pattern cell (row phase, column
+// phase of the lane's first sample) LDS holds the one-hot colour of each of the 8 window columns as four floats; a tap then costs
+// s_c = fma(t, m_c, s_c) and n_c = fma(factor, m_c, n_c) per colour -- exact: t * 1 and t * 0 are exact, x + (+-0) = x, and a sum
+// that starts at +0.0 stays +0.0 under + (+-0) -- for every FINITE t.  Samples outside the window get factor 0 through a
+// column weight of -inf (max(-inf - dy*dy, 0) = 0) instead of two selects.  A row of the window whose dividends leave the
+// proven zone of the fast normalisation (f32 sources: NaN, inf, absurd magnitudes; the same wave-uniform test as above) takes
+// the select form, which never multiplies such a sample.  ~150 instead of ~265 instructions per window row.
+constexpr uint32_t kW8MaxCells = 144;
+template <typename T>
+__global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
+                                                                uint32_t pw, uint32_t ph, float *__restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw][8 columns][4 colours] one-hot weights
+  __shared__ uint16_t s_bits[kW8MaxCells];                            // the same colours, 2 bits per column (select form)
+  for (uint32_t i = threadIdx.x; i < pw * ph; i += blockDim.x) {
+    const uint32_t y = i / pw, x = i % pw;
+    uint32_t bits = 0;
+    #pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+      const uint32_t c = cfa48[y * 48 + (x + k) % 48] & 3u;
+      bits |= c << (2 * k);
+      #pragma unroll
+      for (uint32_t cc = 0; cc < 4; ++cc) s_m[(i * 8 + k) * 4 + cc] = (c == cc) ? 1.0f : 0.0f;
+    }
+    s_bits[i] = (uint16_t)bits;
+  }
+  __syncthreads();
+  const uint32_t col_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool lane_in = col_raw < a.nwidth;
+  const uint32_t col = min(col_raw, a.nwidth - 1);
+  const uint32_t from_x = min(a.width - 1, f32_as_u32_sat(floorf(a.tlx + (a.skip_x_x * (float)col))));
+  const uint32_t to_x = min(a.width - 1, f32_as_u32_sat(floorf(a.tlx + (a.skip_x_x * (float)(col + 1)))));
+  const float center_x = a.tlx + (a.skip_y_x / 2.0f) - 0.5f + (a.skip_x_x * (float)col) + (a.skip_x_x / 2.0f);
+  const uint32_t nx = to_x - from_x + 1;
+  const uint32_t lx = min(from_x, a.width - 8);
+  const uint32_t kshift = from_x - lx;
+  float ax[8], axm[8];                                   // 1 - dx*dx of sample lx + k; axm: the same, -inf outside the window
+  #pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const float delta_x = tb_div((float)(lx + k) - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
+    ax[k] = 1.0f - (delta_x * delta_x);
+    axm[k] = ((k - kshift) < nx) ? ax[k] : -__builtin_inff();
+  }
+  const uint32_t xm = lx % pw;
+  uint32_t kend = 0;
+  #pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) if (__builtin_amdgcn_ballot_w64(kshift + nx > k) != 0) kend = k + 1;
+  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+    const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)row)));
+    const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)(row + 1))));
+    const float center_y = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    for (uint32_t y = from_y; y <= to_y; ++y) {         // wave-uniform bounds
+      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
+      const float dy2 = delta_y * delta_y;
+      float d[8];
+      Row8<T>::load(src + (size_t)(y + a.src_y) * a.src_pitch + a.src_x + lx, d);
+      const uint32_t cell = (y % ph) * pw + xm;
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = d[k] - a.min0;
+      bool fastdiv = a.norm_fast != 0;
+      if (sizeof(T) == 4 && fastdiv) {
+        bool g = false;
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) g |= cdiv_guard(d[k]);
+        // the weights form multiplies every sample by 0 or 1: -inf (which the guard lets through to the division's fixup, and
+        // .min(1.0) keeps) would turn the other colours' sums into NaN.  NaN and +inf become 1.0 under .min(1.0) and are harmless.
+        const float dmin = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+        g |= !(dmin >= -0x1p100f);
+        fastdiv = __builtin_amdgcn_ballot_w64(g) == 0;
+      }
+      if (fastdiv) {
+        const float4 *m = reinterpret_cast<const float4 *>(s_m) + cell * 8;
+        #pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+          if (k < kend) {                                 // wave-uniform
+            // gofloat.rs:126.  cdiv_fast without its div_fixup: that only repairs zero / inf / NaN dividends, and here 0 gives 0
+            // either way while +inf and NaN give NaN, which .min(1.0) turns into the same 1.0 as inf.min(1.0)
+            const float q0 = d[k] * a.inv_range0;
+            const float q = __builtin_fmaf(__builtin_fmaf(-q0, a.range0, d[k]), a.inv_range0, q0);
+            const float factor = fmaxf(axm[k] - dy2, 0.0f);                 // scaling.rs:106-107; 0 outside the window
+            const float t = rs_min(q, 1.0f) * factor;
+            const float4 mk = m[k];
+            s0 = __builtin_fmaf(t, mk.x, s0); n0 = __builtin_fmaf(factor, mk.x, n0);
+            s1 = __builtin_fmaf(t, mk.y, s1); n1 = __builtin_fmaf(factor, mk.y, n1);
+            s2 = __builtin_fmaf(t, mk.z, s2); n2 = __builtin_fmaf(factor, mk.z, n2);
+            if (a.components > 3) { s3 = __builtin_fmaf(t, mk.w, s3); n3 = __builtin_fmaf(factor, mk.w, n3); }
+          }
+        }
+      } else {
+        const uint32_t bits = s_bits[cell];
+        #pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+          if (k < kend) {
+            const bool in = (k - kshift) < nx;
+            const float q = d[k] / a.range0;
+            float factor = ax[k] - dy2;
+            factor = (factor < 0.0f) ? 0.0f : factor;
+            factor = in ? factor : 0.0f;
+            float t = rs_min(q, 1.0f) * factor;
+            t = in ? t : 0.0f;
+            const uint32_t c = (bits >> (2 * k)) & 3u;
+            s0 += (c == 0) ? t : 0.0f; n0 += (c == 0) ? factor : 0.0f;
+            s1 += (c == 1) ? t : 0.0f; n1 += (c == 1) ? factor : 0.0f;
+            s2 += (c == 2) ? t : 0.0f; n2 += (c == 2) ? factor : 0.0f;
+            if (a.components > 3) { s3 += (c == 3) ? t : 0.0f; n3 += (c == 3) ? factor : 0.0f; }
+          }
+        }
+      }
+    }
+    float4 o;
+    o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
+    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
+  }
+}
 template <typename T>
 void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0,
-                                int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, float *dst4, hipStream_t s) {
+                                int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pw, int ph, float *dst4, hipStream_t s) {
   TransformArgs a;
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
@@ -532,14 +647,20 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
       (reinterpret_cast<uintptr_t>(dst4) & 15) == 0) {
     const unsigned gx = (unsigned)((nwidth + 255) / 256);
     const unsigned want = std::max(1u, 4096u / gx);                          // ~16 blocks of 256 threads per CU in total
-    const dim3 grid(gx, (unsigned)std::min<size_t>(nheight, want), 1);
+    const dim3 grid(gx, (unsigned)std::min<size_t>(nheight, want), 1);       // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
+#ifndef IPK_W8_SELECT
+    if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
+      hipLaunchKernelGGL(k_raw_scaled_demosaic_w8m<T>, grid, dim3(256), (size_t)pw * ph * 32 * sizeof(float), s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      return;
+    }
+#endif
     hipLaunchKernelGGL(k_raw_scaled_demosaic_w8<T>, grid, dim3(256), 0, s, src, a, cfa48_dev, dst4);
     return;
   }
   hipLaunchKernelGGL(k_raw_scaled_demosaic<T>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst4);
 }
-template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, float *, hipStream_t);
-template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, float *, hipStream_t);
+template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, int, int, float *, hipStream_t);
+template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, int, int, float *, hipStream_t);
 template void launch_transform_buffer<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, float *, hipStream_t);
 template void launch_transform_buffer<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint8_t *, hipStream_t);
 template void launch_transform_buffer<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint16_t *, hipStream_t);

@@ -205,6 +205,11 @@ def test_raw_scaled_demosaic_vs_oracle(ipa, orc, case, is_float):
         src = src + util.uniform_f32(util.SEED + 91, oh * ow).reshape(oh, ow)
         sp = util.SPECIALS * np.float32(16383.0)
         src[cy + 2, cx: cx + min(w, sp.size)] = sp[: min(w, sp.size)]                      # NaN / inf / denormals inside the frame
+        # and each non-finite value alone in an otherwise ordinary neighbourhood (no other special in the same wave or window row)
+        for i, v in enumerate([-np.inf, np.nan, np.inf, -3.0e38]):
+            r = cy + 8 + 5 * i
+            if r < cy + h - 1:
+                src[r, cx + (w // 2) + i] = v
     dev = torch.from_numpy(np.ascontiguousarray(src).ravel()).cuda() if is_float else ipa.upload_u16(src)
     dst = torch.full((nh * nw * 4,), -5.0, dtype=torch.float32, device="cuda")
     rc = ipa.lib().ipk_raw_scaled_demosaic(dev.data_ptr(), 1 if is_float else 0, ow, cx, cy, w, h, util.BLACK, util.WHITE, cfa.encode(), nw, nh,
