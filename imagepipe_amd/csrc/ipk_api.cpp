@@ -42,7 +42,7 @@ struct Context {
   float xyz_d65_33[9];
   std::map<std::string, DevCfa> cfa_cache;
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
-  struct Block { void *p; size_t bytes; bool busy; };
+  struct Block { void *p; size_t bytes; bool busy; hipStream_t last; };      // last: the stream its most recent user enqueued on
   std::vector<Block> pool;
   std::mutex mu;
 };
@@ -89,20 +89,25 @@ int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
   return IPK_OK;
 }
 
-// scratch pool: buffers are handed out and returned in stream order by a single caller thread
-int pool_get(size_t bytes, void **out) {
+// scratch pool: buffers are handed out and returned in stream order -- a block goes back as soon as its last user is
+// enqueued, and the next user on the SAME stream runs after it.  A block last used on a different stream is only handed
+// out once that stream has drained (rare: callers normally stay on one stream; the host-pointer driver uses its own).
+int pool_get(size_t bytes, void **out, hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g.mu);
   int best = -1;
   for (size_t i = 0; i < g.pool.size(); ++i)
     if (!g.pool[i].busy && g.pool[i].bytes >= bytes && (best < 0 || g.pool[i].bytes < g.pool[best].bytes)) best = (int)i;
-  if (best >= 0) { g.pool[best].busy = true; *out = g.pool[best].p; return IPK_OK; }
+  if (best >= 0) {
+    if (g.pool[best].last != stream) HIPCHK(hipStreamSynchronize(g.pool[best].last));
+    g.pool[best].busy = true; g.pool[best].last = stream; *out = g.pool[best].p; return IPK_OK;
+  }
   // nothing fits: the idle blocks are all too small for this frame size, so they go before a larger one is allocated
   // (a long-running process that moves between frame sizes keeps only what its current size needs)
   for (size_t i = g.pool.size(); i-- > 0;)
     if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
   void *p = nullptr;
   if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-  g.pool.push_back({p, bytes, true});
+  g.pool.push_back({p, bytes, true, stream});
   *out = p;
   return IPK_OK;
 }
@@ -112,9 +117,11 @@ void pool_put(void *p) {
   for (auto &b : g.pool) if (b.p == p) { b.busy = false; return; }
 }
 struct Scratch {                       // RAII: returns its buffers to the pool
+  hipStream_t stream;
   std::vector<void *> bufs;
+  explicit Scratch(hipStream_t s) : stream(s) {}
   ~Scratch() { for (void *p : bufs) pool_put(p); }
-  int get(size_t bytes, void **out) { int rc = pool_get(bytes, out); if (!rc) bufs.push_back(*out); return rc; }
+  int get(size_t bytes, void **out) { int rc = pool_get(bytes, out, stream); if (!rc) bufs.push_back(*out); return rc; }
   void release(void *p) { pool_put(p); bufs.erase(std::remove(bufs.begin(), bufs.end(), p), bufs.end()); }
 };
 
@@ -446,7 +453,7 @@ int ipk_demosaic_run(const float *src, size_t width, size_t height, size_t color
     return ipk_scaled_demosaic(src, width, height, cfa_pat, demosaic_width, demosaic_height, dst4, stream);
   }
   if (scale > 1.0f) {                                                                                      // :54-56
-    Scratch sc; void *full = nullptr;
+    Scratch sc(S(stream)); void *full = nullptr;
     int rc = sc.get(width * height * 4 * sizeof(float), &full); if (rc) return rc;
     rc = ipk_demosaic_full(src, width, height, cfa_pat, static_cast<float *>(full), stream); if (rc) return rc;
     *out_width = demosaic_width; *out_height = demosaic_height;
@@ -813,7 +820,7 @@ static int run_fastpath(const ipk_pipeline_desc *d, const void *src, void *dst, 
   const bool scaled = sc.width != d->width || sc.height != d->height;
   const bool want16 = out_type == IPK_OUT_U16, have16 = d->src_type == IPK_SRC_RGB16;
   const size_t esz = want16 ? 2 : 1;
-  Scratch tmp;
+  Scratch tmp(S(stream));
   const void *rgb = src;
   if (want16 != have16) {                                                  // to_rgb8 / to_rgb16
     void *conv = dst;
@@ -881,7 +888,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       // An orientation other than Normal (every portrait shot): OpTransform is the last op and a pure permutation of
       // pixels, so gofloat..gamma still run as the one fused launch, into a scratch buffer, and rotate_buffer (+ the
       // quantise loop) follows -- 2 or 3 launches instead of 7.
-      Scratch sc2;
+      Scratch sc2(S(stream));
       void *tmp = nullptr, *rot = dst;
       const size_t n3f = r.width * r.height * 3 * sizeof(float);
       rc = sc2.get(n3f, &tmp); if (rc) return rc;
@@ -911,7 +918,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   }
 
   // ---- staged path: the eight ops in the reference's order (pipeline.rs:155-164) ----
-  Scratch sc;
+  Scratch sc(S(stream));
   hipStream_t st = S(stream); (void)st;
   size_t w = r.width, h = r.height, colors;
   int monochrome = 0;

@@ -622,3 +622,25 @@ def test_driver_randomized_configurations(ipa, orc, seed):
     assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(od(**okw))), tag + " 8 bit"
     ww, hh, o16 = pipe.output_16bit()
     assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(od(**okw))), tag + " 16 bit"
+
+
+def test_staged_pipeline_on_alternating_streams(ipa, orc):
+    """The staged driver's scratch pool is stream-ordered: runs that alternate between two HIP streams without synchronising in
+    between (blocks of the pool change streams) still equal the oracle"""
+    import torch
+    frames = [util.noise_u16(util.SEED + 500 + i, 120, 384) for i in range(2)]
+    pipes = []
+    for f in frames:
+        p = ipa.Pipeline.new_from_source(_raw(ipa, f, "GBRG"))
+        p.allow_fused = False
+        pipes.append(p)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for rep in range(6):
+        i = rep % 2
+        with torch.cuda.stream(streams[(rep // 2 + i) % 2]):          # each pipeline visits both streams
+            outs.append((i, pipes[i].run()))
+    torch.cuda.synchronize()
+    wants = [orc.pipeline_run(_oracle_desc(orc, f, "GBRG")) for f in frames]
+    for i, o in outs:
+        assert_bits_equal(o.numpy(), wants[i], "alternating streams, frame %d" % i)
