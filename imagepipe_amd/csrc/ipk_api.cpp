@@ -57,6 +57,9 @@ void build_host_luts() {
 
 int require_init() {
   if (!g.ready) return fail(IPK_ERR_NOT_INIT, "ipk_init() has not succeeded (no MI355X/HIP device bound); there is no CPU fallback");
+  // HIP's current device is per host thread: a caller on another thread than ipk_init's (a Rayon worker) must land on the same GPU
+  static thread_local int bound = -1;
+  if (bound != g.device) { HIPCHK(hipSetDevice(g.device)); bound = g.device; }
   return IPK_OK;
 }
 #define REQUIRE_INIT() do { int rc_ = require_init(); if (rc_) return rc_; } while (0)

@@ -200,3 +200,25 @@ def test_host_pipeline_run_batch(L, orc, cfa, maxwidth, out_type, pinned):
         del outs
         for p in sp + dp:
             L.ipk_host_free(p)
+
+
+def test_host_pipeline_from_another_thread(L, orc):
+    """HIP's current device is per host thread: an entry point called from a thread other than ipk_init's (a Rayon worker in the
+    reference's host code) binds the context's device itself"""
+    import threading
+    import imagepipe_amd as ipa
+    h, w = 64, 256
+    raw = util.noise_u16(util.SEED + 310, h, w)
+    img = ipa.RawImage(width=w, height=h, data=None, cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                       wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    d = ipa.Pipeline(img).desc()
+    out = np.empty(h * w * 3, np.float32)
+    res = {}
+
+    def work():
+        res["rc"] = L.ipk_host_pipeline_run(C.byref(d), P(raw), P(out), 0, None)
+    t = threading.Thread(target=work); t.start(); t.join()
+    assert res["rc"] == 0, L.ipk_last_error()
+    want = orc.pipeline_run(orc.make_pipeline(raw, cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB,
+                                              cam_to_xyz_normalized=util.cam_matrix()))
+    assert_bits_equal(out.reshape(h, w, 3), want, "host pipeline from a worker thread")
