@@ -637,37 +637,47 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
 // OpToLab::run + OpBaseCurve::run + OpFromLab::run + OpGamma::run (colorspaces.rs:89-112, curves.rs:33-49, colorspaces.rs:127-137,
 // gamma.rs:16-26) in one pass: what Pipeline::run computes between rotatecrop and transform when no cache needs the
 // intermediate buffers.
-int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs, const float *cam_to_xyz_normalized,
-                        float exposure, const float *points, int npoints, int linear, float *dst3, void *stream) {
-  REQUIRE_INIT();
-  if (!src4 || !dst3 || !wb_coeffs || !cam_to_xyz_normalized || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad pointwise_chain arguments");
-  if (npoints < 0 || npoints > 64 || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "npoints out of range");
+namespace {
+// what tolab..gamma need besides the pixels: normalised multipliers, the matrix, the curve, the tables -- and whether all of it
+// is ordinary enough for the fast point-wise form (pointwise4_fast; otherwise the kernels evaluate the literal form)
+struct PointwisePrep {
   float mul[4], cm[12];
-  if (monochrome) { ipk::srgb_d65_43(cm); mul[0] = mul[1] = mul[2] = mul[3] = 1.0f; }                     // colorspaces.rs:90-101
-  else { std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul); }
+  ipk::Spline sp;
   ipk::FusedLaunch f;
-  std::memset(&f, 0, sizeof(f));
-  f.src = src4; f.dst = dst3;
-  f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33;
-  {
+  int prepare(int monochrome, const float *wb_coeffs, const float *cam_to_xyz_normalized, float exposure, const float *points, int npoints, int linear) {
+    if (npoints < 0 || npoints > 64 || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "npoints out of range");
+    if (monochrome) { ipk::srgb_d65_43(cm); mul[0] = mul[1] = mul[2] = mul[3] = 1.0f; }                     // colorspaces.rs:90-101
+    else { std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul); }
+    std::memset(&f, 0, sizeof(f));
+    f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33;
     auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };
     bool ok = true;
     for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
     for (int i = 0; i < 12; ++i) ok = ok && sane(cm[i]);
     f.fast_ok = ok ? 1 : 0;
+    f.has_curve = !curve_is_noop(exposure, npoints);
+    if (f.has_curve) {
+      int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
+      for (int i = 0; i < sp.npoints; ++i) if (!(std::fabs(sp.px[i]) <= 0x1p20f && std::fabs(sp.py[i]) <= 0x1p20f && std::fabs(sp.c1[i]) <= 0x1p40f)) f.fast_ok = 0;
+      for (int i = 0; i < sp.nseg; ++i) if (!(std::fabs(sp.c2[i]) <= 0x1p40f && std::fabs(sp.c3[i]) <= 0x1p40f)) f.fast_ok = 0;
+    }
+    f.spline = &sp;
+    f.linear = linear;
+    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
+    f.num_cus = g.num_cus;
+    return IPK_OK;
   }
-  ipk::Spline sp;
-  f.has_curve = !curve_is_noop(exposure, npoints);
-  if (f.has_curve) {
-    int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
-    for (int i = 0; i < sp.npoints; ++i) if (!(std::fabs(sp.px[i]) <= 0x1p20f && std::fabs(sp.py[i]) <= 0x1p20f && std::fabs(sp.c1[i]) <= 0x1p40f)) f.fast_ok = 0;
-    for (int i = 0; i < sp.nseg; ++i) if (!(std::fabs(sp.c2[i]) <= 0x1p40f && std::fabs(sp.c3[i]) <= 0x1p40f)) f.fast_ok = 0;
-  }
-  f.spline = &sp;
-  f.linear = linear;
-  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
-  f.num_cus = g.num_cus;
-  ipk::launch_pointwise_chain(f, width * height, S(stream));
+};
+}  // namespace
+
+int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs, const float *cam_to_xyz_normalized,
+                        float exposure, const float *points, int npoints, int linear, float *dst3, void *stream) {
+  REQUIRE_INIT();
+  if (!src4 || !dst3 || !wb_coeffs || !cam_to_xyz_normalized || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad pointwise_chain arguments");
+  PointwisePrep pp;
+  int rc = pp.prepare(monochrome, wb_coeffs, cam_to_xyz_normalized, exposure, points, npoints, linear); if (rc) return rc;
+  pp.f.src = src4; pp.f.dst = dst3;
+  ipk::launch_pointwise_chain(pp.f, width * height, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
@@ -678,33 +688,11 @@ int ipk_raster_to_srgb(const void *src, int src_type, size_t width, size_t heigh
   if (!src || !dst || !wb_coeffs || !cam_to_xyz_normalized || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad raster_to_srgb arguments");
   if (src_type != IPK_SRC_RGB8 && src_type != IPK_SRC_RGB16) return fail(IPK_ERR_INVALID, "raster_to_srgb takes RGB8 or RGB16 sources");
   if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
-  if (npoints < 0 || npoints > 64 || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "npoints out of range");
   if (width * height < 256) return fail(IPK_ERR_UNSUPPORTED, "raster_to_srgb needs at least 256 pixels (use the staged ops)");
-  float mul[4], cm[12];
-  std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul);                 // colorspaces.rs:97-101
-  ipk::FusedLaunch f;
-  std::memset(&f, 0, sizeof(f));
-  f.src = src; f.dst = dst;
-  f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33;
-  {
-    auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };
-    bool ok = true;
-    for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
-    for (int i = 0; i < 12; ++i) ok = ok && sane(cm[i]);
-    f.fast_ok = ok ? 1 : 0;
-  }
-  ipk::Spline sp;
-  f.has_curve = !curve_is_noop(exposure, npoints);
-  if (f.has_curve) {
-    int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
-    for (int i = 0; i < sp.npoints; ++i) if (!(std::fabs(sp.px[i]) <= 0x1p20f && std::fabs(sp.py[i]) <= 0x1p20f && std::fabs(sp.c1[i]) <= 0x1p40f)) f.fast_ok = 0;
-    for (int i = 0; i < sp.nseg; ++i) if (!(std::fabs(sp.c2[i]) <= 0x1p40f && std::fabs(sp.c3[i]) <= 0x1p40f)) f.fast_ok = 0;
-  }
-  f.spline = &sp;
-  f.linear = linear; f.out_type = out_type;
-  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
-  f.num_cus = g.num_cus;
-  if (ipk::launch_raster_chain(f, width * height, src_type == IPK_SRC_RGB16, g.lut_pairs[ipk::kLutGammaReverse], S(stream)) != 0)
+  PointwisePrep pp;
+  int rc = pp.prepare(0, wb_coeffs, cam_to_xyz_normalized, exposure, points, npoints, linear); if (rc) return rc;
+  pp.f.src = src; pp.f.dst = dst; pp.f.out_type = out_type;
+  if (ipk::launch_raster_chain(pp.f, width * height, src_type == IPK_SRC_RGB16, g.lut_pairs[ipk::kLutGammaReverse], S(stream)) != 0)
     return fail(IPK_ERR_UNSUPPORTED, "raster_to_srgb: frame too small");
   HIPCHK(hipGetLastError());
   return IPK_OK;
