@@ -98,6 +98,7 @@ SIGNATURES = {
     "ipk_scaled_demosaic": (C.c_int, [_vp, _sz, _sz, C.c_char_p, _sz, _sz, _vp, _vp]),
     "ipk_scale_down_opbuf": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "ipk_raw_scaled_demosaic": (C.c_int, [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, C.c_float, C.c_float, C.c_char_p, _sz, _sz, _vp, _vp]),
+    "ipk_raster_scale_down": (C.c_int, [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp]),
     "ipk_demosaic_run": (C.c_int, [_vp, _sz, _sz, _sz, C.c_char_p, _sz, _sz, _vp, _szp, _szp, _vp]),
     "ipk_rotatecrop": (C.c_int, [_vp, _sz, _sz, _sz, _fp, _vp, _szp, _szp, _vp]),
     "ipk_tolab": (C.c_int, [_vp, _sz, _sz, C.c_int, _fp, _fp, _vp, _vp]),

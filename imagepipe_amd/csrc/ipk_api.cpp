@@ -438,6 +438,20 @@ int ipk_raw_scaled_demosaic(const void *src, int src_type, size_t owidth, size_t
   return IPK_OK;
 }
 
+// OpGoFloat::run_other + scale_down_opbuf in one pass over a raster (used by the pipeline drivers when OpDemosaic::run would take its
+// scale_down_opbuf branch for a raster source: the full-size 4-channel f32 buffer never exists)
+int ipk_raster_scale_down(const void *src, int src_type, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                          size_t nwidth, size_t nheight, float *dst4, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst4 || !dims_ok(width, height) || !dims_ok(nwidth, nheight) || (src_type != IPK_SRC_RGB8 && src_type != IPK_SRC_RGB16))
+    return fail(IPK_ERR_INVALID, "bad raster_scale_down arguments");
+  if (x + width > owidth) return fail(IPK_ERR_INVALID, "raster_scale_down: window wider than the source pitch");
+  ipk::launch_raster_scale_down(src, src_type == IPK_SRC_RGB16, owidth, x, y, width, height, nwidth, nheight, g.lut_pairs[ipk::kLutGammaReverse],
+                                dst4, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
 int ipk_demosaic_run(const float *src, size_t width, size_t height, size_t colors, const char *cfa_pat,
                      size_t demosaic_width, size_t demosaic_height, float *dst4, size_t *out_width, size_t *out_height, void *stream) {
   REQUIRE_INIT();
@@ -927,6 +941,13 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       w = dw; h = dh; colors = 4; demosaic_done = true;
     }
   }
+  if (d->allow_fused && !raw && !demosaic_done && ipk::calculate_scaling_total(w, h, dw, dh).scale > 1.0f) {
+    // raster source under a size limit: run_other + OpDemosaic's scale_down_opbuf branch (demosaic.rs:44-46) in one pass
+    rc = sc.get(dw * dh * 4 * sizeof(float), &buf); if (rc) return rc;
+    rc = ipk_raster_scale_down(src, d->src_type, d->width, r.x, r.y, w, h, dw, dh, static_cast<float *>(buf), stream);
+    if (rc < 0) return rc;
+    w = dw; h = dh; colors = 4; demosaic_done = true;
+  }
   if (demosaic_done) {
   } else if (raw) {
     if (d->cpp == 1 && !d->is_cfa) {
@@ -1208,6 +1229,13 @@ int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_
             mask |= 3; buf = o; cache->lru.put(hs[1], o, o->bytes()); i = 1;   // op 1's output; op 0's is never materialised
             continue;
           }
+        }
+        if (d->allow_fused && !raw && ipk::calculate_scaling_total(w0, h0, n.dw, n.dh).scale > 1.0f && !cache->lru.contains(hs[1])) {
+          rc = cbuf_new(n.dw, n.dh, 4, 0, o); if (rc) return rc;                 // raster under a size limit: run_other + scale_down_opbuf in one pass
+          rc = ipk_raster_scale_down(src, d->src_type, d->width, n.r.x, n.r.y, w0, h0, n.dw, n.dh, static_cast<float *>(o->p), stream);
+          if (rc < 0) return rc;
+          mask |= 3; buf = o; cache->lru.put(hs[1], o, o->bytes()); i = 1;
+          continue;
         }
         if (raw) {
           if (d->cpp == 1 && !d->is_cfa) {

@@ -350,6 +350,82 @@ void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t 
   hipLaunchKernelGGL(k_transform_buffer<T>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst);
 }
 
+// OpGoFloat::run_other + scaling::scale_down_opbuf in one pass over an RGB8 / RGB16 raster: dst4 = scale_down_opbuf(run_other(src))
+// (src/ops/gofloat.rs:171-201 + src/scaling.rs:147-160), what OpDemosaic::run does with a raster source under a size limit
+// (demosaic.rs:44-46) -- the full-size 4-channel f32 buffer (16 B/px) never exists.  One thread per output pixel, the window
+// walked y-outer / x-inner like the reference; the three colour components share their weights (the reference keeps one
+// count per component, all fed the same factors), E is 0 * factor summed = +0.0 over a positive count = +0.0.
+// RGB8 samples go through the 256-entry expand_srgb_gamma(input8bit(i)) table built per block; RGB16 samples through
+// input16bit = v / 65535 as the proven three-step division (dividends are the integers 0..65535).
+template <typename SrcT>
+__global__ void k_raster_scale_down(const SrcT *__restrict__ src, TransformArgs a, const LutPair *__restrict__ gamma_reverse, float4 *__restrict__ dst) {
+  __shared__ float s_expand[sizeof(SrcT) == 1 ? 256 : 4];
+  if (sizeof(SrcT) == 1) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_expand[i] = lut_interp(gamma_reverse, input8bit((uint8_t)i));
+    __syncthreads();
+  }
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= a.nwidth) return;
+  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+    const float from_x_r = a.tlx + a.skip_y_x * (float)row;
+    const float to_x_r = a.tlx + a.skip_y_x * (float)(row + 1);
+    const float from_y_r = a.tly + a.skip_y_y * (float)row;
+    const float to_y_r = a.tly + a.skip_y_y * (float)(row + 1);
+    const float center_x_r = a.tlx + (a.skip_y_x * (float)row) + (a.skip_y_x / 2.0f) - 0.5f;
+    const float center_y_r = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f;
+    const uint32_t from_x = min(a.width - 1, f32_as_u32_sat(floorf(from_x_r + (a.skip_x_x * (float)col))));
+    const uint32_t to_x = min(a.width - 1, f32_as_u32_sat(floorf(to_x_r + (a.skip_x_x * (float)(col + 1)))));
+    const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(from_y_r + (a.skip_x_y * (float)col))));
+    const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(to_y_r + (a.skip_x_y * (float)(col + 1)))));
+    const float center_x = center_x_r + (a.skip_x_x * (float)col) + (a.skip_x_x / 2.0f);
+    const float center_y = center_y_r + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, n = 0.0f;
+    for (uint32_t y = from_y; y <= to_y; ++y) {
+      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
+      const float dy2 = delta_y * delta_y;
+      const SrcT *rowp = src + ((size_t)(y + a.src_y) * a.src_pitch + a.src_x) * 3;
+      for (uint32_t x = from_x; x <= to_x; ++x) {
+        const float delta_x = tb_div((float)x - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
+        float factor = 1.0f - (delta_x * delta_x) - dy2;                    // scaling.rs:106
+        factor = (factor < 0.0f) ? 0.0f : factor;
+        const SrcT *p = rowp + (size_t)x * 3;
+        float v0, v1, v2;
+        if (sizeof(SrcT) == 1) { v0 = s_expand[p[0]]; v1 = s_expand[p[1]]; v2 = s_expand[p[2]]; }
+        else {
+          constexpr float c = 65535.0f, rc = 1.0f / 65535.0f;
+          const float x0 = (float)p[0], x1 = (float)p[1], x2 = (float)p[2];
+          const float q0 = x0 * rc, q1 = x1 * rc, q2 = x2 * rc;
+          v0 = __builtin_fmaf(__builtin_fmaf(-q0, c, x0), rc, q0); v1 = __builtin_fmaf(__builtin_fmaf(-q1, c, x1), rc, q1); v2 = __builtin_fmaf(__builtin_fmaf(-q2, c, x2), rc, q2);
+        }
+        s0 += v0 * factor; s1 += v1 * factor; s2 += v2 * factor; n += factor;
+        if (x == 0xFFFFFFFFu) break;
+      }
+      if (y == 0xFFFFFFFFu) break;
+    }
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                          // scaling.rs:122-126: no weight, zero fill
+    if (n > 0.0f) { o.x = s0 / n; o.y = s1 / n; o.z = s2 / n; }
+    dst[(size_t)row * a.nwidth + col] = o;
+  }
+}
+static int cdiv_host_ok(float c);
+void launch_raster_scale_down(const void *src, int src_is_u16, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                              size_t nwidth, size_t nheight, const void *gamma_reverse_pairs, float *dst4, hipStream_t s) {
+  TransformArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
+  a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
+  a.skip_x_x = ((float)((int64_t)width - 1) - 0.0f) / ((float)(nwidth - 1));
+  a.skip_x_y = (0.0f - 0.0f) / ((float)(nwidth - 1));
+  a.skip_y_x = (0.0f - 0.0f) / ((float)(nheight - 1));
+  a.skip_y_y = ((float)((int64_t)height - 1) - 0.0f) / ((float)(nheight - 1));
+  a.inv_skip_x_x = 1.0f / a.skip_x_x; a.inv_skip_y_y = 1.0f / a.skip_y_y;
+  a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
+  a.src_pitch = owidth; a.src_x = x; a.src_y = y;
+  const LutPair *gr = reinterpret_cast<const LutPair *>(gamma_reverse_pairs);
+  if (src_is_u16) hipLaunchKernelGGL(k_raster_scale_down<uint16_t>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, static_cast<const uint16_t *>(src), a, gr, reinterpret_cast<float4 *>(dst4));
+  else hipLaunchKernelGGL(k_raster_scale_down<uint8_t>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, static_cast<const uint8_t *>(src), a, gr, reinterpret_cast<float4 *>(dst4));
+}
+
 // OpGoFloat (CFA branch) + scaling::scaled_demosaic in one pass over the raw sensor frame: dst4 = scaled_demosaic(gofloat(src)).
 // T = uint16_t or float sensor samples; writes f32 RGBE.  (src/ops/gofloat.rs:122-130,158-166 + src/scaling.rs:132-145)
 template <typename T>

@@ -34,6 +34,9 @@ void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t 
                              int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,
                              const uint8_t *cfa48_dev, T *dst, hipStream_t s);
 
+// run_other + scale_down_opbuf in one pass over an RGB8 / RGB16 raster (gofloat.rs:171-201 + scaling.rs:147-160)
+void launch_raster_scale_down(const void *src, int src_is_u16, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                              size_t nwidth, size_t nheight, const void *gamma_reverse_pairs, float *dst4, hipStream_t s);
 template <typename T>
 void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0, int norm_fast, int has_fourth_colour,
                                 size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pattern_width, int pattern_height, float *dst4, hipStream_t s);

@@ -184,6 +184,12 @@ IPK_API int ipk_scale_down_opbuf(const float *src4, size_t width, size_t height,
  * (src/scaling.rs:132-145) in one pass over the raw sensor frame; src_type IPK_SRC_U16 or IPK_SRC_F32. */
 IPK_API int ipk_raw_scaled_demosaic(const void *src, int src_type, size_t owidth, size_t x, size_t y, size_t width, size_t height,
                                     float black0, float white0, const char *cfa, size_t nwidth, size_t nheight, float *dst4, void *stream);
+/* The raster-source counterpart: OpGoFloat::run_other (src/ops/gofloat.rs:171-201) + scaling::scale_down_opbuf (src/scaling.rs:147-160)
+ * in one pass -- what OpGoFloat and OpDemosaic (demosaic.rs:44-46: a 4-channel buffer above the size limit) compute for an RGB8 /
+ * RGB16 raster, without the full-size f32 buffer.  src: owidth-pitched RGB samples, window (x, y, width, height); dst4:
+ * nwidth*nheight*4 f32 (E = 0). */
+IPK_API int ipk_raster_scale_down(const void *src, int src_type, size_t owidth, size_t x, size_t y, size_t width, size_t height,
+                                  size_t nwidth, size_t nheight, float *dst4, void *stream);
 /* OpDemosaic::run dispatch (src/ops/demosaic.rs:27-61).  colors = 1 or 4.  dst4 must hold
  * max(width*height, demosaic_width*demosaic_height)*4 floats.  IPK_NOOP = pass-through.
  * out_width / out_height receive the result size. */

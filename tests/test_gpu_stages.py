@@ -527,3 +527,22 @@ def test_raster_to_srgb_equals_the_staged_ops(ipa, orc, bits, shape):
                 assert np.array_equal(got.view(np.uint16).reshape(h, w, 3), orc.output16bit(want)), tag
     small = torch.zeros(255 * 3, dtype=torch.uint8, device="cuda")
     assert ipa.lib().ipk_raster_to_srgb(small.data_ptr(), 2, 255, 1, fa(wb), fa(cm.ravel()), 0.0, fa([0.0, 0.0]), 0, 0, 1, small.data_ptr(), None) == -5   # IPK_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("case", [(57, 83, 19, 29, 0, 0), (64, 96, 16, 24, 0, 0), (120, 90, 17, 13, 3, 2), (33, 400, 11, 57, 5, 0), (200, 31, 9, 3, 0, 1)])
+def test_raster_scale_down_equals_run_other_then_scale_down_opbuf(ipa, orc, bits, case):
+    """ipk_raster_scale_down = scale_down_opbuf(run_other(raster)) in one pass (gofloat.rs:171-201 + scaling.rs:147-160): integer
+    and fractional scales, windows inside a larger pitched source"""
+    import torch
+    h, w, nh, nw, cx, cy = case
+    oh, ow = h + cy + 1, w + cx + 2
+    rng = np.random.default_rng(util.SEED + 410 + bits)
+    img = rng.integers(0, 256 if bits == 8 else 65536, (oh, ow, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+    img[cy, cx] = [0, 255 if bits == 8 else 65535, 1]
+    src = torch.from_numpy(img.ravel()).cuda() if bits == 8 else ipa.upload_u16(img)
+    dst = torch.full((nh * nw * 4,), -3.0, dtype=torch.float32, device="cuda")
+    rc = ipa.lib().ipk_raster_scale_down(src.data_ptr(), 2 if bits == 8 else 3, ow, cx, cy, w, h, nw, nh, dst.data_ptr(), None)
+    assert rc == 0, ipa.lib().ipk_last_error()
+    want = orc.scale_down_opbuf(orc.gofloat_other(img, cx, cy, w, h), nw, nh)
+    assert_bits_equal(dst.cpu().numpy().reshape(nh, nw, 4), want, "raster scale down bits=%d %r" % (bits, case))
