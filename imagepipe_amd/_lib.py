@@ -106,6 +106,8 @@ SIGNATURES = {
     "ipk_fromlab": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "ipk_gamma": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp]),
     "ipk_rotate_buffer": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _szp, _szp, _vp]),
+    "ipk_rotate_image_u8": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _szp, _szp, _vp]),
+    "ipk_rotate_image_u16": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _szp, _szp, _vp]),
     "ipk_transform": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_int, C.c_int, _vp, _szp, _szp, _vp]),
     "ipk_output8bit": (C.c_int, [_vp, _sz, _vp, _vp]),
     "ipk_output16bit": (C.c_int, [_vp, _sz, _vp, _vp]),

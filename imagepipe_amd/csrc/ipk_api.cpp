@@ -205,6 +205,26 @@ struct ipk_cache {
   explicit ipk_cache(size_t bytes) : lru(bytes) {}
 };
 
+namespace {
+template <typename T>
+int rotate_typed(const T *src3, size_t bwidth, size_t bheight, int orientation, T *dst3, size_t *out_width, size_t *out_height, void *stream) {
+  REQUIRE_INIT();
+  if (!src3 || !dst3 || !out_width || !out_height || !dims_ok(bwidth, bheight)) return fail(IPK_ERR_INVALID, "bad rotate arguments");
+  bool transpose, flip_x, flip_y;
+  ipk::orientation_to_flips(orientation, transpose, flip_x, flip_y);
+  // transform.rs:102-128 in units of pixels
+  int64_t width = (int64_t)bwidth, height = (int64_t)bheight;
+  int64_t base = 0, x_step = 1, y_step = width;
+  if (flip_x) { x_step = -x_step; base += width - 1; }
+  if (flip_y) { y_step = -y_step; base += width * (height - 1); }
+  if (transpose) { std::swap(width, height); std::swap(x_step, y_step); }
+  *out_width = (size_t)width; *out_height = (size_t)height;
+  ipk::launch_rotate<T>(src3, (size_t)width, (size_t)height, base, x_step, y_step, dst3, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+}  // namespace
+
 extern "C" {
 
 // ------------------------------------------------------------------------------------------
@@ -540,20 +560,15 @@ int ipk_gamma(const float *src, size_t width, size_t height, size_t colors, int 
 }
 int ipk_rotate_buffer(const float *src3, size_t bwidth, size_t bheight, int orientation, float *dst3,
                       size_t *out_width, size_t *out_height, void *stream) {
-  REQUIRE_INIT();
-  if (!src3 || !dst3 || !dims_ok(bwidth, bheight)) return fail(IPK_ERR_INVALID, "bad rotate arguments");
-  bool transpose, flip_x, flip_y;
-  ipk::orientation_to_flips(orientation, transpose, flip_x, flip_y);
-  // transform.rs:102-128 in units of pixels
-  int64_t width = (int64_t)bwidth, height = (int64_t)bheight;
-  int64_t base = 0, x_step = 1, y_step = width;
-  if (flip_x) { x_step = -x_step; base += width - 1; }
-  if (flip_y) { y_step = -y_step; base += width * (height - 1); }
-  if (transpose) { std::swap(width, height); std::swap(x_step, y_step); }
-  *out_width = (size_t)width; *out_height = (size_t)height;
-  ipk::launch_rotate(src3, (size_t)width, (size_t)height, base, x_step, y_step, dst3, S(stream));
-  HIPCHK(hipGetLastError());
-  return IPK_OK;
+  return rotate_typed<float>(src3, bwidth, bheight, orientation, dst3, out_width, out_height, stream);
+}
+int ipk_rotate_image_u8(const uint8_t *src3, size_t bwidth, size_t bheight, int orientation, uint8_t *dst3,
+                        size_t *out_width, size_t *out_height, void *stream) {
+  return rotate_typed<uint8_t>(src3, bwidth, bheight, orientation, dst3, out_width, out_height, stream);
+}
+int ipk_rotate_image_u16(const uint16_t *src3, size_t bwidth, size_t bheight, int orientation, uint16_t *dst3,
+                         size_t *out_width, size_t *out_height, void *stream) {
+  return rotate_typed<uint16_t>(src3, bwidth, bheight, orientation, dst3, out_width, out_height, stream);
 }
 int ipk_transform(const float *src3, size_t width, size_t height, int rotation, int fliph, int flipv, float *dst3,
                   size_t *out_width, size_t *out_height, void *stream) {
@@ -894,32 +909,47 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       // pixels, so gofloat..gamma still run as the one fused launch, into a scratch buffer, and rotate_buffer (+ the
       // quantise loop) follows -- 2 or 3 launches instead of 7.
       Scratch sc2(S(stream));
-      void *tmp = nullptr, *rot = dst;
-      const size_t n3f = r.width * r.height * 3 * sizeof(float);
-      rc = sc2.get(n3f, &tmp); if (rc) return rc;
-      if (out_type != IPK_OUT_F32) { rc = sc2.get(n3f, &rot); if (rc) return rc; }
-      fp.out_type = IPK_OUT_F32;
-      rc = ipk_raw_to_srgb(&fp, src, tmp, stream); if (rc < 0) return rc;
+      void *tmp = nullptr;
       size_t ow = 0, oh = 0;
-      rc = ipk_rotate_buffer(static_cast<const float *>(tmp), r.width, r.height, orientation, static_cast<float *>(rot), &ow, &oh, stream);
+      // the fused kernel quantises on the way out; the permutation then runs on the 3- or 6-byte pixels (it commutes with the
+      // per-sample output8bit / output16bit)
+      rc = sc2.get(r.width * r.height * 3 * (out_type == IPK_OUT_F32 ? sizeof(float) : (out_type == IPK_OUT_U8 ? 1 : 2)), &tmp); if (rc) return rc;
+      rc = ipk_raw_to_srgb(&fp, src, tmp, stream); if (rc < 0) return rc;
+      if (out_type == IPK_OUT_F32) rc = ipk_rotate_buffer(static_cast<const float *>(tmp), r.width, r.height, orientation, static_cast<float *>(dst), &ow, &oh, stream);
+      else if (out_type == IPK_OUT_U8) rc = ipk_rotate_image_u8(static_cast<const uint8_t *>(tmp), r.width, r.height, orientation, static_cast<uint8_t *>(dst), &ow, &oh, stream);
+      else rc = ipk_rotate_image_u16(static_cast<const uint16_t *>(tmp), r.width, r.height, orientation, static_cast<uint16_t *>(dst), &ow, &oh, stream);
       if (rc < 0) return rc;
       if (ow != fw || oh != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", ow, oh, fw, fh);
-      if (out_type == IPK_OUT_U8) rc = ipk_output8bit(static_cast<const float *>(rot), ow * oh * 3, static_cast<uint8_t *>(dst), stream);
-      else if (out_type == IPK_OUT_U16) rc = ipk_output16bit(static_cast<const float *>(rot), ow * oh * 3, static_cast<uint16_t *>(dst), stream);
-      if (rc < 0) return rc;
       if (used_fused) *used_fused = 1;
       return IPK_OK;
     }
   }
 
   // ---- raster sources, same idea: run_other + tolab..gamma (+ quantisation) as one launch when OpDemosaic (a 4-channel buffer at
-  // scale <= 1: pass-through, demosaic.rs:39-44), OpRotateCrop and OpTransform are no-ops ----
-  if (d->allow_fused && !raw && rcop.noop() && transform_noop && r.x == 0 && r.y == 0 && r.width == d->width && r.height == d->height &&
+  // scale <= 1: pass-through, demosaic.rs:39-44) and OpRotateCrop are no-ops ----
+  if (d->allow_fused && !raw && rcop.noop() && r.x == 0 && r.y == 0 && r.width == d->width && r.height == d->height &&
       r.width * r.height >= 256 && ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale <= 1.0f) {
+    if (transform_noop) {
+      rc = ipk_raster_to_srgb(src, d->src_type, r.width, r.height, d->wb_coeffs, d->cam_to_xyz_normalized, d->exposure, d->points, d->npoints,
+                              linear, out_type, dst, stream);
+      if (rc == IPK_OK && used_fused) *used_fused = 1;
+      return rc;
+    }
+    // a non-Normal orientation: the same launch into a scratch image of the output type, then the permutation
+    Scratch sc2(S(stream));
+    void *tmp = nullptr;
+    size_t ow = 0, oh = 0;
+    rc = sc2.get(r.width * r.height * 3 * (out_type == IPK_OUT_F32 ? sizeof(float) : (out_type == IPK_OUT_U8 ? 1 : 2)), &tmp); if (rc) return rc;
     rc = ipk_raster_to_srgb(src, d->src_type, r.width, r.height, d->wb_coeffs, d->cam_to_xyz_normalized, d->exposure, d->points, d->npoints,
-                            linear, out_type, dst, stream);
-    if (rc == IPK_OK && used_fused) *used_fused = 1;
-    return rc;
+                            linear, out_type, tmp, stream);
+    if (rc < 0) return rc;
+    if (out_type == IPK_OUT_F32) rc = ipk_rotate_buffer(static_cast<const float *>(tmp), r.width, r.height, orientation, static_cast<float *>(dst), &ow, &oh, stream);
+    else if (out_type == IPK_OUT_U8) rc = ipk_rotate_image_u8(static_cast<const uint8_t *>(tmp), r.width, r.height, orientation, static_cast<uint8_t *>(dst), &ow, &oh, stream);
+    else rc = ipk_rotate_image_u16(static_cast<const uint16_t *>(tmp), r.width, r.height, orientation, static_cast<uint16_t *>(dst), &ow, &oh, stream);
+    if (rc < 0) return rc;
+    if (ow != fw || oh != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", ow, oh, fw, fh);
+    if (used_fused) *used_fused = 1;
+    return IPK_OK;
   }
 
   // ---- staged path: the eight ops in the reference's order (pipeline.rs:155-164) ----
@@ -1048,7 +1078,20 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     if (rc < 0) return rc;
     sc.release(buf); buf = o;
   }
-  // transform
+  // transform -- for the 8- and 16-bit outputs after the quantise loop instead of before it: output8bit / output16bit act
+  // per sample, so the permutation commutes with them and then moves 3 or 6 bytes per pixel instead of 12
+  if (!transform_noop && !f32_out) {
+    void *q = nullptr; size_t ow, oh;
+    rc = sc.get(w * h * 3 * (out_type == IPK_OUT_U8 ? 1 : 2), &q); if (rc) return rc;
+    rc = out_type == IPK_OUT_U8 ? ipk_output8bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint8_t *>(q), stream)
+                                : ipk_output16bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint16_t *>(q), stream);
+    if (rc < 0) return rc;
+    rc = out_type == IPK_OUT_U8 ? ipk_rotate_image_u8(static_cast<const uint8_t *>(q), w, h, orientation, static_cast<uint8_t *>(dst), &ow, &oh, stream)
+                                : ipk_rotate_image_u16(static_cast<const uint16_t *>(q), w, h, orientation, static_cast<uint16_t *>(dst), &ow, &oh, stream);
+    if (rc < 0) return rc;
+    if (ow != fw || oh != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", ow, oh, fw, fh);
+    return IPK_OK;
+  }
   if (!transform_noop) {
     void *o = nullptr; size_t ow, oh;
     if (f32_out) o = dst; else { rc = sc.get(n3, &o); if (rc) return rc; }

@@ -793,8 +793,13 @@ __global__ __launch_bounds__(1024) void k_gamma(const float *__restrict__ src, s
     dst[i] = gamma_sample(s_gam, src[i]);
 }
 // rotate_buffer (src/ops/transform.rs:130-141): strided gather of 3-channel pixels
-__global__ void k_rotate(const f3 *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset, int64_t x_step,
-                         int64_t y_step, f3 *__restrict__ dst) {
+// T = float: rotate_buffer on the OpBuffer (transform.rs:130-141).  T = uint8_t / uint16_t: the same permutation applied to the
+// quantised image -- output8bit / output16bit act per sample, so quantise-then-rotate equals the reference's rotate-then-
+// quantise and moves 4x / 2x fewer bytes through the permutation.
+template <typename T> struct __attribute__((packed)) Px3 { T x, y, z; };
+template <typename T>
+__global__ void k_rotate(const Px3<T> *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset, int64_t x_step,
+                         int64_t y_step, Px3<T> *__restrict__ dst) {
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= owidth) return;
   for (uint32_t row = blockIdx.y; row < oheight; row += gridDim.y) {
@@ -855,9 +860,10 @@ void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst,
 // The transposing orientations (Rotate90/270, Transpose, Transverse: |y_step| == 1, |x_step| == source pitch): consecutive
 // output ROWS are consecutive source pixels, so a 32 x 32 tile is read along the output rows (coalesced in the source),
 // turned through LDS, and written along the output columns (coalesced in the destination).
-__global__ __launch_bounds__(256) void k_rotate_transposed(const f3 *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
-                                                          int64_t x_step, int64_t y_step, f3 *__restrict__ dst) {
-  __shared__ float tile[32][33 * 3];
+template <typename T>
+__global__ __launch_bounds__(256) void k_rotate_transposed(const Px3<T> *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
+                                                          int64_t x_step, int64_t y_step, Px3<T> *__restrict__ dst) {
+  __shared__ T tile[32][33 * 3];
   const uint32_t C0 = blockIdx.x * 32, R0 = blockIdx.y * 32;
   const uint32_t a = threadIdx.x & 31u, b = threadIdx.x >> 5;          // 32 x 8 threads
   #pragma unroll
@@ -865,7 +871,7 @@ __global__ __launch_bounds__(256) void k_rotate_transposed(const f3 *__restrict_
     const uint32_t lr = a, lc = b + 8 * i;                              // lanes run along the output rows
     const uint32_t r = R0 + lr, c = C0 + lc;
     if (r < oheight && c < owidth) {
-      const f3 v = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
+      const Px3<T> v = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
       tile[lc][3 * lr] = v.x; tile[lc][3 * lr + 1] = v.y; tile[lc][3 * lr + 2] = v.z;
     }
   }
@@ -874,20 +880,24 @@ __global__ __launch_bounds__(256) void k_rotate_transposed(const f3 *__restrict_
   for (uint32_t i = 0; i < 4; ++i) {
     const uint32_t lc = a, lr = b + 8 * i;                              // lanes run along the output columns
     const uint32_t r = R0 + lr, c = C0 + lc;
-    if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = f3{tile[lc][3 * lr], tile[lc][3 * lr + 1], tile[lc][3 * lr + 2]};
+    if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = Px3<T>{tile[lc][3 * lr], tile[lc][3 * lr + 1], tile[lc][3 * lr + 2]};
   }
 }
-void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
-                   float *dst3, hipStream_t s) {
+template <typename T>
+void launch_rotate(const T *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
+                   T *dst3, hipStream_t s) {
   if ((y_step_px == 1 || y_step_px == -1) && x_step_px != 1 && x_step_px != -1 && (oheight + 31) / 32 <= 65535) {
-    hipLaunchKernelGGL(k_rotate_transposed, dim3((unsigned)((owidth + 31) / 32), (unsigned)((oheight + 31) / 32), 1), dim3(256), 0, s,
-                       reinterpret_cast<const f3 *>(src3), (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px,
-                       reinterpret_cast<f3 *>(dst3));
+    hipLaunchKernelGGL(k_rotate_transposed<T>, dim3((unsigned)((owidth + 31) / 32), (unsigned)((oheight + 31) / 32), 1), dim3(256), 0, s,
+                       reinterpret_cast<const Px3<T> *>(src3), (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px,
+                       reinterpret_cast<Px3<T> *>(dst3));
     return;
   }
-  hipLaunchKernelGGL(k_rotate, grid_rows(owidth, oheight, 256), dim3(256), 0, s, reinterpret_cast<const f3 *>(src3),
-                     (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px, reinterpret_cast<f3 *>(dst3));
+  hipLaunchKernelGGL(k_rotate<T>, grid_rows(owidth, oheight, 256), dim3(256), 0, s, reinterpret_cast<const Px3<T> *>(src3),
+                     (uint32_t)owidth, (uint32_t)oheight, base_offset_px, x_step_px, y_step_px, reinterpret_cast<Px3<T> *>(dst3));
 }
+template void launch_rotate<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, float *, hipStream_t);
+template void launch_rotate<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, uint8_t *, hipStream_t);
+template void launch_rotate<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, uint16_t *, hipStream_t);
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(k_output8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
 }

@@ -46,8 +46,9 @@ void launch_tolab(const float *src4, size_t npix, const float *mul4, const float
 void launch_basecurve(const float *src3, size_t npix, const SplineHost &sp, float *dst3, int num_cus, hipStream_t s);
 void launch_fromlab(const float *src3, size_t npix, const float *m9, float *dst3, int num_cus, hipStream_t s);
 void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst, int num_cus, hipStream_t s);
-void launch_rotate(const float *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
-                   float *dst3, hipStream_t s);
+template <typename T>   // float (OpBuffer) or uint8_t / uint16_t (the quantised image: same permutation, fewer bytes)
+void launch_rotate(const T *src3, size_t owidth, size_t oheight, int64_t base_offset_px, int64_t x_step_px, int64_t y_step_px,
+                   T *dst3, hipStream_t s);
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s);
 void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s);
 // DynamicImage::to_rgb16 / to_rgb8 channel conversion of the raster fast path (image 0.24: c*257, (c+128)/257)

@@ -219,6 +219,14 @@ IPK_API int ipk_gamma(const float *src, size_t width, size_t height, size_t colo
 /* rotate_buffer (src/ops/transform.rs:87-144), 3-channel */
 IPK_API int ipk_rotate_buffer(const float *src3, size_t width, size_t height, int orientation,
                               float *dst3, size_t *out_width, size_t *out_height, void *stream);
+/* rotate_buffer's permutation (src/ops/transform.rs:87-144) applied to an already quantised 3-channel image: output8bit /
+ * output16bit (src/pipeline.rs:408-414,455-461) act per sample, so quantise-then-rotate equals the reference's rotate-then-
+ * quantise bit for bit while the permutation moves 4x / 2x fewer bytes.  ipk_pipeline_run orders the two this way for the
+ * 8- and 16-bit outputs of non-Normal orientations. */
+IPK_API int ipk_rotate_image_u8(const uint8_t *src3, size_t width, size_t height, int orientation, uint8_t *dst3,
+                                size_t *out_width, size_t *out_height, void *stream);
+IPK_API int ipk_rotate_image_u16(const uint16_t *src3, size_t width, size_t height, int orientation, uint16_t *dst3,
+                                 size_t *out_width, size_t *out_height, void *stream);
 /* OpTransform::run (src/ops/transform.rs:56-73); IPK_NOOP for Normal/Unknown */
 IPK_API int ipk_transform(const float *src3, size_t width, size_t height, int rotation, int fliph, int flipv,
                           float *dst3, size_t *out_width, size_t *out_height, void *stream);

@@ -546,3 +546,24 @@ def test_raster_scale_down_equals_run_other_then_scale_down_opbuf(ipa, orc, bits
     assert rc == 0, ipa.lib().ipk_last_error()
     want = orc.scale_down_opbuf(orc.gofloat_other(img, cx, cy, w, h), nw, nh)
     assert_bits_equal(dst.cpu().numpy().reshape(nh, nw, 4), want, "raster scale down bits=%d %r" % (bits, case))
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (32, 32), (33, 65), (100, 37), (7, 260)])
+def test_rotate_image_quantised_equals_rotate_buffer(ipa, orc, bits, shape):
+    """ipk_rotate_image_u8 / _u16: rotate_buffer's permutation on a quantised image, all eight orientations (+ Unknown), shapes around
+    the 32 x 32 tiles of the transposing kernel"""
+    import ctypes as C
+    import torch
+    h, w = shape
+    rng = np.random.default_rng(util.SEED + 420 + bits)
+    img = rng.integers(0, 256 if bits == 8 else 65536, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+    src = torch.from_numpy(img.ravel()).cuda() if bits == 8 else ipa.upload_u16(img)
+    fn = ipa.lib().ipk_rotate_image_u8 if bits == 8 else ipa.lib().ipk_rotate_image_u16
+    for orientation in range(9):
+        dst = torch.zeros(h * w * 3, dtype=torch.uint8 if bits == 8 else torch.int16, device="cuda")
+        ow, oh = C.c_size_t(), C.c_size_t()
+        assert fn(src.data_ptr(), w, h, orientation, dst.data_ptr(), C.byref(ow), C.byref(oh), None) == 0, ipa.lib().ipk_last_error()
+        want = orc.rotate_buffer(img.astype(np.float32), orientation)          # the permutation, checked on exactly representable values
+        got = dst.cpu().numpy().view(np.uint8 if bits == 8 else np.uint16).reshape(oh.value, ow.value, 3)
+        assert (oh.value, ow.value) == want.shape[:2] and np.array_equal(got.astype(np.float32), want), (bits, shape, orientation)
