@@ -567,3 +567,28 @@ def test_rotate_image_quantised_equals_rotate_buffer(ipa, orc, bits, shape):
         want = orc.rotate_buffer(img.astype(np.float32), orientation)          # the permutation, checked on exactly representable values
         got = dst.cpu().numpy().view(np.uint8 if bits == 8 else np.uint16).reshape(oh.value, ow.value, 3)
         assert (oh.value, ow.value) == want.shape[:2] and np.array_equal(got.astype(np.float32), want), (bits, shape, orientation)
+
+
+@pytest.mark.parametrize("src_off,dst_off", [(1, 0), (3, 1), (2, 3)])
+def test_raster_to_srgb_unaligned_buffers(ipa, orc, src_off, dst_off):
+    """RGB8 rasters and 8-bit outputs at arbitrary byte addresses (a window into a larger allocation): the kernel's 4-byte loads
+    and stores are element-aligned only"""
+    import ctypes as C
+    import torch
+    h, w = 5, 333
+    rng = np.random.default_rng(util.SEED + 430)
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    big = torch.zeros(h * w * 3 + 16, dtype=torch.uint8, device="cuda")
+    big[src_off: src_off + h * w * 3] = torch.from_numpy(img.ravel()).cuda()
+    out = torch.full((h * w * 3 + 16,), 7, dtype=torch.uint8, device="cuda")
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    wb = (1.0, 1.0, 1.0, float("nan"))
+    cm12 = (C.c_float * 12)()
+    assert ipa.lib().ipk_const_matrix(2, cm12) == 0
+    cm = np.array(list(cm12), np.float32).reshape(3, 4)
+    rc = ipa.lib().ipk_raster_to_srgb(big.data_ptr() + src_off, 2, w, h, fa(wb), cm12, 0.25, fa([0.5, 0.6]), 1, 0, 1, out.data_ptr() + dst_off, None)
+    assert rc == 0, ipa.lib().ipk_last_error()
+    want = orc.output8bit(orc.gamma(orc.fromlab(orc.basecurve(orc.tolab(orc.gofloat_other(img, 0, 0, w, h), wb, cm), 0.25, [(0.5, 0.6)]))))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[dst_off: dst_off + h * w * 3].reshape(h, w, 3), want)
+    assert np.all(got[:dst_off] == 7) and np.all(got[dst_off + h * w * 3:] == 7)            # nothing written outside the image
