@@ -51,6 +51,22 @@ def stages(cfa, raw, maxwidth):
     return out
 
 
+RASTER_CASES = {  # name -> (bits, (h, w), maxwidth, exposure): raster sources with an edited op (default ops take the integer fast path)
+    "rgb8_edited": (8, (24, 40), 0, 0.3),
+    "rgb16_scaled3": (16, (30, 48), 16, 0.0),
+}
+
+
+def raster_stages(img, maxwidth, exposure):
+    desc = lambda: orc.make_pipeline(img, maxwidth=maxwidth, exposure=exposure, points=[(0.4, 0.5)], use_fastpath=True)
+    out = {"img": img, "sizes": np.array(sum(orc.pipeline_sizes(desc()), ()), np.int64)}
+    out["gofloat"] = orc.gofloat_other(img, 0, 0, img.shape[1], img.shape[0])
+    out["run"] = orc.pipeline_run(desc())
+    out["out8"] = orc.pipeline_output_8bit(desc())
+    out["out16"] = orc.pipeline_output_16bit(desc())
+    return out
+
+
 def lut_fixture():
     fx = {"note": "TransformLookup tables built with this image's libm (glibc 2.35): sha256 of the little-endian f32 bytes + sampled entries as u32 bits"}
     for which, name in ((orc.LUT_XYZ_LAB, "xyz_lab"), (orc.LUT_SRGB_GAMMA_REVERSE, "srgb_gamma_reverse"), (orc.LUT_SRGB_GAMMA, "srgb_gamma")):
@@ -66,6 +82,13 @@ def main():
         raw[:2, :6] = [[0, 512, 511, 513, 16383, 16382], [600, 16383, 16383, 16383, 0, 0]]   # below black, at black, saturated runs
         st = stages(cfa, raw, mw)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), cfa=np.array(cfa), maxwidth=np.array([mw], np.int64), **st)
+        print(name, {k: v.shape for k, v in st.items()})
+    for i, (name, (bits, (h, w), mw, ex)) in enumerate(sorted(RASTER_CASES.items())):
+        rng = np.random.default_rng(util.SEED + 200 + i)
+        img = rng.integers(0, 256 if bits == 8 else 65536, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+        img[0, :3] = [[0, 0, 0], [255 if bits == 8 else 65535] * 3, [1, 128, 254]]
+        st = raster_stages(img, mw, ex)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), maxwidth=np.array([mw], np.int64), exposure=np.array([ex], np.float32), **st)
         print(name, {k: v.shape for k, v in st.items()})
     json.dump(lut_fixture(), open(os.path.join(HERE, "lut_fixture.json"), "w"), indent=1, sort_keys=True)
 
