@@ -589,7 +589,10 @@ int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *stream) {
 // ------------------------------------------------------------------------------------------
 // fused raw -> sRGB
 // ------------------------------------------------------------------------------------------
-int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream) {
+// ori = 0: the frame as it is.  ori = Rotate90 / Rotate270 (Bayer filters, whole frames): the mosaic is first permuted into the
+// output orientation (1 channel: 2 or 4 bytes per pixel instead of the 12 of the result) and the kernel works in rotated space,
+// so that dst receives OpTransform's output directly; IPK_ERR_UNSUPPORTED (nothing launched) when no such variant exists.
+static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, void *stream, int ori) {
   REQUIRE_INIT();
   if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
   if (p->src_type != IPK_SRC_U16 && p->src_type != IPK_SRC_F32) return fail(IPK_ERR_INVALID, "fused path takes u16 or f32 CFA data");
@@ -619,6 +622,35 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.src_is_u16 = p->src_type == IPK_SRC_U16;
   f.src_aligned4 = (reinterpret_cast<uintptr_t>(base) % 4 == 0) && (p->owidth % 2 == 0);
   f.width = p->width; f.height = p->height; f.owidth = p->owidth;
+  f.ori = 0; f.roles[0] = f.roles[1] = f.roles[2] = f.roles[3] = 0;
+  Scratch rot(S(stream));
+  if (ori != 0) {
+    if (band || !bayer || (ori != IPK_OR_ROT90 && ori != IPK_OR_ROT270) || p->height < 256)
+      return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for this frame");
+    bool t, fx, fy;
+    ipk::orientation_to_flips(ori, t, fx, fy);
+    // rotate_buffer's index walk (transform.rs:102-128) over the crop window of the pitched 1-channel source
+    int64_t width = (int64_t)p->width, height = (int64_t)p->height, x_step = 1, y_step = (int64_t)p->owidth, off = 0;
+    if (fx) { x_step = -x_step; off += width - 1; }
+    if (fy) { y_step = -y_step; off += (int64_t)p->owidth * (height - 1); }
+    if (t) { std::swap(width, height); std::swap(x_step, y_step); }
+    void *m = nullptr;
+    int rc = rot.get((size_t)width * (size_t)height * esz, &m); if (rc) return rc;
+    if (f.src_is_u16) ipk::launch_rotate1<uint16_t>(reinterpret_cast<const uint16_t *>(base), (size_t)width, (size_t)height, off, x_step, y_step, static_cast<uint16_t *>(m), S(stream));
+    else ipk::launch_rotate1<float>(reinterpret_cast<const float *>(base), (size_t)width, (size_t)height, off, x_step, y_step, static_cast<float *>(m), S(stream));
+    HIPCHK(hipGetLastError());
+    // the demosaic role of a rotated-space pixel = the role of the sensor pixel it came from: depends on the parities only
+    for (int pr = 0; pr < 2; ++pr) for (int pc = 0; pc < 2; ++pc) {
+      const int64_t ro = t ? (fy ? (int64_t)p->height - 1 - pc : pc) : (fy ? (int64_t)p->height - 1 - pr : pr);
+      const int64_t co = t ? (fx ? (int64_t)p->width - 1 - pr : pr) : (fx ? (int64_t)p->width - 1 - pc : pc);
+      f.roles[2 * pr + pc] = (int)((((ro + yoff) & 1) << 1) | ((co + xoff) & 1));
+    }
+    f.ori = ori;
+    f.src = m; f.src_aligned4 = (width % 2 == 0);
+    f.width = (size_t)width; f.height = (size_t)height; f.owidth = (size_t)width;
+    f.out_r0 = 0; f.out_r1 = (size_t)height; f.row_off = 0;
+    xoff = 0; yoff = 0;
+  }
   f.black0 = p->black0; f.white0 = p->white0;
   f.exact_norm = validate_cdiv_for_range(p->black0, p->white0 - p->black0, f.src_is_u16) ? 0 : 1;
   f.xoff = xoff; f.yoff = yoff;
@@ -658,9 +690,16 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
   f.out_type = p->out_type;
   f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
   f.num_cus = g.num_cus;
-  ipk::launch_fused_bayer(f, S(stream));
+  if (ipk::launch_fused_bayer(f, S(stream)) != 0) return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for these parameters");
   HIPCHK(hipGetLastError());
   return IPK_OK;
+}
+int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream) { return fused_impl(p, src, dst, stream, 0); }
+int ipk_raw_to_srgb_oriented(const ipk_fused_params *p, const void *src, int orientation, void *dst, size_t *out_width, size_t *out_height, void *stream) {
+  if (!p || !out_width || !out_height) return fail(IPK_ERR_INVALID, "null argument");
+  if (orientation == IPK_OR_NORMAL || orientation == IPK_OR_UNKNOWN) { *out_width = p->width; *out_height = p->height; return fused_impl(p, src, dst, stream, 0); }
+  *out_width = p->height; *out_height = p->width;
+  return fused_impl(p, src, dst, stream, orientation);
 }
 
 // OpToLab::run + OpBaseCurve::run + OpFromLab::run + OpGamma::run (colorspaces.rs:89-112, curves.rs:33-49, colorspaces.rs:127-137,
@@ -908,10 +947,19 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       // An orientation other than Normal (every portrait shot): OpTransform is the last op and a pure permutation of
       // pixels, so gofloat..gamma still run as the one fused launch, into a scratch buffer, and rotate_buffer (+ the
       // quantise loop) follows -- 2 or 3 launches instead of 7.
+      size_t ow = 0, oh = 0;
+      // Rotate90 / Rotate270 of a Bayer frame (the portrait shot): permute the 1-channel mosaic and run the fused kernel in rotated
+      // space -- no pass over the 3-channel result at all
+      rc = ipk_raw_to_srgb_oriented(&fp, src, orientation, dst, &ow, &oh, stream);
+      if (rc == IPK_OK) {
+        if (ow != fw || oh != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", ow, oh, fw, fh);
+        if (used_fused) *used_fused = 1;
+        return IPK_OK;
+      }
+      if (rc != IPK_ERR_UNSUPPORTED) return rc;
       Scratch sc2(S(stream));
       void *tmp = nullptr;
-      size_t ow = 0, oh = 0;
-      // the fused kernel quantises on the way out; the permutation then runs on the 3- or 6-byte pixels (it commutes with the
+      // otherwise: the fused kernel quantises on the way out; the permutation then runs on the 3- or 6-byte pixels (it commutes with the
       // per-sample output8bit / output16bit)
       rc = sc2.get(r.width * r.height * 3 * (out_type == IPK_OUT_F32 ? sizeof(float) : (out_type == IPK_OUT_U8 ? 1 : 2)), &tmp); if (rc) return rc;
       rc = ipk_raw_to_srgb(&fp, src, tmp, stream); if (rc < 0) return rc;

@@ -898,6 +898,46 @@ void launch_rotate(const T *src3, size_t owidth, size_t oheight, int64_t base_of
 template void launch_rotate<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, float *, hipStream_t);
 template void launch_rotate<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, uint8_t *, hipStream_t);
 template void launch_rotate<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, uint16_t *, hipStream_t);
+// The same permutation on a 1-channel image (the sensor mosaic, u16 or f32), source addressed through its own pitch and crop
+// window: `base`, `x_step`, `y_step` in source elements.  Feeds the fused kernel's rotated-space variants.
+template <typename T>
+__global__ void k_rotate1(const T *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset, int64_t x_step, int64_t y_step,
+                          T *__restrict__ dst) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= owidth) return;
+  for (uint32_t row = blockIdx.y; row < oheight; row += gridDim.y) dst[(size_t)row * owidth + col] = src[base_offset + y_step * (int64_t)row + x_step * (int64_t)col];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_rotate1_transposed(const T *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
+                                                           int64_t x_step, int64_t y_step, T *__restrict__ dst) {
+  __shared__ T tile[32][33];
+  const uint32_t C0 = blockIdx.x * 32, R0 = blockIdx.y * 32;
+  const uint32_t a = threadIdx.x & 31u, b = threadIdx.x >> 5;
+  #pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t lr = a, lc = b + 8 * i;                              // lanes run along the output rows = consecutive source elements
+    const uint32_t r = R0 + lr, c = C0 + lc;
+    if (r < oheight && c < owidth) tile[lc][lr] = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
+  }
+  __syncthreads();
+  #pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t lc = a, lr = b + 8 * i;                              // lanes run along the output columns
+    const uint32_t r = R0 + lr, c = C0 + lc;
+    if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = tile[lc][lr];
+  }
+}
+template <typename T>
+void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_offset, int64_t x_step, int64_t y_step, T *dst, hipStream_t s) {
+  if ((y_step == 1 || y_step == -1) && x_step != 1 && x_step != -1 && (oheight + 31) / 32 <= 65535) {
+    hipLaunchKernelGGL(k_rotate1_transposed<T>, dim3((unsigned)((owidth + 31) / 32), (unsigned)((oheight + 31) / 32), 1), dim3(256), 0, s,
+                       src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
+    return;
+  }
+  hipLaunchKernelGGL(k_rotate1<T>, grid_rows(owidth, oheight, 256), dim3(256), 0, s, src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
+}
+template void launch_rotate1<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, float *, hipStream_t);
+template void launch_rotate1<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, uint16_t *, hipStream_t);
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(k_output8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
 }
@@ -960,6 +1000,9 @@ struct FusedArgs {
   uint32_t gen_pw, gen_ph;    // pattern width / height (both divide 48)
   int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not show that every normalised sample is ordinary
   int px_guard;               // 0: u16 source with host-checked levels and parameters -> the variant without per-pixel input guards
+  int ori;                    // ROT variants: the orientation (ipk_orientation) whose rotated space this launch works in
+  int roles[4];               // ROT variants: demosaic role (0 R, 1 G on the R row, 2 G on the B row, 3 B) of the rotated-space pixel with
+                              // parities (row & 1, column & 1) -> roles[2 * (row & 1) + (column & 1)]
   SplineDev spline;
 };
 
@@ -1022,6 +1065,58 @@ __device__ __forceinline__ float4 demosaic_inner_px(float nw, float n, float ne,
   if (ROLE == 1) return make_float4(horiz, own, vert, 0.0f);
   if (ROLE == 2) return make_float4(vert, own, horiz, 0.0f);
   return make_float4(diag, cross, own, 0.0f);
+}
+
+// ---- rotated space (ROT variants) --------------------------------------------------------------------------------------
+// The launch works on the mosaic already permuted into the output orientation (rotate_buffer's permutation, transform.rs:87-144,
+// applied to the 1-channel sensor data instead of the 3-channel result), so that the output needs no permutation pass.  The
+// demosaic must still add its taps in the reference's order, which is defined in the ORIGINAL orientation: the neighbour the
+// reference calls (dy, dx) sits at a mapped offset in rotated space.  With (transpose, flip_x, flip_y) = to_flips(orientation):
+// not transposed: (dy', dx') = (flip_y ? -dy : dy, flip_x ? -dx : dx); transposed: (dy', dx') = (flip_x ? -dx : dx, flip_y ? -dy : dy).
+template <int ORI> struct OriFlips {   // ipk_orientation -> (transpose, flip_x, flip_y): Normal fff, HFlip ftf, Rot180 ftt, VFlip fft, Transpose tff, Rot90 tft, Transverse ttt, Rot270 ttf
+  static constexpr bool t = ORI >= 4, fx = ORI == 1 || ORI == 2 || ORI == 6 || ORI == 7, fy = ORI == 2 || ORI == 3 || ORI == 5 || ORI == 6;
+  static constexpr int ry(int y, int x) { return t ? (fx ? 2 - x : x) : (fy ? 2 - y : y); }   // rotated-space window row of the original tap (y, x)
+  static constexpr int rx(int y, int x) { return t ? (fy ? 2 - y : y) : (fx ? 2 - x : x); }
+};
+// the 3 x 3 window of rotated-space pixel j (rows pw / cw / nw, columns j .. j+2) renamed into the original orientation's tap order
+template <int ORI>
+__device__ __forceinline__ void ori_window(const float pw[6], const float cw[6], const float nw[6], int j, float t[9]) {
+  const float *rows[3] = {pw, cw, nw};
+  #pragma unroll
+  for (int y = 0; y < 3; ++y) {
+    #pragma unroll
+    for (int x = 0; x < 3; ++x) t[3 * y + x] = rows[OriFlips<ORI>::ry(y, x)][j + OriFlips<ORI>::rx(y, x)];
+  }
+}
+template <int ORI>
+__device__ __forceinline__ uint32_t ori_mask(uint32_t m_rot) {   // validity bits of the rotated-space window -> bits in the original tap order
+  uint32_t m = 0;
+  #pragma unroll
+  for (int y = 0; y < 3; ++y) {
+    #pragma unroll
+    for (int x = 0; x < 3; ++x) m |= ((m_rot >> (3 * OriFlips<ORI>::ry(y, x) + OriFlips<ORI>::rx(y, x))) & 1u) << (3 * y + x);
+  }
+  return m;
+}
+template <int ROLE, int ORI>
+__device__ __forceinline__ float4 demosaic_inner_ori(const float pw[6], const float cw[6], const float nw[6], int j) {
+  float t[9];
+  ori_window<ORI>(pw, cw, nw, j, t);
+  return demosaic_inner_px<ROLE>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
+}
+// the four interior pixels of a lane in rotated space (transposing orientations): even pixels have role RE, odd ones RE ^ 2
+template <int ORI>
+__device__ __forceinline__ void demosaic_rot_row(int role_e, const float pw[6], const float cw[6], const float nw[6], float4 px[4]) {
+  if (role_e == 0) { px[0] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 3); }
+  else if (role_e == 2) { px[0] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 3); }
+  else if (role_e == 1) { px[0] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 3); }
+  else { px[0] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 3); }
+}
+__device__ __forceinline__ float4 demosaic_inner_role(int role, const float t[9]) {   // role is wave-uniform
+  if (role == 0) return demosaic_inner_px<0>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
+  if (role == 1) return demosaic_inner_px<1>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
+  if (role == 2) return demosaic_inner_px<2>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
+  return demosaic_inner_px<3>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
 }
 
 // ---- generic-CFA mode (X-Trans and any other filter without a fourth colour) --------------------------------------
@@ -1445,7 +1540,8 @@ struct RgbeStage {
 // CMN = the common parameter set is compiled in: fast point-wise form allowed, a base curve of 2 or 3 knots, the validated fast
 // normalisation, gamma on unless the output is 16-bit (output_16bit forces linear).  Runtime-uniform flags cost scalar
 // branches in the row loop; with them folded away the f32 kernel is 4 % faster.  Anything else runs the CMN = false variant.
-template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false>
+// ROT = the launch works in rotated space (see OriFlips): Bayer filters, orientations Rotate90 / Rotate270 (every portrait shot).
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
@@ -1637,6 +1733,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
         if (!literal) px[j] = demosaic_gen_px(rowcells + cxo[j], t);
         else px[j] = demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, 0x1FFu);
       }
+    } else if (ROT) {
+      // rotated space: the role of a pixel comes from the host's table over (row, column) parity, its taps renamed into the
+      // original orientation's order; both choices are wave-uniform
+      // (along a rotated-space row of a transposing orientation the sensor COLUMN is fixed and the sensor row alternates: the odd
+      // pixels' role is the even pixels' role with its row bit flipped)
+      const int role_e = a.roles[2 * (int)(r & 1u) + (int)xo];
+      if (a.ori == 5) demosaic_rot_row<5>(role_e, pw, cw, nw, px); else demosaic_rot_row<7>(role_e, pw, cw, nw, px);
     } else if (pr == 0) {
       if (xo == 0) {
         px[0] = demosaic_inner_px<0>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
@@ -1676,6 +1779,12 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
             if (r == Hm1) m &= ~0x1C0u;
             if (c == 0) m &= ~0x049u;
             if (c == Wm1) m &= ~0x124u;
+            if (ROT) {
+              float to[9]; uint32_t mo;
+              if (a.ori == 5) { ori_window<5>(pw, cw, nw, j, to); mo = ori_mask<5>(m); } else { ori_window<7>(pw, cw, nw, j, to); mo = ori_mask<7>(m); }
+              const int role = a.roles[2 * (int)(r & 1u) + (int)((j + xo) & 1u)];
+              px[j] = demosaic_edge_dispatch(to, mo, role >> 1, role & 1);
+            } else
             px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, m) : demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
           }
         }
@@ -1792,6 +1901,11 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, false, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
+  if (a.ori != 0) {                                      // rotated space: the common parameter set only (launch_fused_bayer checked)
+    if (a.px_guard == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, false, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, true, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    return;
+  }
   // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards
   if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
@@ -1864,6 +1978,15 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
   a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check; a.px_guard = f.px_guard;
+  a.ori = f.ori;
+  for (int i = 0; i < 4; ++i) a.roles[i] = f.roles[i];
+  if (f.ori != 0) {
+    // rotated space exists for Rotate90 / Rotate270, Bayer filters and the common parameter set (the CMN variants) only;
+    // anything else: the caller permutes the output instead
+    const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
+                        std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
+    if (!common || f.gen_cells || (f.ori != 5 && f.ori != 7)) return -2;
+  }
 
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks, 2);

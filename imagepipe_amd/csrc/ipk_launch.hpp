@@ -72,8 +72,14 @@ struct FusedLaunch {
   int px_guard;                  // 0: u16 source whose levels and parameters the host found ordinary (kernel variant without per-pixel input guards)
   const float *gen_cells; int gen_pw, gen_ph, gen_check;   // generic-CFA mode (device cell records) or null: RGGB phase (xoff, yoff)
   int num_cus;
+  int ori;                       // 0, or the ipk_orientation (Rotate90 / Rotate270) in whose rotated space the launch works: src is the permuted mosaic
+  int roles[4];                  // ori != 0: demosaic role of the rotated-space pixel with parities (row & 1, col & 1), index 2 * row parity + col parity
 };
+// returns 0, or -2 when f.ori != 0 and the parameters have no rotated-space variant (nothing is launched)
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);
+// rotate_buffer's permutation on a 1-channel image through an arbitrary source pitch / window (steps in source elements)
+template <typename T>
+void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_offset, int64_t x_step, int64_t y_step, T *dst, hipStream_t s);
 // OpToLab..OpGamma in one pass over a 4-channel f32 buffer (src/dst, mul4, cm12, rgbm9, curve, linear, tables, fast_ok are read)
 int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s);
 // run_other + OpToLab..OpGamma + quantisation in one pass over an RGB8 / RGB16 raster (npix >= 256; f.out_type selects the output)

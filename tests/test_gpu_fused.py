@@ -644,3 +644,26 @@ def test_staged_pipeline_on_alternating_streams(ipa, orc):
     wants = [orc.pipeline_run(_oracle_desc(orc, f, "GBRG")) for f in frames]
     for i, o in outs:
         assert_bits_equal(o.numpy(), wants[i], "alternating streams, frame %d" % i)
+
+
+@pytest.mark.parametrize("is_float", [False, True])
+@pytest.mark.parametrize("cfa", ["RGGB", "GRBG", "GBRG", "BGGR"])
+@pytest.mark.parametrize("shape,crops", [((256, 300), (0, 0, 0, 0)), ((257, 301), (0, 0, 0, 0)), ((300, 513), (1, 2, 0, 3)), ((321, 256), (3, 0, 1, 1)), ((512, 258), (0, 1, 1, 0))])
+def test_portrait_orientations_run_in_rotated_space(ipa, orc, cfa, shape, crops, is_float):
+    """Rotate90 / Rotate270 of a Bayer frame: the mosaic is permuted and the fused kernel works in rotated space (taps renamed into
+    the original orientation's order, role table from the sensor parities, edge masks mapped) -- every Bayer phase, odd and even
+    sizes, odd crops, all three outputs, bit-identical to the oracle's pipeline with OpTransform"""
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 600 + h + w, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    for rotation in (1, 3):
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops))
+        pipe.ops.transform.rotation = rotation
+        want = orc.pipeline_run(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation))
+        got = pipe.run()
+        assert pipe.last_used_fused
+        assert_bits_equal(got.numpy(), want, "portrait rotation=%d %s %r %r" % (rotation, cfa, shape, crops))
+        ww, hh, o8 = pipe.output_8bit()
+        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
+        ww, hh, o16 = pipe.output_16bit()
+        assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
