@@ -41,6 +41,7 @@ struct Context {
   void *lut_plain[3] = {nullptr, nullptr, nullptr};      // device, 8193 floats
   float xyz_d65_33[9];
   std::map<std::string, DevCfa> cfa_cache;
+  std::map<std::string, float *> rot_cells;              // generic-CFA cell records laid out for a rotated space (pattern, orientation, frame phase)
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
   struct Block { void *p; size_t bytes; bool busy; hipStream_t last; };      // last: the stream its most recent user enqueued on
   std::vector<Block> pool;
@@ -263,6 +264,8 @@ void ipk_shutdown(void) {
   for (int t = 0; t < 3; ++t) { if (g.lut_pairs[t]) (void)hipFree(g.lut_pairs[t]); g.lut_pairs[t] = nullptr; if (g.lut_plain[t]) (void)hipFree(g.lut_plain[t]); g.lut_plain[t] = nullptr; }
   for (auto &kv : g.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); if (kv.second.gen_cells) (void)hipFree(kv.second.gen_cells); }
   g.cfa_cache.clear();
+  for (auto &kv : g.rot_cells) (void)hipFree(kv.second);
+  g.rot_cells.clear();
   for (auto &b : g.pool) (void)hipFree(b.p);
   g.pool.clear();
   host_lanes_release();
@@ -589,6 +592,37 @@ int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *stream) {
 // ------------------------------------------------------------------------------------------
 // fused raw -> sRGB
 // ------------------------------------------------------------------------------------------
+// Generic-CFA cell records for a launch in rotated space: the record of rotated-space pixel (y', x') is the record of the sensor
+// pixel it came from (its taps stay in the sensor's order; the kernel renames the window).  The rotated pattern has the sensor
+// pattern's dimensions swapped (transposing orientations) and a phase that depends on the frame size through the flips.
+static int get_rot_cells(const char *pat, const ipk::Cfa &cfa, int ori, size_t width, size_t height, const float **out) {
+  bool t, fx, fy;
+  ipk::orientation_to_flips(ori, t, fx, fy);
+  const int pw = cfa.width, ph = cfa.height;
+  char key[160];
+  snprintf(key, sizeof(key), "%s|%d|%d|%d", pat, ori, (int)(width % (size_t)pw), (int)(height % (size_t)ph));
+  std::lock_guard<std::mutex> lk(g.mu);
+  auto it = g.rot_cells.find(key);
+  if (it != g.rot_cells.end()) { *out = it->second; return IPK_OK; }
+  std::vector<float> cells;
+  if (!cfa.gen_cells(cells)) return fail(IPK_ERR_UNSUPPORTED, "CFA has a fourth colour");
+  const int rpw = t ? ph : pw, rph = t ? pw : ph;          // rotated pattern: width follows the sensor rows when transposed
+  std::vector<float> rot((size_t)rpw * rph * ipk::Cfa::kGenCellFloats);
+  for (int y = 0; y < rph; ++y)
+    for (int x = 0; x < rpw; ++x) {
+      const int64_t ro = t ? (fy ? (int64_t)height - 1 - x : x) : (fy ? (int64_t)height - 1 - y : y);
+      const int64_t co = t ? (fx ? (int64_t)width - 1 - y : y) : (fx ? (int64_t)width - 1 - x : x);
+      const int sy = (int)(((ro % ph) + ph) % ph), sx = (int)(((co % pw) + pw) % pw);
+      std::memcpy(&rot[((size_t)y * rpw + x) * ipk::Cfa::kGenCellFloats], &cells[((size_t)sy * pw + sx) * ipk::Cfa::kGenCellFloats], ipk::Cfa::kGenCellFloats * sizeof(float));
+    }
+  float *dev = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&dev), rot.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(dev, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice));
+  g.rot_cells[key] = dev;
+  *out = dev;
+  return IPK_OK;
+}
+
 // ori = 0: the frame as it is.  ori = Rotate90 / Rotate270 (Bayer filters, whole frames): the mosaic is first permuted into the
 // output orientation (1 channel: 2 or 4 bytes per pixel instead of the 12 of the result) and the kernel works in rotated space,
 // so that dst receives OpTransform's output directly; IPK_ERR_UNSUPPORTED (nothing launched) when no such variant exists.
@@ -625,7 +659,7 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.ori = 0; f.roles[0] = f.roles[1] = f.roles[2] = f.roles[3] = 0;
   Scratch rot(S(stream));
   if (ori != 0) {
-    if (band || !bayer || (ori != IPK_OR_ROT90 && ori != IPK_OR_ROT270) || p->height < 256)
+    if (band || (ori != IPK_OR_ROT90 && ori != IPK_OR_ROT270) || p->height < 256)
       return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for this frame");
     bool t, fx, fy;
     ipk::orientation_to_flips(ori, t, fx, fy);
@@ -655,6 +689,11 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.exact_norm = validate_cdiv_for_range(p->black0, p->white0 - p->black0, f.src_is_u16) ? 0 : 1;
   f.xoff = xoff; f.yoff = yoff;
   f.gen_cells = bayer ? nullptr : dev.gen_cells; f.gen_pw = dev.gen_pw; f.gen_ph = dev.gen_ph;
+  if (ori != 0 && !bayer) {                                // rotated space: the pattern's dimensions swap, the records follow the sensor pixels
+    const float *rc_dev = nullptr;
+    int rc = get_rot_cells(p->cfa, cfa, ori, p->width, p->height, &rc_dev); if (rc) return rc;
+    f.gen_cells = rc_dev; f.gen_pw = dev.gen_ph; f.gen_ph = dev.gen_pw;
+  }
   // generic-CFA mode sums up to nine normalised samples and divides by a constant: u16 kernels check their samples only
   // when the levels allow one outside [2^-60, 2^60] (f32 kernels always check)
   f.gen_check = (!bayer && f.src_is_u16 && !gen_levels_ok_u16(p->black0, p->white0 - p->black0)) ? 1 : 0;

@@ -1729,7 +1729,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       const bool literal = fP | fC | fN;
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
+        float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
+        if (ROT) { if (a.ori == 5) ori_window<5>(pw, cw, nw, j, t); else ori_window<7>(pw, cw, nw, j, t); }   // rotated space: the cell records are the sensor pixel's, its taps in their original order
         if (!literal) px[j] = demosaic_gen_px(rowcells + cxo[j], t);
         else px[j] = demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, 0x1FFu);
       }
@@ -1783,7 +1784,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
               float to[9]; uint32_t mo;
               if (a.ori == 5) { ori_window<5>(pw, cw, nw, j, to); mo = ori_mask<5>(m); } else { ori_window<7>(pw, cw, nw, j, to); mo = ori_mask<7>(m); }
               const int role = a.roles[2 * (int)(r & 1u) + (int)((j + xo) & 1u)];
-              px[j] = demosaic_edge_dispatch(to, mo, role >> 1, role & 1);
+              px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), to, mo) : demosaic_edge_dispatch(to, mo, role >> 1, role & 1);
             } else
             px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, m) : demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
           }
@@ -1894,16 +1895,17 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 #endif
   const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
                       std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
+  if (a.ori != 0) {                                      // rotated space: the common parameter set only (launch_fused_bayer checked)
+    if (a.gen_cells) { hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, true, true, true, true>), dim3(grid), dim3(tpb), 0, s, a); return; }
+    if (a.px_guard == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, false, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, true, true, true>), dim3(grid), dim3(tpb), 0, s, a);
+    return;
+  }
   if (a.gen_cells) {                                     // generic-CFA mode: one load flavour per source type
     constexpr bool V = sizeof(SrcT) == 4;
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true, true, true>), dim3(grid), dim3(tpb), 0, s, a);
     else if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, true, true>), dim3(grid), dim3(tpb), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, V, OUT, false, true>), dim3(grid), dim3(tpb), 0, s, a);
-    return;
-  }
-  if (a.ori != 0) {                                      // rotated space: the common parameter set only (launch_fused_bayer checked)
-    if (a.px_guard == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, false, true, true>), dim3(grid), dim3(tpb), 0, s, a);
-    else hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, true, true, true>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
   // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards
@@ -1981,11 +1983,11 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.ori = f.ori;
   for (int i = 0; i < 4; ++i) a.roles[i] = f.roles[i];
   if (f.ori != 0) {
-    // rotated space exists for Rotate90 / Rotate270, Bayer filters and the common parameter set (the CMN variants) only;
+    // rotated space exists for Rotate90 / Rotate270 and the common parameter set (the CMN variants) only;
     // anything else: the caller permutes the output instead
     const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
                         std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
-    if (!common || f.gen_cells || (f.ori != 5 && f.ori != 7)) return -2;
+    if (!common || (f.ori != 5 && f.ori != 7)) return -2;
   }
 
   unsigned blocks;

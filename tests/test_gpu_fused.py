@@ -656,6 +656,11 @@ def test_portrait_orientations_run_in_rotated_space(ipa, orc, cfa, shape, crops,
     h, w = shape
     raw = util.noise_u16(util.SEED + 600 + h + w, h, w)
     src = raw.astype(np.float32) if is_float else raw
+    if is_float:                                               # guarded samples (denormal, huge, non-finite): the literal redo in rotated space
+        with np.errstate(over="ignore"):
+            sp = util.SPECIALS * np.float32(16383.0)
+        src[33, 20: 20 + sp.size] = sp
+        src[100, 150] = -np.inf; src[h - 1, 0] = np.nan; src[0, w - 1] = np.float32(3e38)
     for rotation in (1, 3):
         pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops))
         pipe.ops.transform.rotation = rotation
@@ -667,3 +672,30 @@ def test_portrait_orientations_run_in_rotated_space(ipa, orc, cfa, shape, crops,
         assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
         ww, hh, o16 = pipe.output_16bit()
         assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
+
+
+
+@pytest.mark.parametrize("is_float", [False, True])
+@pytest.mark.parametrize("cfa", [XT, W8X2])
+@pytest.mark.parametrize("shape,crops", [((258, 300), (0, 0, 0, 0)), ((263, 301), (0, 0, 0, 0)), ((300, 517), (1, 2, 0, 3)), ((331, 262), (5, 0, 1, 4))])
+def test_portrait_orientations_generic_cfa(ipa, orc, cfa, shape, crops, is_float):
+    """The same for filters in generic-CFA mode (X-Trans 6 x 6 and an 8 x 2 pattern): the cell records are laid out for the rotated
+    pattern (dimensions swapped, phase from the frame size), the taps keep the sensor's order; f32 frames carry NaN / inf /
+    denormal samples, whose row windows take the literal bins in rotated space as well"""
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 620 + h + w, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    if is_float:
+        with np.errstate(over="ignore"):
+            sp = util.SPECIALS * np.float32(16383.0)
+        src[40, 30: 30 + sp.size] = sp
+        src[90, 200] = -np.inf; src[150, 7] = np.nan; src[h - 1, w - 1] = np.inf; src[0, 0] = np.float32(1e-40)
+    for rotation in (1, 3):
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops))
+        pipe.ops.transform.rotation = rotation
+        want = orc.pipeline_run(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation))
+        got = pipe.run()
+        assert pipe.last_used_fused
+        assert_bits_equal(got.numpy(), want, "portrait generic rotation=%d %r %r" % (rotation, shape, crops))
+        ww, hh, o8 = pipe.output_8bit()
+        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
