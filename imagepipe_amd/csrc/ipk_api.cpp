@@ -659,10 +659,10 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.ori = 0; f.roles[0] = f.roles[1] = f.roles[2] = f.roles[3] = 0;
   Scratch rot(S(stream));
   if (ori != 0) {
-    if (band || (ori != IPK_OR_ROT90 && ori != IPK_OR_ROT270) || p->height < 256)
-      return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for this frame");
     bool t, fx, fy;
     ipk::orientation_to_flips(ori, t, fx, fy);
+    if (band || ori < 1 || ori > 7 || (t ? p->height : p->width) < 256)               // the rotated frame must be at least one 256-pixel strip wide
+      return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for this frame");
     // rotate_buffer's index walk (transform.rs:102-128) over the crop window of the pitched 1-channel source
     int64_t width = (int64_t)p->width, height = (int64_t)p->height, x_step = 1, y_step = (int64_t)p->owidth, off = 0;
     if (fx) { x_step = -x_step; off += width - 1; }
@@ -692,7 +692,9 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   if (ori != 0 && !bayer) {                                // rotated space: the pattern's dimensions swap, the records follow the sensor pixels
     const float *rc_dev = nullptr;
     int rc = get_rot_cells(p->cfa, cfa, ori, p->width, p->height, &rc_dev); if (rc) return rc;
-    f.gen_cells = rc_dev; f.gen_pw = dev.gen_ph; f.gen_ph = dev.gen_pw;
+    bool tt, fxx, fyy; ipk::orientation_to_flips(ori, tt, fxx, fyy);
+    f.gen_cells = rc_dev;
+    if (tt) { f.gen_pw = dev.gen_ph; f.gen_ph = dev.gen_pw; }
   }
   // generic-CFA mode sums up to nine normalised samples and divides by a constant: u16 kernels check their samples only
   // when the levels allow one outside [2^-60, 2^60] (f32 kernels always check)
@@ -737,7 +739,8 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
 int ipk_raw_to_srgb_oriented(const ipk_fused_params *p, const void *src, int orientation, void *dst, size_t *out_width, size_t *out_height, void *stream) {
   if (!p || !out_width || !out_height) return fail(IPK_ERR_INVALID, "null argument");
   if (orientation == IPK_OR_NORMAL || orientation == IPK_OR_UNKNOWN) { *out_width = p->width; *out_height = p->height; return fused_impl(p, src, dst, stream, 0); }
-  *out_width = p->height; *out_height = p->width;
+  if (orientation < 0 || orientation > 8) return fail(IPK_ERR_INVALID, "bad orientation");
+  { bool t, fx, fy; ipk::orientation_to_flips(orientation, t, fx, fy); *out_width = t ? p->height : p->width; *out_height = t ? p->width : p->height; }
   return fused_impl(p, src, dst, stream, orientation);
 }
 

@@ -1109,13 +1109,43 @@ __device__ __forceinline__ float4 demosaic_inner_ori(const float pw[6], const fl
   ori_window<ORI>(pw, cw, nw, j, t);
   return demosaic_inner_px<ROLE>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
 }
-// the four interior pixels of a lane in rotated space (transposing orientations): even pixels have role RE, odd ones RE ^ 2
+// the four interior pixels of a lane in rotated space.  Along a rotated-space row of a transposing orientation the sensor column is
+// fixed and the sensor row alternates (odd pixels: the even pixels' role with its row bit flipped), otherwise the other way round.
+template <int RE, int ORI>
+__device__ __forceinline__ void demosaic_rot_row4(const float pw[6], const float cw[6], const float nw[6], float4 px[4]) {
+  constexpr int RO = RE ^ (OriFlips<ORI>::t ? 2 : 1);
+  px[0] = demosaic_inner_ori<RE, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<RO, ORI>(pw, cw, nw, 1);
+  px[2] = demosaic_inner_ori<RE, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<RO, ORI>(pw, cw, nw, 3);
+}
 template <int ORI>
 __device__ __forceinline__ void demosaic_rot_row(int role_e, const float pw[6], const float cw[6], const float nw[6], float4 px[4]) {
-  if (role_e == 0) { px[0] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 3); }
-  else if (role_e == 2) { px[0] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<2, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<0, ORI>(pw, cw, nw, 3); }
-  else if (role_e == 1) { px[0] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 3); }
-  else { px[0] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 0); px[1] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 1); px[2] = demosaic_inner_ori<3, ORI>(pw, cw, nw, 2); px[3] = demosaic_inner_ori<1, ORI>(pw, cw, nw, 3); }
+  if (role_e == 0) demosaic_rot_row4<0, ORI>(pw, cw, nw, px);
+  else if (role_e == 1) demosaic_rot_row4<1, ORI>(pw, cw, nw, px);
+  else if (role_e == 2) demosaic_rot_row4<2, ORI>(pw, cw, nw, px);
+  else demosaic_rot_row4<3, ORI>(pw, cw, nw, px);
+}
+// wave-uniform dispatch over the seven non-Normal orientations
+__device__ __forceinline__ void demosaic_rot_row_dyn(int ori, int role_e, const float pw[6], const float cw[6], const float nw[6], float4 px[4]) {
+  switch (ori) {
+    case 1: demosaic_rot_row<1>(role_e, pw, cw, nw, px); break;
+    case 2: demosaic_rot_row<2>(role_e, pw, cw, nw, px); break;
+    case 3: demosaic_rot_row<3>(role_e, pw, cw, nw, px); break;
+    case 4: demosaic_rot_row<4>(role_e, pw, cw, nw, px); break;
+    case 5: demosaic_rot_row<5>(role_e, pw, cw, nw, px); break;
+    case 6: demosaic_rot_row<6>(role_e, pw, cw, nw, px); break;
+    default: demosaic_rot_row<7>(role_e, pw, cw, nw, px); break;
+  }
+}
+__device__ __forceinline__ uint32_t ori_window_dyn(int ori, const float pw[6], const float cw[6], const float nw[6], int j, float t[9], uint32_t m_rot) {
+  switch (ori) {
+    case 1: ori_window<1>(pw, cw, nw, j, t); return ori_mask<1>(m_rot);
+    case 2: ori_window<2>(pw, cw, nw, j, t); return ori_mask<2>(m_rot);
+    case 3: ori_window<3>(pw, cw, nw, j, t); return ori_mask<3>(m_rot);
+    case 4: ori_window<4>(pw, cw, nw, j, t); return ori_mask<4>(m_rot);
+    case 5: ori_window<5>(pw, cw, nw, j, t); return ori_mask<5>(m_rot);
+    case 6: ori_window<6>(pw, cw, nw, j, t); return ori_mask<6>(m_rot);
+    default: ori_window<7>(pw, cw, nw, j, t); return ori_mask<7>(m_rot);
+  }
 }
 __device__ __forceinline__ float4 demosaic_inner_role(int role, const float t[9]) {   // role is wave-uniform
   if (role == 0) return demosaic_inner_px<0>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]);
@@ -1545,7 +1575,7 @@ struct RgbeStage {
 // CMN = the common parameter set is compiled in: fast point-wise form allowed, a base curve of 2 or 3 knots, the validated fast
 // normalisation, gamma on unless the output is 16-bit (output_16bit forces linear).  Runtime-uniform flags cost scalar
 // branches in the row loop; with them folded away the f32 kernel is 4 % faster.  Anything else runs the CMN = false variant.
-// ROT = the launch works in rotated space (see OriFlips): Bayer filters, orientations Rotate90 / Rotate270 (every portrait shot).
+// ROT = the launch works in rotated space (see OriFlips): any of the seven non-Normal orientations, wave-uniform dispatch on a.ori.
 template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
@@ -1735,17 +1765,14 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
-        if (ROT) { if (a.ori == 5) ori_window<5>(pw, cw, nw, j, t); else ori_window<7>(pw, cw, nw, j, t); }   // rotated space: the cell records are the sensor pixel's, its taps in their original order
+        if (ROT) (void)ori_window_dyn(a.ori, pw, cw, nw, j, t, 0x1FFu);   // rotated space: the cell records are the sensor pixel's, its taps in their original order
         if (!literal) px[j] = demosaic_gen_px(rowcells + cxo[j], t);
         else px[j] = demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, 0x1FFu);
       }
     } else if (ROT) {
       // rotated space: the role of a pixel comes from the host's table over (row, column) parity, its taps renamed into the
       // original orientation's order; both choices are wave-uniform
-      // (along a rotated-space row of a transposing orientation the sensor COLUMN is fixed and the sensor row alternates: the odd
-      // pixels' role is the even pixels' role with its row bit flipped)
-      const int role_e = a.roles[2 * (int)(r & 1u) + (int)xo];
-      if (a.ori == 5) demosaic_rot_row<5>(role_e, pw, cw, nw, px); else demosaic_rot_row<7>(role_e, pw, cw, nw, px);
+      demosaic_rot_row_dyn(a.ori, a.roles[2 * (int)(r & 1u) + (int)xo], pw, cw, nw, px);
     } else if (pr == 0) {
       if (xo == 0) {
         px[0] = demosaic_inner_px<0>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
@@ -1786,8 +1813,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
             if (c == 0) m &= ~0x049u;
             if (c == Wm1) m &= ~0x124u;
             if (ROT) {
-              float to[9]; uint32_t mo;
-              if (a.ori == 5) { ori_window<5>(pw, cw, nw, j, to); mo = ori_mask<5>(m); } else { ori_window<7>(pw, cw, nw, j, to); mo = ori_mask<7>(m); }
+              float to[9];
+              const uint32_t mo = ori_window_dyn(a.ori, pw, cw, nw, j, to, m);
               const int role = a.roles[2 * (int)(r & 1u) + (int)((j + xo) & 1u)];
               px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), to, mo) : demosaic_edge_dispatch(to, mo, role >> 1, role & 1);
             } else
@@ -1988,11 +2015,11 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.ori = f.ori;
   for (int i = 0; i < 4; ++i) a.roles[i] = f.roles[i];
   if (f.ori != 0) {
-    // rotated space exists for Rotate90 / Rotate270 and the common parameter set (the CMN variants) only;
+    // rotated space exists for the common parameter set (the CMN variants) only;
     // anything else: the caller permutes the output instead
     const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
                         std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
-    if (!common || (f.ori != 5 && f.ori != 7)) return -2;
+    if (!common || f.ori < 1 || f.ori > 7) return -2;
   }
 
   unsigned blocks;

@@ -266,10 +266,11 @@ typedef struct {
  * IPK_ERR_UNSUPPORTED for RGBE-style filters (callers then run the staged ops). */
 IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
 /* ipk_raw_to_srgb followed by OpTransform (src/ops/transform.rs:56-73) for the given rawloader orientation, without a pass over the
- * 3-channel result: for Rotate90 / Rotate270 of a three-colour-filter frame (whole frames at least 256 rows high, the common parameter set) the
- * 1-channel mosaic is permuted instead and the kernel works in rotated space, adding the demosaic taps in the reference's order of
- * the original orientation.  dst receives out_width x out_height x 3 samples of p->out_type.  Normal / Unknown: ipk_raw_to_srgb.
- * Returns IPK_ERR_UNSUPPORTED (nothing written) for the other orientations, filters or parameters: the caller then uses
+ * 3-channel result: the 1-channel mosaic is permuted instead (rotate_buffer's index walk, :102-128) and the kernel works in
+ * rotated space, adding the demosaic taps in the reference's order of the ORIGINAL orientation.  Whole frames (no band) of a
+ * three-colour filter whose rotated width is at least 256 pixels, with the common parameter set (finite ordinary multipliers and
+ * matrix, a 2- or 3-knot curve, validated levels).  dst receives out_width x out_height x 3 samples of p->out_type.
+ * Normal / Unknown: ipk_raw_to_srgb.  Returns IPK_ERR_UNSUPPORTED (nothing written) otherwise: the caller then uses
  * ipk_raw_to_srgb + ipk_rotate_buffer / ipk_rotate_image_*, as ipk_pipeline_run does. */
 IPK_API int ipk_raw_to_srgb_oriented(const ipk_fused_params *p, const void *src, int orientation, void *dst,
                                      size_t *out_width, size_t *out_height, void *stream);

@@ -649,7 +649,7 @@ def test_staged_pipeline_on_alternating_streams(ipa, orc):
 @pytest.mark.parametrize("is_float", [False, True])
 @pytest.mark.parametrize("cfa", ["RGGB", "GRBG", "GBRG", "BGGR"])
 @pytest.mark.parametrize("shape,crops", [((256, 300), (0, 0, 0, 0)), ((257, 301), (0, 0, 0, 0)), ((300, 513), (1, 2, 0, 3)), ((321, 256), (3, 0, 1, 1)), ((512, 258), (0, 1, 1, 0))])
-def test_portrait_orientations_run_in_rotated_space(ipa, orc, cfa, shape, crops, is_float):
+def test_orientations_run_in_rotated_space(ipa, orc, cfa, shape, crops, is_float):
     """Rotate90 / Rotate270 of a Bayer frame: the mosaic is permuted and the fused kernel works in rotated space (taps renamed into
     the original orientation's order, role table from the sensor parities, edge masks mapped) -- every Bayer phase, odd and even
     sizes, odd crops, all three outputs, bit-identical to the oracle's pipeline with OpTransform"""
@@ -661,24 +661,25 @@ def test_portrait_orientations_run_in_rotated_space(ipa, orc, cfa, shape, crops,
             sp = util.SPECIALS * np.float32(16383.0)
         src[33, 20: 20 + sp.size] = sp
         src[100, 150] = -np.inf; src[h - 1, 0] = np.nan; src[0, w - 1] = np.float32(3e38)
-    for rotation in (1, 3):
+    for rotation, fliph in [(1, False), (3, False), (0, True), (2, False), (2, True), (1, True), (3, True)]:     # the seven non-Normal orientations
         pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops))
-        pipe.ops.transform.rotation = rotation
-        want = orc.pipeline_run(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation))
+        pipe.ops.transform.rotation = rotation; pipe.ops.transform.fliph = fliph
+        okw = dict(crops=crops, rotation=rotation, fliph=fliph)
+        want = orc.pipeline_run(_oracle_desc(orc, src, cfa, **okw))
         got = pipe.run()
         assert pipe.last_used_fused
-        assert_bits_equal(got.numpy(), want, "portrait rotation=%d %s %r %r" % (rotation, cfa, shape, crops))
+        assert_bits_equal(got.numpy(), want, "rotated space rotation=%d fliph=%s %s %r %r" % (rotation, fliph, cfa, shape, crops))
         ww, hh, o8 = pipe.output_8bit()
-        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
+        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, **okw)))
         ww, hh, o16 = pipe.output_16bit()
-        assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
+        assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, cfa, **okw)))
 
 
 
 @pytest.mark.parametrize("is_float", [False, True])
 @pytest.mark.parametrize("cfa", [XT, W8X2])
 @pytest.mark.parametrize("shape,crops", [((258, 300), (0, 0, 0, 0)), ((263, 301), (0, 0, 0, 0)), ((300, 517), (1, 2, 0, 3)), ((331, 262), (5, 0, 1, 4))])
-def test_portrait_orientations_generic_cfa(ipa, orc, cfa, shape, crops, is_float):
+def test_orientations_in_rotated_space_generic_cfa(ipa, orc, cfa, shape, crops, is_float):
     """The same for filters in generic-CFA mode (X-Trans 6 x 6 and an 8 x 2 pattern): the cell records are laid out for the rotated
     pattern (dimensions swapped, phase from the frame size), the taps keep the sensor's order; f32 frames carry NaN / inf /
     denormal samples, whose row windows take the literal bins in rotated space as well"""
@@ -690,12 +691,13 @@ def test_portrait_orientations_generic_cfa(ipa, orc, cfa, shape, crops, is_float
             sp = util.SPECIALS * np.float32(16383.0)
         src[40, 30: 30 + sp.size] = sp
         src[90, 200] = -np.inf; src[150, 7] = np.nan; src[h - 1, w - 1] = np.inf; src[0, 0] = np.float32(1e-40)
-    for rotation in (1, 3):
+    for rotation, fliph in [(1, False), (3, False), (0, True), (2, False), (2, True), (1, True), (3, True)]:
         pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, cfa, is_float=is_float, crops=crops))
-        pipe.ops.transform.rotation = rotation
-        want = orc.pipeline_run(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation))
+        pipe.ops.transform.rotation = rotation; pipe.ops.transform.fliph = fliph
+        okw = dict(crops=crops, rotation=rotation, fliph=fliph)
+        want = orc.pipeline_run(_oracle_desc(orc, src, cfa, **okw))
         got = pipe.run()
         assert pipe.last_used_fused
-        assert_bits_equal(got.numpy(), want, "portrait generic rotation=%d %r %r" % (rotation, shape, crops))
+        assert_bits_equal(got.numpy(), want, "rotated space generic rotation=%d fliph=%s %r %r" % (rotation, fliph, shape, crops))
         ww, hh, o8 = pipe.output_8bit()
-        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, crops=crops, rotation=rotation)))
+        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, **okw)))
