@@ -1333,7 +1333,7 @@ int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_
 
   // Nothing memoised and the whole chain is one fused launch: cheaper on this machine than materialising seven
   // intermediates; only the final buffer enters the cache.
-  if (startpos == 0 && d->allow_fused && cfa_branch && d->cpp == 1 && n.rc.noop() && n.transform_noop) {
+  if (startpos == 0 && d->allow_fused && cfa_branch && d->cpp == 1 && n.rc.noop()) {   // any orientation: ipk_pipeline_run folds OpTransform in
     const float scale = ipk::calculate_scaling_total(w0, h0, n.dw, n.dh).scale;
     ipk::Cfa cfa; int xo, yo;
     if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && (cfa.bayer_phase(xo, yo) || cfa.three_colour())) {
