@@ -909,7 +909,8 @@ __global__ void k_rotate1(const T *__restrict__ src, uint32_t owidth, uint32_t o
 }
 // tiles of TW x TW elements with TW * sizeof(T) = 128 bytes: every wave-level load and store covers whole 128-byte lines
 // (2-byte sensor samples: 32-wide tiles, 64-byte pieces, 2.0 TB/s; 64-wide, 2.55 TB/s; 128 x 128 tiles with two samples per lane on
-// both sides, 2.3 TB/s -- the 16-bit LDS traffic, not the line size, is what is left)
+// both sides, 2.3 TB/s; 2 x 2 blocks with all LDS and global traffic 32 bits wide, 2.6 TB/s -- neither the line size nor the LDS
+// width is the limit; the walk across 64 source rows a pitch apart is)
 template <typename T>
 __global__ __launch_bounds__(256) void k_rotate1_transposed(const T *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
                                                            int64_t x_step, int64_t y_step, T *__restrict__ dst) {
