@@ -701,3 +701,27 @@ def test_orientations_in_rotated_space_generic_cfa(ipa, orc, cfa, shape, crops, 
         assert_bits_equal(got.numpy(), want, "rotated space generic rotation=%d fliph=%s %r %r" % (rotation, fliph, shape, crops))
         ww, hh, o8 = pipe.output_8bit()
         assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, src, cfa, **okw)))
+
+
+@pytest.mark.parametrize("H,W,cfa", [(4000, 6000, "RGGB"), (10000, 10000, "GBRG"), (5760, 8640, XT)])
+def test_full_size_rotated_space_equals_rotating_the_normal_result(ipa, H, W, cfa):
+    """BASELINE.json frame sizes: the rotated-space launch (mosaic permuted, kernel renames its taps) against OpTransform applied to
+    the Normal-orientation result of the same frame, which the tests above pin to the oracle -- every sample, all seven orientations"""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    data = torch.randint(0, 16384, (H * W,), generator=g, device="cuda", dtype=torch.int32).to(torch.int16)
+    def pipe_for(rotation, fliph):
+        img = ipa.RawImage(width=W, height=H, data=data, cfa=cfa, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                           wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+        p = ipa.Pipeline.new_from_source(img)
+        p.ops.transform.rotation = rotation; p.ops.transform.fliph = fliph
+        return p
+    normal = pipe_for(0, False).run()
+    for rotation, fliph in [(1, False), (3, False), (2, False), (0, True), (1, True), (2, True), (3, True)]:
+        p = pipe_for(rotation, fliph)
+        got = p.run()
+        assert p.last_used_fused
+        want = p.ops.transform.run(p.globals, normal)                    # rotate_buffer on the verified result
+        assert (got.width, got.height) == (want.width, want.height)
+        assert torch.equal(got.data.view(torch.int32), want.data.view(torch.int32)), (rotation, fliph)
+        del got, want
