@@ -907,6 +907,29 @@ __global__ void k_rotate1(const T *__restrict__ src, uint32_t owidth, uint32_t o
   if (col >= owidth) return;
   for (uint32_t row = blockIdx.y; row < oheight; row += gridDim.y) dst[(size_t)row * owidth + col] = src[base_offset + y_step * (int64_t)row + x_step * (int64_t)col];
 }
+// flips and 180 degrees (|x_step| == 1): 16 bytes per lane, reversed inside the lane when the walk descends
+template <typename T>
+__global__ void k_rotate1_rows(const T *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset, int64_t x_step, int64_t y_step,
+                               T *__restrict__ dst) {
+  constexpr uint32_t NV = 16 / sizeof(T);
+  struct __attribute__((packed, aligned(sizeof(T)))) Vec { T v[NV]; };
+  const uint32_t c0 = (blockIdx.x * blockDim.x + threadIdx.x) * NV;
+  if (c0 >= owidth) return;
+  for (uint32_t row = blockIdx.y; row < oheight; row += gridDim.y) {
+    const int64_t o0 = base_offset + y_step * (int64_t)row + x_step * (int64_t)c0;
+    T *o = dst + (size_t)row * owidth + c0;
+    if (c0 + NV <= owidth) {
+      Vec v = *reinterpret_cast<const Vec *>(src + (x_step > 0 ? o0 : o0 - (int64_t)(NV - 1)));
+      if (x_step < 0) {
+        #pragma unroll
+        for (uint32_t k = 0; k < NV / 2; ++k) { const T t = v.v[k]; v.v[k] = v.v[NV - 1 - k]; v.v[NV - 1 - k] = t; }
+      }
+      *reinterpret_cast<Vec *>(o) = v;
+    } else {
+      for (uint32_t k = 0; c0 + k < owidth; ++k) o[k] = src[o0 + x_step * (int64_t)k];
+    }
+  }
+}
 // tiles of TW x TW elements with TW * sizeof(T) = 128 bytes: every wave-level load and store covers whole 128-byte lines
 // (2-byte sensor samples: 32-wide tiles, 64-byte pieces, 2.0 TB/s; 64-wide, 2.55 TB/s; 128 x 128 tiles with two samples per lane on
 // both sides, 2.3 TB/s; 2 x 2 blocks with all LDS and global traffic 32 bits wide, 2.6 TB/s -- neither the line size nor the LDS
@@ -938,6 +961,11 @@ void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_of
   if ((y_step == 1 || y_step == -1) && x_step != 1 && x_step != -1 && (oheight + TW - 1) / TW <= 65535) {
     hipLaunchKernelGGL(k_rotate1_transposed<T>, dim3((unsigned)((owidth + TW - 1) / TW), (unsigned)((oheight + TW - 1) / TW), 1), dim3(256), 0, s,
                        src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
+    return;
+  }
+  if (x_step == 1 || x_step == -1) {
+    constexpr size_t NV = 16 / sizeof(T);
+    hipLaunchKernelGGL(k_rotate1_rows<T>, grid_rows((owidth + NV - 1) / NV, oheight, 256), dim3(256), 0, s, src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
     return;
   }
   hipLaunchKernelGGL(k_rotate1<T>, grid_rows(owidth, oheight, 256), dim3(256), 0, s, src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
