@@ -845,6 +845,12 @@ int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits) {
   ipk::launch_selftest_clamp(dev, nullptr); HIPCHK(hipGetLastError());
   return selftest_collect(dev, n_bad, first_bad_bits);
 }
+int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;
+  ipk::launch_selftest_quant8(dev, variant, nullptr); HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
 int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream) {
   REQUIRE_INIT();
   if (!in || !out || variant < 0 || variant > 2) return fail(IPK_ERR_INVALID, "bad selftest arguments");

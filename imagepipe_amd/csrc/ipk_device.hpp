@@ -194,8 +194,17 @@ __device__ __forceinline__ float gamma_sample(const LutPair *__restrict__ gam, f
 }
 
 // output8bit / output16bit (src/color_conversions.rs:323-330)
-__device__ __forceinline__ uint8_t output8bit(float v) {
+__device__ __forceinline__ uint8_t output8bit_literal(float v) {
   return (uint8_t)f32_as_u32_sat(rs_min(rs_max(v * 256.0f, 0.0f), 255.0f));
+}
+__device__ __forceinline__ uint8_t output8bit(float v) { return output8bit_literal(v); }
+// four samples into one dword: v_cvt_pk_u8_f32 converts with saturation to [0, 255] (NaN -> 0) and writes one byte lane; it rounds
+// to nearest, so it is fed floor(v * 256) -- equal to output8bit on every f32 (exhaustive: ipk_selftest_quant8 variant 1)
+__device__ __forceinline__ uint32_t output8bit_x4(float a, float b, float c, float d) {
+  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(floorf(a * 256.0f), 0u, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(floorf(b * 256.0f), 1u, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(floorf(c * 256.0f), 2u, w);
+  return __builtin_amdgcn_cvt_pk_u8_f32(floorf(d * 256.0f), 3u, w);
 }
 __device__ __forceinline__ uint16_t output16bit(float v) {
   return (uint16_t)f32_as_u32_sat(rs_min(rs_max(roundf(v * 65535.0f), 0.0f), 65535.0f));

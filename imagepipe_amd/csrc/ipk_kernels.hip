@@ -812,7 +812,7 @@ __global__ void k_output8(const float *__restrict__ src, size_t n, uint8_t *__re
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 3)) == 0 ? n / 4 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4 *>(src)[i];
-    reinterpret_cast<uint32_t *>(dst)[i] = (uint32_t)output8bit(v.x) | ((uint32_t)output8bit(v.y) << 8) | ((uint32_t)output8bit(v.z) << 16) | ((uint32_t)output8bit(v.w) << 24);
+    reinterpret_cast<uint32_t *>(dst)[i] = output8bit_x4(v.x, v.y, v.z, v.w);
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output8bit(src[i]);
 }
@@ -1538,13 +1538,19 @@ template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 store
 };
 template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
   static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
+    uint32_t *p = stg + 3 * lane;
+#ifdef IPK_Q8_LITERAL
     uint32_t q[12];
     #pragma unroll
     for (int j = 0; j < 4; ++j) { q[3 * j] = output8bit(o[j].r); q[3 * j + 1] = output8bit(o[j].g); q[3 * j + 2] = output8bit(o[j].b); }
-    uint32_t *p = stg + 3 * lane;
     p[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
     p[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
     p[2] = q[8] | (q[9] << 8) | (q[10] << 16) | (q[11] << 24);
+#else
+    p[0] = output8bit_x4(o[0].r, o[0].g, o[0].b, o[1].r);
+    p[1] = output8bit_x4(o[1].g, o[1].b, o[2].r, o[2].g);
+    p[2] = output8bit_x4(o[2].b, o[3].r, o[3].g, o[3].b);
+#endif
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
     u32u *g = reinterpret_cast<u32u *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);        // byte-aligned dword stores
@@ -2291,6 +2297,23 @@ __global__ void k_selftest_clamp(SelftestOut *out) {
   }
   if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
 }
+// output8bit: (v * 256).max(0).min(255) as u8 versus v_cvt_pk_u8_f32 of the product (variant 0), of its floor (variant 1), and
+// versus the saturating v_cvt_u32_f32 + unsigned min (variant 2), every bit pattern
+__global__ void k_selftest_quant8(SelftestOut *out, int variant) {
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float v = __uint_as_float((unsigned)i);
+    const uint32_t a = output8bit_literal(v);
+    const float p = v * 256.0f;
+    uint32_t b;
+    if (variant == 0) b = __builtin_amdgcn_cvt_pk_u8_f32(p, 0u, 0u);
+    else if (variant == 1) b = __builtin_amdgcn_cvt_pk_u8_f32(floorf(p), 0u, 0u);
+    else b = min(f32_as_u32_sat(p), 255u);
+    if (a != b) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
 // device cbrt variants on an array (the host compares with libm): 0 literal glibc port, 1 select form, 2 fast form for (1,2)
 __global__ void k_selftest_cbrt(const float *__restrict__ in, float *__restrict__ out, size_t n, int variant) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -2308,6 +2331,7 @@ int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bit
 }
 int launch_selftest_fract(void *out_dev, hipStream_t s) { hipLaunchKernelGGL(k_selftest_fract, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev)); return 0; }
 int launch_selftest_clamp(void *out_dev, hipStream_t s) { hipLaunchKernelGGL(k_selftest_clamp, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev)); return 0; }
+int launch_selftest_quant8(void *out_dev, int variant, hipStream_t s) { hipLaunchKernelGGL(k_selftest_quant8, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev), variant); return 0; }
 int launch_selftest_cbrt(const float *in, float *out, size_t n, int variant, hipStream_t s) {
   hipLaunchKernelGGL(k_selftest_cbrt, dim3(256 * 8), dim3(256), 0, s, in, out, n, variant); return 0;
 }

@@ -89,6 +89,7 @@ int launch_raster_chain(const FusedLaunch &f, size_t npix, int src_is_u16, const
 int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bits, int include_special, void *out_dev, hipStream_t s);
 int launch_selftest_fract(void *out_dev, hipStream_t s);
 int launch_selftest_clamp(void *out_dev, hipStream_t s);
+int launch_selftest_quant8(void *out_dev, int variant, hipStream_t s);
 int launch_selftest_cbrt(const float *in, float *out, size_t n, int variant, hipStream_t s);
 
 }  // namespace ipk

@@ -419,6 +419,9 @@ IPK_API int ipk_selftest_cdiv(float c, int variant, float lo, float hi, int incl
 IPK_API int ipk_selftest_lut_weight(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* v.max(0.0).min(1.0) (src/ops/gamma.rs:22) versus v_med3_f32(v,0,1) for every f32 */
 IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
+/* output8bit (src/color_conversions.rs:323-326) on every f32 against a cheaper form: variant 0 v_cvt_pk_u8_f32(v*256), 1 the same of
+ * floor(v*256), 2 min(saturating v_cvt_u32_f32(v*256), 255) -- the form the kernels use must report 0 mismatches */
+IPK_API int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_bad_bits);
 /* the device cbrtf routines (variant 0 literal glibc port, 1 select form, 2 form for 1<x<2) on a device array;
  * callers compare with the host libm's cbrtf (src/color_conversions.rs:123 -> f32::cbrt) */
 IPK_API int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream);
