@@ -155,7 +155,8 @@ _lib = None
 
 
 class IpkError(RuntimeError):
-    pass
+    """a negative ipk_status; `code` holds it (None for failures raised by the Python plumbing itself)"""
+    code = None
 
 
 def load():
@@ -178,5 +179,7 @@ def load():
 
 def check(rc, what=""):
     if rc < 0:
-        raise IpkError("%s failed (%d): %s" % (what or "ipk call", rc, load().ipk_last_error().decode()))
+        err = IpkError("%s failed (%d): %s" % (what or "ipk call", rc, load().ipk_last_error().decode()))
+        err.code = rc
+        raise err
     return rc

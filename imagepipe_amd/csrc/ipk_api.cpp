@@ -69,9 +69,16 @@ hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 bool dims_ok(size_t w, size_t h) { return w >= 1 && h >= 1 && w < (1ull << 31) && h < (1ull << 31); }
 
+// 16-letter patterns are refused, not guessed: rawloader's tile shape for them is unverified (ipk_host.hpp Cfa::parse)
+int cfa_fail(const char *pat) {
+  if (ipk::Cfa::unpinned_length(pat))
+    return fail(IPK_ERR_UNSUPPORTED, "16-letter CFA pattern \"%s\": tile shape (8x2 or 2x8) unverified against rawloader, refused", pat);
+  return fail(IPK_ERR_INVALID, "invalid CFA pattern \"%s\"", pat ? pat : "(null)");
+}
+
 // device-side tables for one CFA pattern string (uploaded once, cached)
 int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
-  if (!ipk::Cfa::parse(pat, cfa) || !cfa.valid()) return fail(IPK_ERR_INVALID, "invalid CFA pattern \"%s\"", pat ? pat : "(null)");
+  if (!ipk::Cfa::parse(pat, cfa) || !cfa.valid()) return cfa_fail(pat);
   std::lock_guard<std::mutex> lk(g.mu);
   auto it = g.cfa_cache.find(pat);
   if (it != g.cfa_cache.end()) { dev = it->second; return IPK_OK; }
@@ -343,7 +350,7 @@ int ipk_rotatecrop_calc_size(const float *p, float input_ratio, size_t width, si
 }
 int ipk_cfa_shift(const char *pattern, int x, int y, char *out) {
   ipk::Cfa c;
-  if (!ipk::Cfa::parse(pattern, c)) return fail(IPK_ERR_INVALID, "invalid CFA pattern");
+  if (!ipk::Cfa::parse(pattern, c)) return cfa_fail(pattern);
   const std::string s = c.shifted_name(x, y);
   std::memcpy(out, s.c_str(), s.size() + 1);
   return IPK_OK;
@@ -481,7 +488,7 @@ int ipk_demosaic_run(const float *src, size_t width, size_t height, size_t color
   if (colors != 1 && colors != 4) return fail(IPK_ERR_INVALID, "demosaic expects 1 or 4 colours");
   const float scale = ipk::calculate_scaling_total(width, height, demosaic_width, demosaic_height).scale;
   ipk::Cfa cfa;
-  if (!ipk::Cfa::parse(cfa_pat ? cfa_pat : "", cfa)) return fail(IPK_ERR_INVALID, "invalid CFA pattern");
+  if (!ipk::Cfa::parse(cfa_pat ? cfa_pat : "", cfa)) return cfa_fail(cfa_pat);
   const float minscale = ipk::demosaic_minscale(cfa.width);
   if (scale <= 1.0f && colors == 4) { *out_width = width; *out_height = height; return IPK_NOOP; }        // demosaic.rs:41-43
   if (colors == 4) {                                                                                       // :44-46

@@ -90,6 +90,7 @@ struct Cfa {
   bool valid() const { return width > 0; }
   int color_at(size_t row, size_t col) const { return pattern[(row + 48) % 48][(col + 48) % 48]; }
   // CFA::new(patname)
+  static bool unpinned_length(const char *pat) { return pat && std::strlen(pat) == 16; }
   static bool parse(const char *pat, Cfa &out) {
     const size_t len = pat ? std::strlen(pat) : 0;
     out = Cfa();
@@ -97,7 +98,10 @@ struct Cfa {
       case 0: return true;
       case 4: out.width = 2; out.height = 2; break;
       case 36: out.width = 6; out.height = 6; break;
-      case 16: out.width = 8; out.height = 2; break;
+      // 16 letters: rawloader 0.37 is absent from /root/reference and its tile shape for this length is unverified (8 wide x 2
+      // high as imagepipe's `8 => 2.0` minscale arm suggests, or dcraw's 2 wide x 8 high); no reference test constructs one.
+      // Rejected (IPK_ERR_UNSUPPORTED at the API) rather than guessed -- DESIGN.md section 7.
+      case 16: return false;
       case 144: out.width = 12; out.height = 12; break;
       default: return false;
     }

@@ -303,7 +303,8 @@ static int cfa_new(const char *pat, orc_cfa *c) {
     case 0: c->width = 0; c->height = 0; return 0;
     case 4: c->width = 2; c->height = 2; break;
     case 36: c->width = 6; c->height = 6; break;
-    case 16: c->width = 8; c->height = 2; break;
+    /* 16 letters: tile shape (8x2 or dcraw's 2x8) cannot be verified here -- rawloader is absent; refused like the product */
+    case 16: return -1;
     case 144: c->width = 12; c->height = 12; break;
     default: return -1;
   }

@@ -111,13 +111,18 @@ def test_rotatecrop_calc_size(L, orc):
 def test_cfa_shift_and_orientation(L, orc):
     out = C.create_string_buffer(200)
     xt = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
-    for pat in ["RGGB", "GBRG", xt, "RGGBRGGBGRBGGRBG"]:
+    for pat in ["RGGB", "GBRG", xt, (xt[:6] * 2 + xt[6:12] * 2) * 6]:
         for x in range(7):
             for y in range(7):
                 assert L.ipk_cfa_shift(pat.encode(), x, y, out) == 0
                 assert out.value.decode() == orc.cfa_shift(pat, x, y)
     assert orc.cfa_shift("RGGB", 1, 0) == "GRBG" and orc.cfa_shift("RGGB", 0, 1) == "GBRG" and orc.cfa_shift("RGGB", 1, 1) == "BGGR"
     assert L.ipk_cfa_shift(b"RGXB", 0, 0, out) == -2
+    # 16 letters: the tile shape (8x2 or 2x8) is unverified against rawloader -- refused by product and oracle alike
+    assert L.ipk_cfa_shift(b"RGGBGRBGGBRGBGGR", 0, 0, out) == -5            # IPK_ERR_UNSUPPORTED
+    assert b"16-letter" in L.ipk_last_error()
+    with pytest.raises(Exception):
+        orc.cfa_shift("RGGBGRBGGBRGBGGR", 0, 0)
     f = (C.c_int * 3)()
     for o in range(9):
         L.ipk_orientation_to_flips(o, f)

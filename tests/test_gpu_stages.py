@@ -86,7 +86,7 @@ def test_gofloat_other(ipa, orc):
 # demosaic::full (parity unpinned by the reference's tests: oracle + hand-derived answers)
 # ---------------------------------------------------------------------------------------------
 XTRANS = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
-CFAS = ["RGGB", "BGGR", "GRBG", "GBRG", "RGBE", "ERBG", XTRANS, "RGGBRGGBGRBGGRBG"]
+CFAS = ["RGGB", "BGGR", "GRBG", "GBRG", "RGBE", "ERBG", XTRANS, (XTRANS[:6] * 2 + XTRANS[6:12] * 2) * 6]   # 2x2, four-colour, 6x6, 12x12
 
 
 def _demosaic(ipa, cfa, buf, nw=0, nh=0):
