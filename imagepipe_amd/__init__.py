@@ -115,6 +115,7 @@ class RawImage:
     blacklevels: Sequence[float] = (0, 0, 0, 0)
     whitelevels: Sequence[float] = (65535, 65535, 65535, 65535)
     wb_coeffs: Sequence[float] = (1.0, 1.0, 1.0, float("nan"))
+    neutralwb: Optional[Sequence[float]] = None             # RawImage::neutralwb() (rawloader; caller-computed): OpToLab's fallback
     cam_to_xyz_normalized: Optional[np.ndarray] = None      # [[f32;4];3]; default SRGB_D65_43
     cam_to_xyz: Optional[np.ndarray] = None                 # [[f32;4];3]; only OpToLab.get_temp reads it
     xyz_to_cam: Optional[np.ndarray] = None                 # [[f32;3];4]; only OpToLab.set_temp reads it
@@ -316,7 +317,17 @@ class OpToLab(ImageOp):
             self.cam_to_xyz_normalized = cm.reshape(3, 4)
             self.cam_to_xyz = self.cam_to_xyz_normalized if img.cam_to_xyz is None else np.asarray(img.cam_to_xyz, np.float32).reshape(3, 4)
             self.xyz_to_cam = xyz_d65_34() if img.xyz_to_cam is None else np.asarray(img.xyz_to_cam, np.float32).reshape(4, 3)
-            self.wb_coeffs = [float(v) for v in img.wb_coeffs]
+            # colorspaces.rs:33-41: normalize_wbs(wb_coeffs), or normalize_wbs(neutralwb()) when any of wb[0..2] is not normal
+            wb = np.asarray(img.wb_coeffs, np.float32)
+            tiny = np.finfo(np.float32).tiny
+            normal = bool(np.all(np.isfinite(wb[:3]) & (np.abs(wb[:3]) >= tiny)))
+            if not normal:
+                if img.neutralwb is None:
+                    raise IpkError("OpToLab: as-shot wb_coeffs are not normal and the RawImage carries no neutralwb")
+                wb = np.asarray(img.neutralwb, np.float32)
+            out = (C.c_float * 4)()
+            _lib.check(lib().ipk_normalize_wbs(_farr(wb, 4), out), "ipk_normalize_wbs")
+            self.wb_coeffs = [float(v) for v in out]
         else:
             self.cam_to_xyz_normalized = self.cam_to_xyz = SRGB_D65_43
             self.xyz_to_cam = xyz_d65_34()

@@ -43,7 +43,8 @@ struct Context {
   std::map<std::string, DevCfa> cfa_cache;
   std::map<std::string, float *> rot_cells;              // generic-CFA cell records laid out for a rotated space (pattern, orientation, frame phase)
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
-  struct Block { void *p; size_t bytes; bool busy; hipStream_t last; };      // last: the stream its most recent user enqueued on
+  // last: the stream its most recent user enqueued on; done: recorded on that stream when the block came back (pool_put)
+  struct Block { void *p; size_t bytes; bool busy; hipStream_t last; hipEvent_t done; bool recorded; };
   std::vector<Block> pool;
   std::mutex mu;
 };
@@ -101,39 +102,47 @@ int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
 }
 
 // scratch pool: buffers are handed out and returned in stream order -- a block goes back as soon as its last user is
-// enqueued, and the next user on the SAME stream runs after it.  A block last used on a different stream is only handed
-// out once that stream has drained (rare: callers normally stay on one stream; the host-pointer driver uses its own).
+// enqueued (pool_put records an event on that stream), and the next user on the SAME stream runs after it.  A user on a
+// different stream makes ITS stream wait for that event (hipStreamWaitEvent: no host stall, nothing done under the lock that
+// blocks, and the previous stream's handle is never touched again -- the caller may have destroyed it).
 int pool_get(size_t bytes, void **out, hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g.mu);
   int best = -1;
   for (size_t i = 0; i < g.pool.size(); ++i)
     if (!g.pool[i].busy && g.pool[i].bytes >= bytes && (best < 0 || g.pool[i].bytes < g.pool[best].bytes)) best = (int)i;
   if (best >= 0) {
-    if (g.pool[best].last != stream) HIPCHK(hipStreamSynchronize(g.pool[best].last));
-    g.pool[best].busy = true; g.pool[best].last = stream; *out = g.pool[best].p; return IPK_OK;
+    auto &b = g.pool[best];
+    if (b.last != stream && b.recorded) HIPCHK(hipStreamWaitEvent(stream, b.done, 0));
+    b.busy = true; b.last = stream; *out = b.p; return IPK_OK;
   }
   // nothing fits: the idle blocks are all too small for this frame size, so they go before a larger one is allocated
-  // (a long-running process that moves between frame sizes keeps only what its current size needs)
+  // (a long-running process that moves between frame sizes keeps only what its current size needs).  hipFree waits for
+  // the device work that still uses them.
   for (size_t i = g.pool.size(); i-- > 0;)
-    if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
+    if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); (void)hipEventDestroy(g.pool[i].done); g.pool.erase(g.pool.begin() + (long)i); }
   void *p = nullptr;
   if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-  g.pool.push_back({p, bytes, true, stream});
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(p); return fail(IPK_ERR_HIP, "hipEventCreate failed"); }
+  g.pool.push_back({p, bytes, true, stream, ev, false});
   *out = p;
   return IPK_OK;
 }
-void pool_put(void *p) {
+void pool_put(void *p, hipStream_t stream) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g.mu);
-  for (auto &b : g.pool) if (b.p == p) { b.busy = false; return; }
+  for (auto &b : g.pool) if (b.p == p) {
+    b.recorded = hipEventRecord(b.done, stream) == hipSuccess;             // a failed record (dead stream) leaves "nothing to wait for"
+    b.last = stream; b.busy = false; return;
+  }
 }
 struct Scratch {                       // RAII: returns its buffers to the pool
   hipStream_t stream;
   std::vector<void *> bufs;
   explicit Scratch(hipStream_t s) : stream(s) {}
-  ~Scratch() { for (void *p : bufs) pool_put(p); }
+  ~Scratch() { for (void *p : bufs) pool_put(p, stream); }
   int get(size_t bytes, void **out) { int rc = pool_get(bytes, out, stream); if (!rc) bufs.push_back(*out); return rc; }
-  void release(void *p) { pool_put(p); bufs.erase(std::remove(bufs.begin(), bufs.end(), p), bufs.end()); }
+  void release(void *p) { pool_put(p, stream); bufs.erase(std::remove(bufs.begin(), bufs.end(), p), bufs.end()); }
 };
 
 
@@ -181,8 +190,11 @@ bool validate_cdiv_for_range_uncached(float black, float range, bool src_is_u16)
     for (uint32_t v = 0; v < 65536; ++v) if (!ok((float)v - black)) return false;
     return true;
   }
+  // f32 sources: any dividend can occur.  Every dividend mantissa against this divisor (a proof for the guarded exponent zone,
+  // ipk_host.hpp), then a spread of exponents as a check of the scaling argument itself.
+  if (!ipk::cdiv_mantissa_exhaustive_ok(range)) return false;
   uint64_t st = 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < 65536; ++i) {
+  for (int i = 0; i < 4096; ++i) {
     st = st * 6364136223846793005ull + 1442695040888963407ull;
     uint32_t bits = (uint32_t)(st >> 32);
     bits = (bits & 0x807FFFFFu) | ((27u + (bits >> 23) % 200u) << 23);      // exponent in [2^-100, 2^100)
@@ -273,7 +285,7 @@ void ipk_shutdown(void) {
   g.cfa_cache.clear();
   for (auto &kv : g.rot_cells) (void)hipFree(kv.second);
   g.rot_cells.clear();
-  for (auto &b : g.pool) (void)hipFree(b.p);
+  for (auto &b : g.pool) { (void)hipFree(b.p); (void)hipEventDestroy(b.done); }
   g.pool.clear();
   host_lanes_release();
   g.ready = false; g.device = -1; g.num_cus = 0;
@@ -868,7 +880,10 @@ int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void 
 // ------------------------------------------------------------------------------------------
 // Pipeline::run (src/pipeline.rs:311-375) for one source, cache == None
 // ------------------------------------------------------------------------------------------
-int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h, size_t *final_w, size_t *final_h) {
+// rc_state (may be null): the OpRotateCrop as the two folds of the negotiation leave it (input_ratio, output size) -- the state
+// its Serialize impl exposes to the hash chain (pipeline.rs:318-335, rotatecrop.rs:10-18)
+static int pipeline_sizes_impl(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h, size_t *final_w, size_t *final_h,
+                               ipk::RotateCrop *rc_state) {
   if (!d) return fail(IPK_ERR_INVALID, "null descriptor");
   if (d->rotation < 0 || d->rotation > 3) return fail(IPK_ERR_INVALID, "bad rotation");
   ipk::RotateCrop rc;                                                     // reset() state (pipeline.rs:314-316)
@@ -884,6 +899,7 @@ int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *d
   w = s.width; h = s.height;
   ipk::transform_forward(d->rotation, w, h, w, h);                        // reverse fold (:331-335)
   rc.transform_reverse(w, h, w, h);
+  if (rc_state) *rc_state = rc;
   *demosaic_w = w; *demosaic_h = h;
   // The size run() PRODUCES (what output_8bit reports and tests/maxsize_test.rs asserts on): every op sizes its output from
   // the buffer it is handed, not from the negotiation, so behind a rotatecrop the result can differ from the forward fold by a
@@ -905,6 +921,9 @@ int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *d
   }
   *final_w = pw; *final_h = ph;
   return IPK_OK;
+}
+int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h, size_t *final_w, size_t *final_h) {
+  return pipeline_sizes_impl(d, demosaic_w, demosaic_h, final_w, final_h, nullptr);
 }
 
 // Pipeline::default_ops (pipeline.rs:286-288) for a raster source: every user-visible op field equals PipelineOps::new(Other),
@@ -1220,19 +1239,10 @@ struct Negotiated {
 int negotiate(const ipk_pipeline_desc *d, int out_type, Negotiated &n) {
   if (!d) return fail(IPK_ERR_INVALID, "null descriptor");
   if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
-  int rc = ipk_pipeline_sizes(d, &n.dw, &n.dh, &n.fw, &n.fh); if (rc) return rc;
+  // one negotiation: the sizes and the rotatecrop state both come from pipeline_sizes_impl's folds (the reverse fold is seeded
+  // with scaling_size of the forward result, pipeline.rs:328-335 -- not with the size run() produces)
+  int rc = pipeline_sizes_impl(d, &n.dw, &n.dh, &n.fw, &n.fh, &n.rc); if (rc) return rc;
   ipk::size_image(d->crop_top, d->crop_right, d->crop_bottom, d->crop_left, d->width, d->height, n.r);
-  n.rc = ipk::RotateCrop();
-  n.rc.crop_top = d->rotatecrop[0]; n.rc.crop_right = d->rotatecrop[1]; n.rc.crop_bottom = d->rotatecrop[2];
-  n.rc.crop_left = d->rotatecrop[3]; n.rc.rotation = d->rotatecrop[4];
-  { // the state the two folds leave in the op (pipeline.rs:318-335), which its Serialize impl exposes to the hash
-    size_t w = n.r.width, h = n.r.height;
-    n.rc.transform_forward(w, h, w, h);
-    ipk::transform_forward(d->rotation, w, h, w, h);
-    w = n.fw; h = n.fh;
-    ipk::transform_forward(d->rotation, w, h, w, h);
-    n.rc.transform_reverse(w, h, w, h);
-  }
   n.linear = out_type == IPK_OUT_U8 ? 0 : (out_type == IPK_OUT_U16 ? 1 : (d->linear != 0));
   n.orientation = ipk::transform_orientation(d->rotation, d->fliph != 0, d->flipv != 0);
   n.transform_noop = n.orientation == IPK_OR_NORMAL || n.orientation == IPK_OR_UNKNOWN;
@@ -1242,7 +1252,7 @@ int negotiate(const ipk_pipeline_desc *d, int out_type, Negotiated &n) {
 void hash_chain(const ipk_pipeline_desc *d, const Negotiated &n, uint64_t source_id, ipk::BufHash out[8]) {
   ipk::BufHasher h;
   // PipelineSettings (pipeline.rs:110-137)
-  h.usize(d->maxwidth); h.usize(d->maxheight); h.usize(n.dw); h.usize(n.dh); h.boolean(n.linear != 0); h.boolean(true);
+  h.usize(d->maxwidth); h.usize(d->maxheight); h.usize(n.dw); h.usize(n.dh); h.boolean(n.linear != 0); h.boolean(d->use_fastpath != 0);
   // gofloat (gofloat.rs:4-12).  The reference hashes no identity of the image at all (a PipelineCache is only
   // valid for one source); source_id + the source geometry make one cache safe across several resident frames.
   h.str_raw("gofloat");

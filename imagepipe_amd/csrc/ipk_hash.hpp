@@ -8,6 +8,7 @@
 // made by the same process), so this restates the *contract* -- same fields, same order, same chaining --
 // over SHA-256 (FIPS 180-4) and a fixed little-endian layout.  Host-only code.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <list>

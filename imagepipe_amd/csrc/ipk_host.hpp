@@ -10,6 +10,8 @@
 #include <cstddef>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -196,6 +198,34 @@ struct Cfa {
 };
 
 // ---- OpGoFloat::size_image (src/ops/gofloat.rs:74-82) --------------------------------------
+// ---- runtime divisors of the three-step division (ipk_device.hpp cdiv_fast) ------------------------------------------
+// q0 = d*rc ; r = fma(-q0, c, d) ; q1 = fma(r, rc, q0) with rc = RN(1/c).  Scaling d or c by a power of two scales every
+// intermediate exactly (no under/overflow inside the guarded zone 2^-100 <= |d| <= 2^100, 2^-60 <= c <= 2^60), so whether
+// q1 == RN(d/c) depends on the two MANTISSAS only: sweeping all 2^23 dividend mantissas against c's mantissa is a proof
+// for that divisor, not a sample (about 10 ms on one host core; memoised per divisor mantissa).
+inline bool cdiv_mantissa_exhaustive_ok(float c) {
+  if (!(c >= 0x1p-60f && c <= 0x1p60f)) return false;                       // also NaN, <= 0
+  uint32_t cb; std::memcpy(&cb, &c, 4);
+  const uint32_t cm = cb & 0x007FFFFFu;
+  static std::mutex mu;
+  static std::map<uint32_t, bool> memo;
+  { std::lock_guard<std::mutex> lk(mu); auto it = memo.find(cm); if (it != memo.end()) return it->second; }
+  const uint32_t c1b = cm | 0x3F800000u;                                    // c scaled into [1, 2)
+  float c1; std::memcpy(&c1, &c1b, 4);
+  const float rc = 1.0f / c1;
+  bool ok = true;
+  for (uint32_t m = 0; m < (1u << 23) && ok; ++m) {
+    const uint32_t db = m | 0x3F800000u;
+    float d; std::memcpy(&d, &db, 4);
+    const float q0 = d * rc;
+    const float r = std::fma(-q0, c1, d);
+    ok = std::fma(r, rc, q0) == d / c1;
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  memo[cm] = ok;
+  return ok;
+}
+
 struct Rect { size_t x, y, width, height; };
 inline bool size_image(size_t crop_top, size_t crop_right, size_t crop_bottom, size_t crop_left,
                        size_t owidth, size_t oheight, Rect &r) {

@@ -313,22 +313,9 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
   }
 }
 // Host check of a runtime divisor for cdiv_fast (same obligations as ipk_api.cpp's validate_cdiv_for_range): positive,
-// ordinary magnitude, and the three-step quotient equal to the IEEE one on a spread of dividends.
-static int cdiv_host_ok(float c) {
-  if (!(c >= 0x1p-60f && c <= 0x1p60f)) return 0;
-  const float rc = 1.0f / c;
-  uint64_t st = 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < 4096; ++i) {
-    st = st * 6364136223846793005ull + 1442695040888963407ull;
-    uint32_t bits = (uint32_t)(st >> 32);
-    bits = (bits & 0x807FFFFFu) | ((100u + (bits >> 23) % 54u) << 23);       // |d| in [2^-27, 2^27): the dividends are pixel offsets
-    float d; std::memcpy(&d, &bits, 4);
-    const float q0 = d * rc;
-    const float r = std::fma(-q0, c, d);
-    if (std::fma(r, rc, q0) != d / c) return 0;
-  }
-  return 1;
-}
+// ordinary magnitude, and the three-step quotient equal to the IEEE one for EVERY dividend mantissa (exhaustive per divisor,
+// memoised: ipk_host.hpp cdiv_mantissa_exhaustive_ok).  The dividends here are pixel offsets, far inside the exponent zone.
+static int cdiv_host_ok(float c) { return cdiv_mantissa_exhaustive_ok(c) ? 1 : 0; }
 
 template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,

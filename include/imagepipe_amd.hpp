@@ -73,6 +73,8 @@ struct ImageSource {
   size_t crops[4] = {0, 0, 0, 0};                      // top, right, bottom, left
   float blacklevels[4] = {0, 0, 0, 0}, whitelevels[4] = {65535, 65535, 65535, 65535};
   float wb_coeffs[4] = {1.0f, 1.0f, 1.0f, NAN};
+  bool has_neutralwb = false; float neutralwb[4] = {1.0f, 1.0f, 1.0f, NAN};   // RawImage::neutralwb() (rawloader, computed by the caller): the
+                                                       // fallback OpToLab::new takes when the as-shot coefficients are not normal (colorspaces.rs:33-39)
   float cam_to_xyz_normalized[12] = {0.4124564f, 0.3575761f, 0.1804375f, 0, 0.2126729f, 0.7151522f, 0.0721750f, 0, 0.0193339f, 0.1191920f, 0.9503041f, 0};
   float cam_to_xyz[12] = {0.4124564f, 0.3575761f, 0.1804375f, 0, 0.2126729f, 0.7151522f, 0.0721750f, 0, 0.0193339f, 0.1191920f, 0.9503041f, 0};
   bool has_xyz_to_cam = false; float xyz_to_cam[12] = {};   // [[f32;3];4]; OpToLab::set_temp only (default XYZ_D65_34)
@@ -192,7 +194,11 @@ struct OpToLab : ImageOp {
       std::memcpy(cam_to_xyz, img.cam_to_xyz, sizeof(cam_to_xyz));
       std::memcpy(cam_to_xyz_normalized, img.cam_to_xyz_normalized, sizeof(cam_to_xyz_normalized));
       if (img.has_xyz_to_cam) std::memcpy(xyz_to_cam, img.xyz_to_cam, sizeof(xyz_to_cam));
-      std::memcpy(wb_coeffs, img.wb_coeffs, sizeof(wb_coeffs));
+      // colorspaces.rs:33-41: normalize_wbs(wb_coeffs), or normalize_wbs(neutralwb()) when any of wb[0..2] is not normal.  neutralwb()
+      // is rawloader's (camera metadata, absent here): the caller supplies it, and a raw source that needs it without one fails loudly
+      const bool normal = std::isnormal(img.wb_coeffs[0]) && std::isnormal(img.wb_coeffs[1]) && std::isnormal(img.wb_coeffs[2]);
+      if (!normal && !img.has_neutralwb) throw Error("OpToLab: as-shot wb_coeffs are not normal and the ImageSource carries no neutralwb");
+      check(ipk_normalize_wbs(normal ? img.wb_coeffs : img.neutralwb, wb_coeffs), "normalize_wbs");
     } else {
       check(ipk_const_matrix(2, cam_to_xyz), "const_matrix"); std::memcpy(cam_to_xyz_normalized, cam_to_xyz, sizeof(cam_to_xyz));
       const float w[4] = {1, 1, 1, 0}; std::memcpy(wb_coeffs, w, sizeof(w));
