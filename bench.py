@@ -1,15 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- megapixels/s of the full raw->sRGB pipe on a 100 MP f32 Bayer frame (BASELINE.json's metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c4|c5|c5b] [--batch B --width X --height Y]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One step = one pass of the hot path (Pipeline::run: gofloat + demosaic + tolab + basecurve + fromlab + gamma, fused)
-over one 10000x10000 synthetic RGGB f32 frame per GPU, input and output resident in HBM.  Frames are independent, so
-N GPUs each process their own frame with no data-path collective (weak scaling); value = all frames' pixels / max-rank time.
-Prints ONE JSON line on rank 0.
+One step = one pass of the hot path (Pipeline::run: gofloat + demosaic + tolab + basecurve + fromlab + gamma) over one batch of
+synthetic frames, input and output resident in HBM.  Frames are independent (src/pipeline.rs:246-249), so frame i of a batch goes to
+rank i mod N with no data-path collective; value = all frames' pixels / max-rank time.  Prints ONE JSON line on rank 0.
+
+  --config c3 (default)  BASELINE.json configs[2]: one 10000x10000 RGGB f32 frame PER GPU per step (weak scaling) -- the headline
+  --config c2            configs[1]: 6000x4000 RGGB f32, one frame per GPU per step
+  --config c4            configs[3]: a batch of 64 x 24 MP frames sharded frame i -> rank i mod N (strong scaling; = --batch 64
+                         --width 6000 --height 4000), with a second figure that includes the all-gather of the f32 results
+  --config c5 / c5b      configs[4]: 8640x5760 X-Trans -> 2160x1440 (scaled demosaic + point-wise chain) / the same at full size
+The default run also reports, as extra objects of the same line: the cold-clock time, the median, the measured device-copy
+ceiling, two more data kinds (smooth, photo), the 64 x 24 MP batch (configs[3]) and the VALU-issue model of the kernel.
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
 import sys
@@ -19,8 +28,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-BYTES_PER_PX = 16.0            # algorithmic: 4 B mosaic sample in + 3 x 4 B RGB out
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measured device-copy ceiling is reported beside it
+XTRANS = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+CONFIGS = {            # name: (width, height, cfa, maxwidth, frames per step [None = one per GPU], BASELINE.json configs[] index)
+    "c3": (10000, 10000, "RGGB", 0, None, 2),
+    "c2": (6000, 4000, "RGGB", 0, None, 1),
+    "c4": (6000, 4000, "RGGB", 0, 64, 3),
+    "c5": (8640, 5760, XTRANS, 2160, None, 4),
+    "c5b": (8640, 5760, XTRANS, 0, None, 4),
+}
 
 
 def parse():
@@ -28,8 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=10000)
-    ap.add_argument("--height", type=int, default=10000)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="frames per step, sharded frame i -> rank i mod N (default: one frame per GPU)")
     ap.add_argument("--data", choices=["noise", "smooth", "photo", "flat", "white"], default="noise",
                     help="noise: uniform 14-bit values (worst case, the headline); smooth: diagonal gradient over the full range; "
                          "photo: low-frequency mid-tone scene with shot-like noise and ~2 %% blown highlights; flat / white: development extremes (nothing / everything saturated)")
@@ -38,16 +56,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (cold clock, copy ceiling, other data kinds, 64-frame batch)")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
-                    help="untimed launches before the W warmup steps, to bring the shader clock to its loaded steady state (0 = off)")
+                    help="untimed launches before the W warmup steps, to bring the shader clock to its loaded steady state (0 = off); "
+                         "the same workload without it is reported as config.cold_ms")
     ap.add_argument("--band", action="store_true",
-                    help="additionally time ONE frame row-sharded over the N GPUs with the RCCL halo exchange (reported as an extra "
-                         "'band_mode' object; the headline value stays the batch-sharded one)")
+                    help="additionally time ONE frame row-sharded over the N GPUs with the halo exchange (extra 'band_mode' object)")
     return ap.parse_args()
 
 
 def synth_frame(torch, h, w, kind, seed):
-    """14-bit sensor values (black 512, white 16383) as f32, generated on the device."""
+    """14-bit sensor values (black 512, white 16383) as int32, generated on the device."""
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     if kind == "noise":       # uniform in [0, 16383]: worst case for lookup-table locality
@@ -70,108 +89,220 @@ def synth_frame(torch, h, w, kind, seed):
     return torch.clamp(base + n, max=16383)
 
 
+def glibc_version():
+    try:
+        libc = ctypes.CDLL(None)
+        libc.gnu_get_libc_version.restype = ctypes.c_char_p
+        return libc.gnu_get_libc_version().decode()
+    except Exception:
+        return None
+
+
+class Ctx:
+    """process-wide plumbing: torch, the process group, barriers and max-over-ranks reductions"""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            # IPK_BENCH_SHARE_GPU=1 (development only): all ranks on one GPU over gloo, to exercise the N > 1 control flow on a 1-GPU box
+            share = os.environ.get("IPK_BENCH_SHARE_GPU") == "1"
+            if share:
+                self.local_rank = 0
+            torch.cuda.set_device(self.local_rank)
+            if share:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        self.red_dev = "cpu" if (self.dist is not None and self.dist.get_backend() == "gloo") else "cuda"
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, vals):
+        if self.dist is None:
+            return [float(v) for v in vals]
+        t = self.torch.tensor(list(vals), device=self.red_dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+
+def timed(ctx, step, steps, warmup, prewarm_ms=0.0):
+    """W untimed warm-ups, then EXACTLY `steps` steps between barrier + synchronize on both sides.  Returns (wall seconds for the
+    K steps, max over ranks; mean and median HIP-event milliseconds per step on the launch stream, max over ranks)."""
+    torch = ctx.torch
+    ctx.barrier()
+    if prewarm_ms > 0:
+        # The MI355X raises its shader clock over the first tens of milliseconds of sustained load (the same kernel takes ~15 % longer
+        # in the first 20 launches after idle).  These launches are untimed; config.cold_ms reports the run without them.
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < prewarm_ms:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        evs[i].record()
+        step()
+    evs[steps].record()
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    mean_ms = evs[0].elapsed_time(evs[steps]) / steps
+    median_ms = per[steps // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
+    elapsed, mean_ms, median_ms = ctx.max_over_ranks([elapsed, mean_ms, median_ms])
+    return elapsed, mean_ms, median_ms
+
+
+class FusedBatch:
+    """B frames of W x H through the fused raw->sRGB launch, frame i on rank i mod N; every frame keeps its own output buffer"""
+
+    def __init__(self, ctx, ipa, util, W, H, B, cfa, src_kind, out_kind, data, seed0):
+        torch = ctx.torch
+        self.ctx, self.W, self.H, self.B = ctx, W, H, B
+        self.is_float = src_kind == "f32"
+        self.out_type = {"f32": ipa.OUT_F32, "u8": ipa.OUT_U8, "u16": ipa.OUT_U16}[out_kind]
+        out_dt = {"f32": torch.float32, "u8": torch.uint8, "u16": torch.int16}[out_kind]
+        self.mine = [i for i in range(B) if i % ctx.world == ctx.rank]
+        self.srcs, self.dsts = [], []
+        for i in self.mine:
+            ints = synth_frame(torch, H, W, data, seed0 + i)
+            self.srcs.append(ints.to(torch.float32).reshape(-1).contiguous() if self.is_float else ints.to(torch.int16).reshape(-1).contiguous())
+            del ints
+            self.dsts.append(torch.empty(H * W * 3, dtype=out_dt, device="cuda"))
+        self.cm = util.cam_matrix()
+        self.plan = ipa.FusedPlan(width=W, height=H, is_float=self.is_float, black0=util.BLACK, white0=util.WHITE, cfa=cfa, wb_coeffs=util.WB,
+                                  cam_to_xyz_normalized=self.cm, out_type=self.out_type)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.in_b = 4.0 if self.is_float else 2.0
+        self.out_b = {"f32": 12.0, "u8": 3.0, "u16": 6.0}[out_kind]
+        self.launches_per_step = max(1, len(self.mine))
+
+    def step(self):
+        for s, d in zip(self.srcs, self.dsts):
+            self.plan.run(s, d, self.stream)
+
+    def alg_bytes_per_launch(self):
+        return (self.in_b + self.out_b) * self.H * self.W
+
+
+def oracle_check(ctx, util, wl, rows=None):
+    """whole-frame (or first `rows` rows) bit-for-bit comparison of the rank's first frame with the CPU oracle"""
+    import numpy as np
+    import oracle
+    torch = ctx.torch
+    H, W = wl.H, wl.W
+    src, dst = wl.srcs[0], wl.dsts[0]
+    wl.plan.run(src, dst, wl.stream); torch.cuda.synchronize()
+
+    def compare(n):
+        part = src[: min(H, n + 2) * W].cpu().numpy().reshape(-1, W)
+        desc = oracle.make_pipeline(part if wl.is_float else part.view(np.uint16), cfa="RGGB", source_kind=1 if wl.is_float else 0,
+                                    blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=wl.cm)
+        want = torch.from_numpy(oracle.pipeline_run(desc)[:n].reshape(-1))
+        got = dst[: n * W * 3].cpu()
+        if not torch.equal(got.view(torch.int32), want.view(torch.int32)):
+            util.assert_bits_equal(got.numpy().reshape(n, W, 3), want.numpy().reshape(n, W, 3), "bench parity check")
+    if rows is not None:
+        compare(rows)
+        return "first %d rows of the rank's first frame bit-identical to the CPU oracle" % rows
+    try:
+        compare(H)
+        return "all %d rows (%d output samples) bit-identical to the CPU oracle" % (H, H * W * 3)
+    except MemoryError:
+        compare(12)
+        return "first 12 rows bit-identical to the CPU oracle (no host memory for the whole frame)"
+
+
+def copy_ceiling(ctx, nbytes):
+    """device-to-device copy of `nbytes` (read + write counted): the practical HBM ceiling next to the 8 TB/s spec peak"""
+    torch = ctx.torch
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def valu_model(kernel_ms):
+    """The VALU-issue model of the fused kernel: dynamic instruction counts per launch by issue class
+    (rocprofv3 PMC + the class split of the hot loop's disassembly) x the measured issue cost per class (tools/ubench2.hip),
+    spread over the chip's SIMDs -- everything taken from the tracked file profiles/r*_valu_model.json."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_model.json")))
+    if not files:
+        return None
+    try:
+        m = json.load(open(files[-1]))
+        pred = m["predicted_ms"]
+        return {"bound": "valu-issue", "insts_per_launch": m["insts_per_launch"], "ns_per_wave_inst": m["ns_per_wave_inst"], "simds": m["simds"],
+                "predicted_ms": pred, "measured_ms": round(kernel_ms, 4), "frac": round(pred / kernel_ms, 4),
+                "note": "predicted = sum(class count x class issue ns) / SIMDs: the time the VALU needs just to issue the kernel's instructions; "
+                        "frac = predicted / measured (1.0 = VALU-issue-bound)", "source": os.path.relpath(files[-1], ROOT)}
+    except Exception as e:      # a malformed evidence file must not take the bench line down
+        return {"error": repr(e)}
+
+
 def main():
     args = parse()
-    import torch
+    ctx = Ctx(args)
+    torch = ctx.torch
     import imagepipe_amd as ipa
     import util
+    ipa.init(ctx.local_rank)
+    rank, world = ctx.rank, ctx.world
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        # IPK_BENCH_SHARE_GPU=1 (development only): all ranks on one GPU over gloo, to exercise the N > 1 control flow on a 1-GPU box
-        share = os.environ.get("IPK_BENCH_SHARE_GPU") == "1"
-        if share:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    red_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else "cuda"
-    ipa.init(local_rank)
+    cW, cH, cfa, maxw, cB, cidx = CONFIGS[args.config]
+    W = args.width or cW
+    H = args.height or cH
+    B = args.batch if args.batch is not None else cB
+    weak = B is None
+    if weak:
+        B = world
+    if args.config in ("c5", "c5b") and (args.width is None and args.height is None):
+        return main_xtrans(args, ctx, ipa, util, W, H, cfa, maxw)
 
-    H, W = args.height, args.width
-    ints = synth_frame(torch, H, W, args.data, util.SEED + 2 + rank)
-    is_float = args.src == "f32"
-    src = ints.to(torch.float32).reshape(-1).contiguous() if is_float else ints.to(torch.int16).reshape(-1).contiguous()
-    del ints
-    out_type = {"f32": ipa.OUT_F32, "u8": ipa.OUT_U8, "u16": ipa.OUT_U16}[args.out]
-    out_dt = {"f32": torch.float32, "u8": torch.uint8, "u16": torch.int16}[args.out]
-    dst = torch.empty(H * W * 3, dtype=out_dt, device="cuda")
-    cm = util.cam_matrix()
-    plan = ipa.FusedPlan(width=W, height=H, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
-                         cam_to_xyz_normalized=cm, out_type=out_type)
-    stream = torch.cuda.current_stream().cuda_stream
+    wl = FusedBatch(ctx, ipa, util, W, H, B, cfa, args.src, args.out, args.data, util.SEED + 2)
 
-    def step():
-        plan.run(src, dst, stream)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- correctness check against the CPU oracle (outside the timed region): the whole frame, every output sample ----
+    # ---- correctness check against the CPU oracle (outside the timed region) ----
     checked = None
-    if not args.no_check and rank == 0 and args.out == "f32":
-        import numpy as np
-        import oracle
-        step(); torch.cuda.synchronize()
+    if not args.no_check and rank == 0 and args.out == "f32" and cfa == "RGGB" and wl.mine:
+        checked = oracle_check(ctx, util, wl, rows=None if B <= world else 64)
 
-        def compare(rows):
-            part = src[: min(H, rows + 2) * W].cpu().numpy().reshape(-1, W)
-            desc = oracle.make_pipeline(part if is_float else part.view(np.uint16), cfa="RGGB", source_kind=1 if is_float else 0,
-                                        blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
-            want = torch.from_numpy(oracle.pipeline_run(desc)[:rows].reshape(-1))
-            got = dst[: rows * W * 3].cpu()
-            if not torch.equal(got.view(torch.int32), want.view(torch.int32)):
-                util.assert_bits_equal(got.numpy().reshape(rows, W, 3), want.numpy().reshape(rows, W, 3), "bench parity check")
-        try:
-            compare(H)
-            checked = "all %d rows (%d output samples) bit-identical to the CPU oracle" % (H, H * W * 3)
-        except MemoryError:
-            compare(12)
-            checked = "first 12 rows bit-identical to the CPU oracle (no host memory for the whole frame)"
+    extras = (not args.no_extras) and args.config == "c3" and args.width is None and args.height is None and args.batch is None
+    cold_ms = None
+    if extras:
+        # the same K steps straight after idle (rank 0 has just spent seconds in the parity check), no clock pre-warm
+        ctx.barrier(); time.sleep(0.5)
+        _, cold_ms, _ = timed(ctx, wl.step, args.steps, 0, 0.0)
 
-    # every rank starts its clock pre-warm together (rank 0 has just spent seconds in the parity check; a rank that warmed up
-    # early would sit idle at the barrier below and cool down again)
-    barrier()
-    # The MI355X raises its shader clock over the first tens of milliseconds of sustained load (measured: the same kernel
-    # takes 0.78 ms in the first 20 launches after idle and 0.68 ms from ~50 launches on).  These launches are untimed.
-    t_pw = time.perf_counter()
-    while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
-        for _ in range(16):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: avg kernel (+launch gap) per step
-    if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
-
-    mp_total = world * args.steps * (H * W) / 1e6
+    elapsed, mean_ms, median_ms = timed(ctx, wl.step, args.steps, args.warmup, args.prewarm_ms)
+    kernel_ms = mean_ms / wl.launches_per_step                  # HIP events on the launch stream: average launch duration over the timed region
+    mp_total = args.steps * B * (H * W) / 1e6
     value = mp_total / elapsed
-    in_b = 4.0 if is_float else 2.0
-    out_b = {"f32": 12.0, "u8": 3.0, "u16": 6.0}[args.out]
-    alg_bytes = (in_b + out_b) * H * W
+    alg_bytes = wl.alg_bytes_per_launch()
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     result = {
@@ -179,22 +310,28 @@ def main():
         "value": round(value, 1), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (%s, 14-bit RGGB sensor values, torch Philox seed 0x%X+rank)" % (args.data, util.SEED + 2),
-        "config": {"workload": "%dx%d (%.0f MP) synthetic RGGB Bayer %s mosaic -> fused gofloat+demosaic+tolab+basecurve+fromlab+gamma -> %s RGB, one frame per GPU per step"
-                               % (W, H, H * W / 1e6, args.src, args.out),
-                   "frame": [W, H], "src": args.src, "out": args.out, "frames_per_step": world, "prewarm_ms": args.prewarm_ms, "sharding": "one independent frame per GPU, no collective"},
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (%s, 14-bit %s sensor values, torch Philox seed 0x%X+frame)" % (args.data, cfa if len(cfa) == 4 else "X-Trans", util.SEED + 2),
+        "config": {"workload": "%dx%d (%.0f MP) synthetic %s %s mosaic -> fused gofloat+demosaic+tolab+basecurve+fromlab+gamma -> %s RGB, %s"
+                               % (W, H, H * W / 1e6, cfa if len(cfa) == 4 else "X-Trans", args.src, args.out,
+                                  "one frame per GPU per step" if weak else "%d frames per step, frame i on rank i mod N" % B),
+                   "baseline_config": "BASELINE.json configs[%d]" % cidx,
+                   "frame": [W, H], "src": args.src, "out": args.out, "frames_per_step": B, "prewarm_ms": args.prewarm_ms,
+                   "sharding": "independent frames, no data-path collective", "host_glibc": glibc_version()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "k_fused_bayer", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel": "k_fused_bayer", "kernel_ms": round(kernel_ms, 4), "kernel_ms_median": round(median_ms / wl.launches_per_step, 4),
+                     "algorithmic_bytes_per_launch": alg_bytes},
     }
+    if cold_ms is not None:
+        result["config"]["cold_ms"] = round(cold_ms / wl.launches_per_step, 4)
     if checked:
         result["parity_check"] = checked
     # HBM traffic per launch: not measurable from inside this process (PMC counters need rocprofv3); taken from the
     # committed rocprofv3 passes of this same command (tools/profile.sh -> profiles/<round>_counters.json: separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note) when the workload matches.
-    if rank == 0 and (W, H, args.src, args.out, args.data) == (10000, 10000, "f32", "f32", "noise"):
-        import glob
+    headline = (W, H, args.src, args.out, args.data, weak) == (10000, 10000, "f32", "f32", "noise", True)
+    if rank == 0 and headline:
         profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))
         if profs:
             try:
@@ -204,62 +341,175 @@ def main():
                     result["roofline"]["traffic_source"] = os.path.relpath(profs[-1], ROOT)
             except Exception:
                 pass
+        vm = valu_model(kernel_ms)
+        if vm:
+            result["roofline_valu"] = vm
 
-    # ---- optional: one frame sharded by row bands over the ranks, 1-row halo exchange (RCCL P2P) before every launch ----
-    if args.band:
-        from imagepipe_amd import parallel as par
-        bands = par.band_plan(H, world, 2)
-        band = bands[rank]
-        slab, own = par.alloc_slab(band, W, src.dtype, "cuda")
-        own.copy_(src.view(H, W)[band.out_row0: band.out_row0 + band.out_rows])
-        plan_b = ipa.FusedPlan(width=W, height=H, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
-                               cam_to_xyz_normalized=cm, out_type=out_type, band=(band.src_row0, band.src_rows, band.out_row0, band.out_rows))
-        out_b = plan_b.new_output()
+    if extras:
+        result["roofline"]["copy_ceiling_GBps"] = round(copy_ceiling(ctx, 1200 * 1000 * 1000), 1)     # every rank (keeps the ranks in step)
+        result["roofline"]["frac_of_copy_ceiling"] = round(achieved / result["roofline"]["copy_ceiling_GBps"], 4)
+        other = {}
+        for kind in ("smooth", "photo"):
+            w2 = FusedBatch(ctx, ipa, util, W, H, world, cfa, args.src, args.out, kind, util.SEED + 2)
+            _, m2, md2 = timed(ctx, w2.step, max(5, args.steps // 2), 2, 0.0)       # the clock is still loaded from the main run
+            other[kind] = {"kernel_ms": round(m2, 4), "kernel_ms_median": round(md2, 4), "frac": round(alg_bytes / (m2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del w2
+        result["other_data"] = other
+        # BASELINE.json configs[3]: 64 x 24 MP frames, frame i -> rank i mod N, compute-only and with the all-gather of the results
+        del wl
+        torch.cuda.empty_cache()
+        result["batch_64x24MP"] = batch_mode(ctx, ipa, util, 6000, 4000, 64, "f32", "f32", args.data, steps=5, warmup=1, gather=world > 1)
 
-        def step_band():
-            if world > 1:
-                par.exchange_halo_inplace(slab, band, bands)
-            plan_b.run(slab.view(-1), out_b, stream)
+    if args.config == "c4" or (args.batch is not None and args.batch > world):
+        result["with_gather"] = gather_leg(ctx, wl, steps=max(2, args.steps // 4)) if world > 1 else {
+            "note": "one GPU: every result is already resident on it, the gather is a no-op"}
 
-        for _ in range(args.warmup):
-            step_band()
-        barrier()
-        tb = time.perf_counter()
-        for _ in range(args.steps):
-            step_band()
-        barrier()
-        eb = time.perf_counter() - tb
-        if dist is not None:
-            t = torch.tensor([eb], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            eb = float(t[0])
-        result["band_mode"] = {"ms_per_frame": round(eb / args.steps * 1e3, 4), "value": round(args.steps * H * W / 1e6 / eb, 1), "unit": "MP/s",
-                               "scaling": "strong", "rows_per_rank": band.out_rows, "halo_bytes_per_neighbour": W * (4 if is_float else 2),
-                               "gather": "none (bands stay on their GPUs)"}
+    # ---- optional: one frame sharded by row bands over the ranks, 1-row halo exchange (P2P) before every launch ----
+    if args.band and weak and not extras:
+        result["band_mode"] = band_leg(ctx, ipa, util, wl, args)
 
     # ---- CPU baseline: the oracle's reference-shaped pipeline (unfused, one task per row) on this host ----
     if rank == 0 and not args.no_cpu_baseline:
-        import numpy as np
-        import oracle
-        ch, cw = 4000, 6000                                   # a 24 MP sample of the same synthetic workload
-        sample = util.noise_u16(util.SEED + 2, ch, cw).astype(np.float32) if args.data == "noise" else util.smooth_u16(util.SEED + 2, ch, cw).astype(np.float32)
-        desc = oracle.make_pipeline(sample, cfa="RGGB", source_kind=1, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
-                                    wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
-        oracle.pipeline_run(desc)                              # warm-up (tables, page faults)
-        n = 0; t0 = time.perf_counter()
-        while True:
-            oracle.pipeline_run(desc); n += 1
-            dt = time.perf_counter() - t0
-            if dt >= args.cpu_seconds or n >= 50:
-                break
-        result["cpu_baseline"] = {"value": round(n * ch * cw / 1e6 / dt, 1), "unit": "MP/s", "cores": oracle.max_threads(), "kind": "port",
-                                  "sample": "%d x 24 MP (6000x4000) frames of the same synthetic RGGB f32 workload through the C restatement of the "
-                                            "reference's unfused per-op pipeline (one OpenMP task per row); the Rust reference cannot be built here" % n}
+        result["cpu_baseline"] = cpu_baseline(util, args.data, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()                      # the other ranks wait here while rank 0 runs the CPU baseline leg
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()                  # the other ranks wait here while rank 0 runs the CPU baseline leg
+        ctx.dist.destroy_process_group()
+
+
+def gather_leg(ctx, wl, steps):
+    """compute + all-gather of every frame's result to every rank (SURVEY.md 8e prices the f32 gather above the compute; both
+    figures are reported).  torch.distributed (RCCL) all_gather_into_tensor, one collective per round of N frames."""
+    torch, dist = ctx.torch, ctx.dist
+    try:
+        rounds = (wl.B + ctx.world - 1) // ctx.world
+        if rounds * ctx.world != wl.B:
+            return {"error": "batch not a multiple of the rank count"}
+        per = wl.H * wl.W * 3
+        big = [torch.empty(ctx.world * per, dtype=wl.dsts[0].dtype, device="cuda") for _ in range(rounds)]
+
+        def step():
+            for j, (s, d) in enumerate(zip(wl.srcs, wl.dsts)):
+                wl.plan.run(s, d, wl.stream)
+                dist.all_gather_into_tensor(big[j], d)          # enqueued behind frame j's kernel; frame j+1's launch follows on the same stream
+        elapsed, _, _ = timed(ctx, step, steps, 1, 0.0)
+        mp = steps * wl.B * wl.H * wl.W / 1e6
+        return {"value": round(mp / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "gathered_bytes_per_rank_per_step": per * wl.dsts[0].element_size() * wl.B,
+                "collective": "all_gather_into_tensor (RCCL) of the f32 results, one per round of N frames"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def batch_mode(ctx, ipa, util, W, H, B, src_kind, out_kind, data, steps, warmup, gather):
+    wl = FusedBatch(ctx, ipa, util, W, H, B, "RGGB", src_kind, out_kind, data, util.SEED + 1000)
+    elapsed, mean_ms, median_ms = timed(ctx, wl.step, steps, warmup, 0.0)
+    mp = steps * B * H * W / 1e6
+    kernel_ms = mean_ms / wl.launches_per_step
+    out = {"config": "BASELINE.json configs[3]: %d x %dx%d RGGB %s frames per step, frame i on rank i mod N, no data-path collective" % (B, W, H, src_kind),
+           "value": round(mp / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "scaling": "strong",
+           "frames_on_rank0": len(wl.mine), "kernel_ms": round(kernel_ms, 4),
+           "frac": round(wl.alg_bytes_per_launch() / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if gather:
+        out["with_gather"] = gather_leg(ctx, wl, steps=2)
+    return out
+
+
+def band_leg(ctx, ipa, util, wl, args):
+    """ONE frame row-sharded over the ranks through the C entry points: ipk_band_plan, ipk_band_exchange_halo (RCCL ncclSend/ncclRecv in
+    place on the slab; host transport when the ranks share a GPU), the band form of the fused kernel."""
+    from imagepipe_amd import parallel as par
+    H, W = wl.H, wl.W
+    comm = par.Comm()
+    bands = par.band_plan(H, ctx.world, 2)
+    band = bands[ctx.rank]
+    slab, own = par.alloc_slab(band, W, wl.srcs[0].dtype, "cuda")
+    own.copy_(wl.srcs[0].view(H, W)[band.out_row0: band.out_row0 + band.out_rows])
+    plan_b = ipa.FusedPlan(width=W, height=H, is_float=wl.is_float, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
+                           cam_to_xyz_normalized=wl.cm, out_type=wl.out_type, band=(band.src_row0, band.src_rows, band.out_row0, band.out_rows))
+    out_b = plan_b.new_output()
+
+    def step_band():
+        comm.exchange_halo(slab, bands, wl.stream)
+        plan_b.run(slab.view(-1), out_b, wl.stream)
+    eb, _, _ = timed(ctx, step_band, args.steps, args.warmup, 0.0)
+    comm.close()
+    return {"ms_per_frame": round(eb / args.steps * 1e3, 4), "value": round(args.steps * H * W / 1e6 / eb, 1), "unit": "MP/s",
+            "scaling": "strong", "rows_per_rank": band.out_rows, "halo_bytes_per_neighbour": W * (4 if wl.is_float else 2),
+            "transport": comm.transport, "gather": "none (bands stay on their GPUs)"}
+
+
+def cpu_baseline(util, data, seconds):
+    import numpy as np
+    import oracle
+    ch, cw = 4000, 6000                                   # a 24 MP sample of the same synthetic workload
+    sample = util.noise_u16(util.SEED + 2, ch, cw).astype(np.float32) if data == "noise" else util.smooth_u16(util.SEED + 2, ch, cw).astype(np.float32)
+    desc = oracle.make_pipeline(sample, cfa="RGGB", source_kind=1, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                                wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    oracle.pipeline_run(desc)                              # warm-up (tables, page faults)
+    n = 0; t0 = time.perf_counter()
+    while True:
+        oracle.pipeline_run(desc); n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 50:
+            break
+    return {"value": round(n * ch * cw / 1e6 / dt, 1), "unit": "MP/s", "cores": oracle.max_threads(), "kind": "port",
+            "sample": "%d x 24 MP (6000x4000) frames of the same synthetic RGGB f32 workload through the C restatement of the "
+                      "reference's unfused per-op pipeline (one OpenMP task per row); the Rust reference cannot be built here" % n}
+
+
+def main_xtrans(args, ctx, ipa, util, W, H, cfa, maxw):
+    """configs[4]: 8640x5760 X-Trans -> 2160x1440 (c5: gofloat + scaled_demosaic in one pass, then the point-wise chain) or full size
+    (c5b: the fused kernel in generic-CFA mode).  One frame per GPU per step.  The roofline object is the dominant kernel's:
+    c5 times ipk_raw_scaled_demosaic alone for it (its algorithmic bytes: 4 W H in + 16 nW nH out), c5b the single fused launch."""
+    torch = ctx.torch
+    import ctypes as C
+    ints = synth_frame(torch, H, W, args.data, util.SEED + 2 + ctx.rank)
+    src = ints.to(torch.float32).reshape(-1).contiguous()
+    del ints
+    img = ipa.RawImage(width=W, height=H, data=src, cfa=cfa, is_float=True, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                       wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    pipe = ipa.Pipeline.new_from_source(img)
+    pipe.globals.settings.maxwidth = maxw
+    out = pipe.run()
+    nW, nH = out.width, out.height
+
+    def step():
+        pipe.run(out=out.data)
+    elapsed, mean_ms, median_ms = timed(ctx, step, args.steps, args.warmup, args.prewarm_ms)
+    if maxw:
+        dst4 = torch.empty(nW * nH * 4, dtype=torch.float32, device="cuda")
+        L = ipa.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def kstep():
+            rc = L.ipk_raw_scaled_demosaic(src.data_ptr(), ipa.SRC_F32, W, 0, 0, W, H, C.c_float(util.BLACK), C.c_float(util.WHITE), cfa.encode(), nW, nH,
+                                           dst4.data_ptr(), stream)
+            assert rc == 0, rc
+        _, kernel_ms, kmed = timed(ctx, kstep, args.steps, args.warmup, 0.0)
+        kname, alg_bytes = "k_raw_scaled_demosaic_w8m", 4.0 * W * H + 16.0 * nW * nH
+    else:
+        kernel_ms, kmed, kname, alg_bytes = mean_ms, median_ms, "k_fused_bayer (generic-CFA mode)", 16.0 * W * H
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "megapixels/sec full raw->sRGB pipe (input mosaic pixels)",
+        "value": round(args.steps * ctx.world * H * W / 1e6 / elapsed, 1), "unit": "MP/s",
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (%s, 14-bit X-Trans sensor values, torch Philox seed 0x%X+rank)" % (args.data, util.SEED + 2),
+        "config": {"workload": "%dx%d (%.1f MP) synthetic X-Trans 6x6 f32 mosaic -> %dx%d f32 RGB (%s), one frame per GPU per step"
+                               % (W, H, H * W / 1e6, nW, nH, "gofloat+scaled_demosaic, then tolab+basecurve+fromlab+gamma in one pass" if maxw else "fused, generic-CFA mode"),
+                   "baseline_config": "BASELINE.json configs[4]", "frame": [W, H], "out_frame": [nW, nH], "output_MP_per_s": round(args.steps * ctx.world * nW * nH / 1e6 / elapsed, 1),
+                   "used_fused": bool(pipe.last_used_fused), "host_glibc": glibc_version()},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_median": round(kmed, 4), "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if ctx.rank == 0:
+        print(json.dumps(result), flush=True)
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -52,6 +52,16 @@ class PipelineDesc(C.Structure):
     ]
 
 
+class Band(C.Structure):
+    """ipk_band"""
+    _fields_ = [("out_row0", _sz), ("out_rows", _sz), ("src_row0", _sz), ("src_rows", _sz)]
+
+
+# ipk_exchange_fn: (ctx, send_peer, send, send_bytes, recv_peer, recv, recv_bytes) -> int
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, _vp, _sz, C.c_int, _vp, _sz)
+_bp = C.POINTER(Band)
+COMM_ID_BYTES = 128
+
 # name -> (restype, argtypes).  Every symbol include/imagepipe_amd.h declares is listed here;
 # tests/test_cabi_symbols.py cross-checks this table against the header text.
 _GO = [_sz, _sz, _sz, _sz, _sz]                       # owidth, x, y, width, height
@@ -148,6 +158,21 @@ SIGNATURES = {
     "ipk_cache_contains": (C.c_int, [_vp, C.c_char_p]),
     "ipk_cache_stats": (C.c_int, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ipk_cache_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int)]),
+    "ipk_band_plan": (C.c_int, [_sz, C.c_int, C.c_int, _bp]),
+    "ipk_band_plan_scaled": (C.c_int, [_sz, _sz, C.c_int, _bp]),
+    "ipk_raw_scaled_demosaic_band": (C.c_int, [_vp, C.c_int, _sz, _sz, _sz, _sz, C.c_float, C.c_float, C.c_char_p, _sz, _sz, _bp, _vp, _vp]),
+    "ipk_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ipk_comm_init_rccl": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "ipk_comm_init_host": (C.c_int, [C.c_int, C.c_int, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
+    "ipk_comm_free": (C.c_int, [_vp]),
+    "ipk_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ipk_band_exchange_halo": (C.c_int, [_vp, _vp, _sz, _bp, _vp]),
+    "ipk_host_band_exchange_halo": (C.c_int, [_vp, _vp, _sz, _bp]),
+    "ipk_band_gather": (C.c_int, [_vp, _vp, _sz, _bp, C.c_int, _vp]),
+    "ipk_host_band_gather": (C.c_int, [_vp, _vp, _sz, _bp, C.c_int]),
+    "ipk_band_gather_begin": (C.c_int, [_vp, _vp, _sz, _bp, C.c_int, _vp]),
+    "ipk_comm_wait": (C.c_int, [_vp, _vp]),
+    "ipk_comm_selftest": (C.c_int, [_vp]),
     "ipk_pipeline_run_cached": (C.c_int, [C.POINTER(PipelineDesc), _vp, C.c_uint64, _vp, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
 }
 

@@ -17,6 +17,7 @@
 #include "../../include/imagepipe_amd.h"
 #include "ipk_hash.hpp"
 #include "ipk_host.hpp"
+#include "ipk_internal.hpp"
 #include "ipk_launch.hpp"
 
 namespace {
@@ -65,6 +66,16 @@ int require_init() {
   return IPK_OK;
 }
 #define REQUIRE_INIT() do { int rc_ = require_init(); if (rc_) return rc_; } while (0)
+}  // namespace
+namespace ipk {
+int internal_fail(int code, const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return code;
+}
+int internal_require_init() { return require_init(); }
+int internal_device() { return g.device; }
+}  // namespace ipk
+namespace {
 
 hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
@@ -474,8 +485,23 @@ int ipk_raw_scaled_demosaic(const void *src, int src_type, size_t owidth, size_t
     return fail(IPK_ERR_INVALID, "bad raw_scaled_demosaic arguments");
   ipk::Cfa cfa; DevCfa dev; int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
   const int norm_fast = validate_cdiv_for_range(black0, white0 - black0, src_type == IPK_SRC_U16) ? 1 : 0;
-  if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream));
-  else ipk::launch_raw_scaled_demosaic<float>(static_cast<const float *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream));
+  if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream), 0, 0, 0);
+  else ipk::launch_raw_scaled_demosaic<float>(static_cast<const float *>(src), owidth, x, y, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream), 0, 0, 0);
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+// one output-row band of the same (ipk_band_plan_scaled): multi-GPU sharding of a frame that OpDemosaic scales
+int ipk_raw_scaled_demosaic_band(const void *src, int src_type, size_t owidth, size_t x, size_t width, size_t height, float black0, float white0,
+                                 const char *cfa_pat, size_t nwidth, size_t nheight, const ipk_band *band, float *dst4, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst4 || !cfa_pat || !band || !dims_ok(width, height) || !dims_ok(nwidth, nheight) || (src_type != IPK_SRC_U16 && src_type != IPK_SRC_F32))
+    return fail(IPK_ERR_INVALID, "bad raw_scaled_demosaic_band arguments");
+  if (band->out_rows == 0) return IPK_OK;
+  if (band->out_row0 + band->out_rows > nheight || band->src_row0 + band->src_rows > height) return fail(IPK_ERR_INVALID, "band outside the frame");
+  ipk::Cfa cfa; DevCfa dev; int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
+  const int norm_fast = validate_cdiv_for_range(black0, white0 - black0, src_type == IPK_SRC_U16) ? 1 : 0;
+  if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, 0, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream), band->src_row0, band->out_row0, band->out_rows);
+  else ipk::launch_raw_scaled_demosaic<float>(static_cast<const float *>(src), owidth, x, 0, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream), band->src_row0, band->out_row0, band->out_rows);
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }

@@ -236,6 +236,9 @@ struct TransformArgs {
   // optional fused OpGoFloat (CFA branch, gofloat.rs:122-130/158-166): the source is the raw sensor frame
   int norm; float min0, range0; uint64_t src_pitch, src_x, src_y;
   int norm_fast; float inv_range0;    // fused OpGoFloat: the host validated cdiv_fast for range0 (else IEEE division)
+  // output-row band [out_r0, out_r1) of the fused gofloat + scaled_demosaic kernels (multi-GPU sharding of one frame):
+  // dst row 0 = output row out_r0; the source slab's first row is folded into src_y (which may wrap: pointer arithmetic mod 2^64)
+  uint32_t out_r0, out_r1;
 };
 // (v - center) / skip  (scaling.rs:104-105): cdiv_fast when the host validated the divisor and the dividend is in the proven
 // zone, the IEEE division otherwise (zero or negative skips of degenerate / rotated transforms, absurd centres)
@@ -422,7 +425,7 @@ __global__ void k_raw_scaled_demosaic(const T *__restrict__ src, TransformArgs a
   __syncthreads();
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= a.nwidth) return;
-  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+  for (uint32_t row = a.out_r0 + blockIdx.y; row < a.out_r1; row += gridDim.y) {
     const float from_x_r = a.tlx + a.skip_y_x * (float)row;
     const float to_x_r = a.tlx + a.skip_y_x * (float)(row + 1);
     const float from_y_r = a.tly + a.skip_y_y * (float)row;
@@ -442,7 +445,7 @@ __global__ void k_raw_scaled_demosaic(const T *__restrict__ src, TransformArgs a
       const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
       const float dy2 = delta_y * delta_y;
       uint32_t xm = xm0;
-      const T *rowp = src + (size_t)(y + a.src_y) * a.src_pitch + a.src_x;
+      const T *rowp = src + (size_t)((uint64_t)y + a.src_y) * a.src_pitch + a.src_x;
       for (uint32_t x = from_x; x <= to_x; ++x) {
         const float delta_x = tb_div((float)x - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
         float factor = 1.0f - (delta_x * delta_x) - dy2;
@@ -462,7 +465,7 @@ __global__ void k_raw_scaled_demosaic(const T *__restrict__ src, TransformArgs a
     }
     float4 o;
     o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
-    reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
+    reinterpret_cast<float4 *>(dst)[(size_t)(row - a.out_r0) * a.nwidth + col] = o;
   }
 }
 // The same for windows of at most 8 x 8 source samples (every scale up to 7, i.e. all previews larger than 1/7 size).
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
   uint32_t kend = 0;                                     // one past the last sample index any lane of the wave uses
   #pragma unroll
   for (uint32_t k = 0; k < 8; ++k) if (__builtin_amdgcn_ballot_w64(kshift + nx > k) != 0) kend = k + 1;
-  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+  for (uint32_t row = a.out_r0 + blockIdx.y; row < a.out_r1; row += gridDim.y) {
     const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)row)));
     const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)(row + 1))));
     const float center_y = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
       const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
       const float dy2 = delta_y * delta_y;
       float d[8];
-      Row8<T>::load(src + (size_t)(y + a.src_y) * a.src_pitch + a.src_x + lx, d);
+      Row8<T>::load(src + (size_t)((uint64_t)y + a.src_y) * a.src_pitch + a.src_x + lx, d);
       const uint32_t bits = s_bits[(y % 48) * 48 + xm0];
       #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = d[k] - a.min0;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
     }
     float4 o;
     o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
-    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
+    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)(row - a.out_r0) * a.nwidth + col] = o;
   }
 }
 // The same again for filters with a short period (pw x ph cells, pw * ph <= kW8MaxCells: Bayer, X-Trans, 8x2, 12x12 ...): the
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
   uint32_t kend = 0;
   #pragma unroll
   for (uint32_t k = 0; k < 8; ++k) if (__builtin_amdgcn_ballot_w64(kshift + nx > k) != 0) kend = k + 1;
-  for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
+  for (uint32_t row = a.out_r0 + blockIdx.y; row < a.out_r1; row += gridDim.y) {
     const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)row)));
     const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)(row + 1))));
     const float center_y = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
       const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
       const float dy2 = delta_y * delta_y;
       float d[8];
-      Row8<T>::load(src + (size_t)(y + a.src_y) * a.src_pitch + a.src_x + lx, d);
+      Row8<T>::load(src + (size_t)((uint64_t)y + a.src_y) * a.src_pitch + a.src_x + lx, d);
       const uint32_t cell = (y % ph) * pw + xm;
       #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = d[k] - a.min0;
@@ -687,12 +690,13 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
     }
     float4 o;
     o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
-    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)row * a.nwidth + col] = o;
+    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)(row - a.out_r0) * a.nwidth + col] = o;
   }
 }
 template <typename T>
 void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0,
-                                int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pw, int ph, float *dst4, hipStream_t s) {
+                                int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pw, int ph, float *dst4, hipStream_t s,
+                                size_t band_src_row0, size_t band_out_row0, size_t band_out_rows) {
   TransformArgs a;
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
@@ -704,13 +708,18 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
   a.has_cfa = 1; a.norm = 1; a.min0 = black0; a.range0 = white0 - black0; a.src_pitch = owidth; a.src_x = x; a.src_y = y;
   a.norm_fast = norm_fast; a.inv_range0 = 1.0f / a.range0;
+  // whole frame, or the output-row band [band_out_row0, +band_out_rows) of a frame sharded across GPUs: `src` then points at sensor
+  // row y + band_src_row0 (the slab's first row), which is folded into src_y; window bounds still clamp against the full height
+  a.out_r0 = 0; a.out_r1 = (uint32_t)nheight;
+  if (band_out_rows) { a.out_r0 = (uint32_t)band_out_row0; a.out_r1 = (uint32_t)(band_out_row0 + band_out_rows); a.src_y = (uint64_t)0 - (uint64_t)band_src_row0; }
+  const size_t out_rows = a.out_r1 - a.out_r0;
   a.components = has_fourth_colour ? 4 : 3;               // the w8 kernel skips the fourth bin for three-colour filters (it stays 0.0)
   // windows of at most 8 x 8 samples: floor(skip*(c+1)) - floor(skip*c) + 1 <= ceil(skip) + 1
   if (a.skip_x_x >= 1.0f && a.skip_x_x <= 7.0f && a.skip_y_y >= 1.0f && a.skip_y_y <= 7.0f && width >= 8 &&
       (reinterpret_cast<uintptr_t>(dst4) & 15) == 0) {
     const unsigned gx = (unsigned)((nwidth + 255) / 256);
     const unsigned want = std::max(1u, 4096u / gx);                          // ~16 blocks of 256 threads per CU in total
-    const dim3 grid(gx, (unsigned)std::min<size_t>(nheight, want), 1);       // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
+    const dim3 grid(gx, (unsigned)std::min<size_t>(out_rows, want), 1);      // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
 #ifndef IPK_W8_SELECT
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
       hipLaunchKernelGGL(k_raw_scaled_demosaic_w8m<T>, grid, dim3(256), (size_t)pw * ph * 32 * sizeof(float), s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
@@ -720,10 +729,10 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
     hipLaunchKernelGGL(k_raw_scaled_demosaic_w8<T>, grid, dim3(256), 0, s, src, a, cfa48_dev, dst4);
     return;
   }
-  hipLaunchKernelGGL(k_raw_scaled_demosaic<T>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst4);
+  hipLaunchKernelGGL(k_raw_scaled_demosaic<T>, grid_rows_few(nwidth, out_rows, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst4);
 }
-template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, int, int, float *, hipStream_t);
-template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, int, int, float *, hipStream_t);
+template void launch_raw_scaled_demosaic<uint16_t>(const uint16_t *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, int, int, float *, hipStream_t, size_t, size_t, size_t);
+template void launch_raw_scaled_demosaic<float>(const float *, size_t, size_t, size_t, size_t, size_t, float, float, int, int, size_t, size_t, const uint8_t *, int, int, float *, hipStream_t, size_t, size_t, size_t);
 template void launch_transform_buffer<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, float *, hipStream_t);
 template void launch_transform_buffer<uint8_t>(const uint8_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint8_t *, hipStream_t);
 template void launch_transform_buffer<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, size_t, size_t, size_t, const uint8_t *, uint16_t *, hipStream_t);

@@ -39,7 +39,8 @@ void launch_raster_scale_down(const void *src, int src_is_u16, size_t owidth, si
                               size_t nwidth, size_t nheight, const void *gamma_reverse_pairs, float *dst4, hipStream_t s);
 template <typename T>
 void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0, int norm_fast, int has_fourth_colour,
-                                size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pattern_width, int pattern_height, float *dst4, hipStream_t s);
+                                size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pattern_width, int pattern_height, float *dst4, hipStream_t s,
+                                size_t band_src_row0 = 0, size_t band_out_row0 = 0, size_t band_out_rows = 0);   // band_out_rows == 0: the whole frame
 
 void launch_tolab(const float *src4, size_t npix, const float *mul4, const float *cm12, const void *lab_pairs, float *dst3,
                   int num_cus, hipStream_t s);

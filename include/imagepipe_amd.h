@@ -383,6 +383,69 @@ IPK_API int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src,
                                     int out_type, void *dst, int *ops_run, int *used_fused, void *stream);
 
 /* ---------------------------------------------------------------------------------------- */
+/* Multi-GPU: one process per GPU; a frame batch shards with no exchange (frame i -> rank i mod N, */
+/* src/pipeline.rs:246-249), ONE frame shards by row bands                */
+/* ---------------------------------------------------------------------------------------- */
+
+/* One rank's row band.  Full-resolution path (ipk_raw_to_srgb's band_* fields): output rows [out_row0, +out_rows) of the cropped
+ * frame, and the source rows [src_row0, +src_rows) its slab must hold = the band plus the 1-row halos demosaic::full taps
+ * (src/ops/demosaic.rs:70-74) where they lie inside the frame.  Scaled path: out_* count rows of the nwidth x nheight result and
+ * src_* the source rows its windows read (src/scaling.rs:84-94). */
+typedef struct { size_t out_row0, out_rows, src_row0, src_rows; } ipk_band;
+
+/* Row bands of near-equal size whose boundaries are multiples of the CFA period (2 Bayer, 6 X-Trans, 12), so every band starts
+ * at the frame's CFA phase.  bands[nranks].  Host-only. */
+IPK_API int ipk_band_plan(size_t height, int nranks, int cfa_period, ipk_band *bands);
+/* Output-row bands of scaling::scaled_demosaic (src/scaling.rs:132-145) from width x height to nwidth x nheight: rank k produces
+ * output rows [out_row0, +out_rows) and needs source rows floor(skip*r0) .. floor(skip*r1) (:84-87, clamped to the frame) --
+ * neighbouring ranks' source ranges overlap by a window, nothing is exchanged.  Host-only. */
+IPK_API int ipk_band_plan_scaled(size_t height, size_t nheight, int nranks, ipk_band *bands);
+/* ipk_raw_scaled_demosaic for one band of ipk_band_plan_scaled: `src` points at the slab's first row (sensor row y + band->src_row0,
+ * column 0 of the sensor frame), dst4 receives band->out_rows x nwidth RGBE pixels.  Bit-identical to the same rows of the whole frame. */
+IPK_API int ipk_raw_scaled_demosaic_band(const void *src, int src_type, size_t owidth, size_t x, size_t width, size_t height,
+                                         float black0, float white0, const char *cfa, size_t nwidth, size_t nheight,
+                                         const ipk_band *band, float *dst4, void *stream);
+
+/* A communicator over the ranks that share one frame.  Two transports behind the same entry points:
+ *   RCCL   (ipk_comm_init_rccl): ncclSend/ncclRecv/ncclAllGather on device buffers over xGMI -- the product path on a multi-GPU node;
+ *   host   (ipk_comm_init_host): the caller's own messaging (MPI, gloo, a socket) moves the bytes, staged through host memory --
+ *          for hosts that already have a fabric of their own, and for ranks that share ONE GPU (RCCL refuses two ranks per device).
+ * Nothing here touches pixels: results are bit-identical to the unsharded run by construction of the band kernels. */
+typedef struct ipk_comm ipk_comm;
+#define IPK_COMM_ID_BYTES 128
+/* ncclGetUniqueId on one rank; the caller hands the 128 bytes to every rank by its own means (it has to rendezvous anyway) */
+IPK_API int ipk_comm_unique_id(uint8_t *id128);
+/* ncclCommInitRank on the device ipk_init bound.  Collective over the nranks processes. */
+IPK_API int ipk_comm_init_rccl(const uint8_t *id128, int rank, int nranks, ipk_comm **out);
+/* Host transport.  exchange(ctx, send_peer, send, send_bytes, recv_peer, recv, recv_bytes) must send `send` to send_peer and
+ * receive recv_bytes from recv_peer into `recv` (either peer may be -1 = none), returning 0 on success; it may block until both
+ * complete (MPI_Sendrecv semantics).  Buffers are host memory. */
+typedef int (*ipk_exchange_fn)(void *ctx, int send_peer, const void *send, size_t send_bytes, int recv_peer, void *recv, size_t recv_bytes);
+IPK_API int ipk_comm_init_host(int rank, int nranks, ipk_exchange_fn exchange, void *ctx, ipk_comm **out);
+IPK_API int ipk_comm_free(ipk_comm *comm);
+/* transport: 0 RCCL, 1 host */
+IPK_API int ipk_comm_info(const ipk_comm *comm, int *rank, int *nranks, int *transport);
+/* Halo exchange of the full-resolution path, in place on the slab (device memory, row pitch row_bytes, rows = bands[rank].src_rows):
+ * the band's first / last own row goes to the neighbour above / below, their edge rows arrive in the slab's halo rows.  RCCL: one
+ * ncclGroup of ncclSend/ncclRecv on `stream` (asynchronous); host transport: synchronous.  Bands with no rows are skipped. */
+IPK_API int ipk_band_exchange_halo(ipk_comm *comm, void *slab, size_t row_bytes, const ipk_band *bands, void *stream);
+/* The same on a HOST slab (host transport only; what a caller does before uploading its band). */
+IPK_API int ipk_host_band_exchange_halo(ipk_comm *comm, void *slab, size_t row_bytes, const ipk_band *bands);
+/* Reassembles the result IN PLACE: `frame` is the full out_height x out_row_bytes image on every receiving rank, and each rank's
+ * kernel has already written its own band at its rows (dst = frame + bands[rank].out_row0 * out_row_bytes).  root = -1: every rank
+ * receives every band (ncclAllGather when the bands are equal, one group of ncclSend/ncclRecv straight into place otherwise: the xGMI
+ * mesh is point-to-point, all peers at once); root >= 0: only that rank receives.  Any element type: sizes are bytes. */
+IPK_API int ipk_band_gather(ipk_comm *comm, void *frame, size_t out_row_bytes, const ipk_band *bands, int root, void *stream);
+/* The same on a HOST frame (host transport only). */
+IPK_API int ipk_host_band_gather(ipk_comm *comm, void *frame, size_t out_row_bytes, const ipk_band *bands, int root);
+/* The gather on the communicator's own stream, ordered after the work `after_stream` holds now: frame k's gather overlaps frame
+ * k+1's kernel.  ipk_comm_wait makes `stream` wait for the gathers begun so far (no host block). */
+IPK_API int ipk_band_gather_begin(ipk_comm *comm, void *frame, size_t out_row_bytes, const ipk_band *bands, int root, void *after_stream);
+IPK_API int ipk_comm_wait(ipk_comm *comm, void *stream);
+/* Transport self-check: a ring send/recv and an all-gather of a known pattern on device buffers, verified on the host.  Collective. */
+IPK_API int ipk_comm_selftest(ipk_comm *comm);
+
+/* ---------------------------------------------------------------------------------------- */
 /* Host-pointer forms of the stage kernels: what a Rust `impl ImageOp::run` binds when it keeps   */
 /* its OpBuffers in host Vec<f32>s.  Same arguments as the device forms, minus the stream.       */
 /* ---------------------------------------------------------------------------------------- */

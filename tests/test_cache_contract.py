@@ -220,7 +220,8 @@ def test_cached_staged_resumes_after_last_unchanged_op(ipa, orc):
     b = pipe.run(cache).numpy()
     assert pipe.last_ops_run == 0xF0
     assert_bits_equal(b, orc.pipeline_run(want(exposure=0.7)), "preview after exposure edit")
-    # edit white balance: ops 3..7
+    # edit white balance: ops 3..7 (OpToLab::new stored the NORMALISED as-shot coefficients, colorspaces.rs:33-41: restore those below)
+    wb_at_new = list(pipe.ops.tolab.wb_coeffs)
     pipe.ops.tolab.wb_coeffs = [1.7, 1.0, 1.9, float("nan")]
     c = pipe.run(cache).numpy()
     assert pipe.last_ops_run == 0xF8
@@ -231,7 +232,7 @@ def test_cached_staged_resumes_after_last_unchanged_op(ipa, orc):
     assert pipe.last_ops_run == 0x80
     assert_bits_equal(e, orc.pipeline_run(want(exposure=0.7, wb_coeffs=[1.7, 1.0, 1.9, float("nan")], fliph=True)), "preview after flip")
     # undo everything: the first run's buffers are still there
-    pipe.ops.transform.fliph = False; pipe.ops.tolab.wb_coeffs = list(util.WB); pipe.ops.basecurve.exposure = 0.0
+    pipe.ops.transform.fliph = False; pipe.ops.tolab.wb_coeffs = wb_at_new; pipe.ops.basecurve.exposure = 0.0
     assert pipe.run(cache).numpy().tobytes() == a.tobytes() and pipe.last_ops_run == 0
     # a rotatecrop edit invalidates from op 2 on but keeps the (expensive) demosaic
     pipe.ops.rotatecrop.crop_left = 0.1; pipe.ops.rotatecrop.rotation = 0.05

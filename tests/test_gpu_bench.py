@@ -42,14 +42,65 @@ def test_bench_two_ranks_control_flow():
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["scaling"] == "weak" and d["value"] > 0
 
 
+def test_bench_batch_mode_and_configs():
+    """bench.py --batch (BASELINE.json configs[3] shape, small here; the full 64 x 24 MP batch is tests/test_gpu_fused.py's) and the
+    per-config modes: one JSON line each, strong scaling for a fixed batch, a roofline object per config"""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "6", "--width", "1200", "--height", "800", "--no-cpu-baseline",
+                        "--prewarm-ms", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["scaling"] == "strong" and d["config"]["frames_per_step"] == 6 and d["value"] > 0 and "with_gather" in d and "bit-identical" in d["parity_check"]
+    for cfg, kern in (("c5", "k_raw_scaled_demosaic"), ("c5b", "k_fused_bayer"), ("c2", "k_fused_bayer")):
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--config", cfg, "--no-cpu-baseline", "--no-check", "--prewarm-ms", "0"],
+                           cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _last_json(r.stdout)
+        assert kern in d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] < 1 and d["config"]["baseline_config"].startswith("BASELINE.json configs[")
+
+
+def test_bench_batch_two_ranks():
+    env = dict(os.environ, IPK_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+                        "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "6", "--width", "1024", "--height", "512", "--no-cpu-baseline", "--prewarm-ms", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 6 and d["scaling"] == "strong" and d["value"] > 0
+    assert "value" in d["with_gather"] or "error" in d["with_gather"]          # gloo may refuse device tensors; RCCL is the driver's path
+
+
 @pytest.mark.parametrize("cfa,H,W,nproc", [("RGGB", 150, 600, 2), ("GBRG", 301, 258, 3), ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 180, 300, 4)])
 def test_one_frame_banded_over_ranks_matches_oracle(cfa, H, W, nproc):
-    """row-band sharding of ONE frame with the real kernel: band plan aligned to the CFA period, 1-row halo exchange between
-    neighbours (dist.batch_isend_irecv), band form of the fused kernel, all-gather of the output -- ranks share the GPU over gloo"""
+    """row-band sharding of ONE frame through the C entry points with the real kernel: ipk_band_plan aligned to the CFA period, the 1-row
+    halo exchange in place on the slab (ipk_band_exchange_halo), the band form of the fused kernel writing into its rows of the frame,
+    ipk_band_gather / ipk_band_gather_begin in place (f32 and 8-bit) -- ranks share the GPU, so the communicator runs its host transport"""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                         "--master-port", str(29540 + nproc), os.path.join("tests", "helpers", "band_worker.py"), cfa, str(H), str(W)],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BANDED_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("cfa,H,W,nW,nH,nproc", [("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 576, 864, 216, 144, 2), ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 580, 870, 217, 145, 3),
+                                                 ("RGGB", 400, 600, 150, 100, 4)])
+def test_scaled_path_banded_over_ranks_matches_oracle(cfa, H, W, nW, nH, nproc):
+    """config 5's shape (X-Trans -> 4x smaller) sharded by OUTPUT-row bands: ipk_band_plan_scaled gives each rank the source rows its
+    windows read (scaling.rs:84-94), ipk_raw_scaled_demosaic_band computes the band, ipk_band_gather assembles the frame on rank 0"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29560 + nproc), os.path.join("tests", "helpers", "band_worker.py"), cfa, str(H), str(W), "scaled", str(nW), str(nH)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BANDED_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_rccl_transport_single_rank():
+    """the RCCL transport end to end on the one GPU of this box: ncclGetUniqueId, ncclCommInitRank (one rank), a self ncclSend/ncclRecv
+    group and an ncclAllGather on device buffers (ipk_comm_selftest), the band entry points as no-ops"""
+    code = ("import torch, ctypes as C, imagepipe_amd as ipa; from imagepipe_amd import _lib; ipa.init(0); L=_lib.load();"
+            "idb=C.create_string_buffer(128); _lib.check(L.ipk_comm_unique_id(idb),'id'); h=C.c_void_p();"
+            "_lib.check(L.ipk_comm_init_rccl(idb.raw,0,1,C.byref(h)),'init'); _lib.check(L.ipk_comm_selftest(h),'selftest');"
+            "r=C.c_int(); n=C.c_int(); t=C.c_int(); L.ipk_comm_info(h,C.byref(r),C.byref(n),C.byref(t)); assert (r.value,n.value,t.value)==(0,1,0);"
+            "L.ipk_comm_free(h); print('RCCL_OK')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
 @pytest.mark.parametrize("n_frames,nproc", [(7, 2), (8, 4)])

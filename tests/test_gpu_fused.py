@@ -187,10 +187,13 @@ def test_fused_generic_cfa_vs_oracle(ipa, orc, cfa, shape, is_float):
 def test_sixteen_letter_cfa_is_refused(ipa, orc):
     """rawloader's tile shape for a 16-letter pattern (8x2 or 2x8) cannot be verified here: product and oracle refuse it"""
     raw = util.noise_u16(util.SEED + 81, 32, 300)
-    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, W16))
-    with pytest.raises(ipa.IpkError) as e:
-        pipe.run()
+    with pytest.raises(ipa.IpkError) as e:                              # OpDemosaic::new's cropped_cfa() is the first to parse it
+        ipa.Pipeline.new_from_source(_raw(ipa, raw, W16)).run()
     assert e.value.code == -5 and "16-letter" in str(e.value)           # IPK_ERR_UNSUPPORTED
+    plan = ipa.FusedPlan(width=300, height=32, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa=W16)
+    with pytest.raises(ipa.IpkError) as e:
+        plan.run(ipa.upload_u16(raw), plan.new_output())
+    assert e.value.code == -5
     with pytest.raises(Exception):
         orc.pipeline_run(_oracle_desc(orc, raw, W16))
 
@@ -365,6 +368,52 @@ def test_config2_config3_full_size_vs_oracle(ipa, orc, H, W, is_float):
     same = torch.equal(got.data.cpu().view(torch.int32), want.view(torch.int32))
     if not same:                                             # NaN payloads aside, report where
         assert_bits_equal(got.numpy(), want.numpy().reshape(H, W, 3), "full-size frame")
+
+
+def test_config4_batch_of_64_frames_full_size(ipa, orc):
+    """BASELINE.json configs[3] at its real size on one GPU: a batch of 64 independent 24 MP (6000x4000) RGGB f32 frames through ONE
+    prepared fused launch descriptor, every frame with its own resident input and output (6 GB in, 18 GB out).  Frames are
+    independent pipelines (src/pipeline.rs:246-249).  Five frames spread over the batch are compared sample by sample with the
+    oracle; all the others through size-independent properties: a frame computed inside the batch equals the same frame computed
+    alone afterwards (no cross-frame state, no buffer aliasing), two slots that hold the SAME mosaic produce the same bits, and
+    every frame equals the staged kernels' result (an independent set of kernels, themselves oracle-checked stage by stage)."""
+    import torch
+    H, W, B = 4000, 6000, 64
+    plan = ipa.FusedPlan(width=W, height=H, is_float=True, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
+                         cam_to_xyz_normalized=util.cam_matrix())
+    g = torch.Generator(device="cuda")
+    srcs, outs = [], []
+    for i in range(B):
+        g.manual_seed(util.SEED + 4000 + (i if i != 37 else 5))          # slot 37 repeats frame 5's mosaic
+        srcs.append(torch.randint(0, 16384, (H * W,), generator=g, device="cuda", dtype=torch.int32).to(torch.float32))
+        outs.append(plan.new_output())
+    for s, o in zip(srcs, outs):                                          # the batch: 64 launches back to back on one stream
+        plan.run(s, o)
+    torch.cuda.synchronize()
+    # (1) a handful of frames against the oracle, every sample
+    for i in (0, 5, 21, 42, 63):
+        raw = srcs[i].cpu().numpy().reshape(H, W)
+        want = torch.from_numpy(orc.pipeline_run(_oracle_desc(orc, raw, "RGGB")).reshape(-1))
+        if not torch.equal(outs[i].cpu().view(torch.int32), want.view(torch.int32)):
+            assert_bits_equal(outs[i].cpu().numpy().reshape(H, W, 3), want.numpy().reshape(H, W, 3), "batch frame %d" % i)
+    # (2) independence: recompute alone into a fresh buffer; identical inputs -> identical outputs
+    assert torch.equal(outs[37].view(torch.int32), outs[5].view(torch.int32))
+    alone = plan.new_output()
+    sums = []
+    for i in range(B):
+        plan.run(srcs[i], alone); torch.cuda.synchronize()
+        assert torch.equal(alone.view(torch.int32), outs[i].view(torch.int32)), i
+        sums.append(int(outs[i].view(torch.int32).to(torch.int64).sum().item()))
+    assert len(set(sums)) == B - 1                                        # 63 distinct frames + the deliberate repeat
+    # (3) every frame against the staged path (gofloat, demosaic, tolab, basecurve, fromlab, gamma as separate kernels)
+    for i in range(0, B, 7):
+        pipe = ipa.Pipeline.new_from_source(ipa.RawImage(width=W, height=H, data=srcs[i], cfa="RGGB", is_float=True, blacklevels=[util.BLACK] * 4,
+                                                         whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix()))
+        pipe.allow_fused = False
+        st = pipe.run()
+        assert not pipe.last_used_fused
+        assert torch.equal(st.data.view(torch.int32), outs[i].view(torch.int32)), i
+        del st, pipe
 
 
 def test_config5_full_size_vs_oracle(ipa, orc):

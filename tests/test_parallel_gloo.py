@@ -39,7 +39,7 @@ def _worker(rank, world, port, case, q):
           b = bands[rank]
           assert sum(x.out_rows for x in bands) == h and all(x.out_row0 % period == 0 for x in bands)
 
-          def compute(slab, band):
+          def compute(slab, band, out):
               # the oracle on the slab; slab row 0 is image row band.src_row0 (one row before a multiple of the CFA period
               # when there is a top halo), so the window is padded to the frame's CFA phase
               s = slab.numpy().view(np.uint16)
@@ -48,21 +48,24 @@ def _worker(rank, world, port, case, q):
               win = np.concatenate([np.zeros((pad_top, s.shape[1]), np.uint16), s]) if pad_top else s
               res = orc.pipeline_run(orc.make_pipeline(win, **kw))
               off = pad_top + (band.out_row0 - band.src_row0)
-              out = res[off: off + band.out_rows].copy()
               # rows adjacent to a dummy row / the slab edge are only valid when they are true frame edges or had a halo
-              return torch.from_numpy(out)
+              out.copy_(torch.from_numpy(res[off: off + band.out_rows].copy()))
 
+          # the C entry points through the host transport (ipk_comm_init_host; gloo moves the bytes): ipk_band_plan,
+          # ipk_host_band_exchange_halo on the host slab, ipk_host_band_gather in place on the host frame
+          comm = par.Comm("host")
           own = torch.from_numpy(raw[b.out_row0: b.out_row0 + b.out_rows].view(np.int16).copy())
-          out, full = par.process_frame_banded(own, h, w, compute, period=period, gather="all")
+          out, full = par.process_frame_banded(comm, own, h, w, compute, period=period, gather="all")
           ok_band = np.array_equal(out.numpy().view(np.uint32), whole[b.out_row0: b.out_row0 + b.out_rows].view(np.uint32))
           ok_full = np.array_equal(full.numpy().view(np.uint32), whole.view(np.uint32))
-          out2, root = par.process_frame_banded(own, h, w, compute, period=period, gather="root")
+          out2, root = par.process_frame_banded(comm, own, h, w, compute, period=period, gather="root")
           ok_root = (root is None) if rank else np.array_equal(root.numpy().view(np.uint32), whole.view(np.uint32))
-          # in-place slab variant (what bench.py --band uses)
+          # the slab after the exchange is exactly the frame's rows [src_row0, src_row0 + src_rows)
           slab, own_view = par.alloc_slab(b, w, torch.int16, "cpu")
           own_view.copy_(own)
-          par.exchange_halo_inplace(slab, b, bands)
+          comm.exchange_halo(slab, bands)
           ok_band = ok_band and np.array_equal(slab.numpy().view(np.uint16), raw[b.src_row0: b.src_row0 + b.src_rows])
+          comm.close()
           frames = par.shard_frames(7, rank, world)
           q.put((rank, ok_band, ok_full, ok_root, frames, (b.src_row0, b.src_rows, b.out_row0, b.out_rows)))
       except Exception as e:                                   # never leave the parent waiting on the queue
@@ -99,7 +102,29 @@ def test_band_plan_properties():
                 r = 0
                 for b in bands:
                     assert b.out_row0 == r and b.out_row0 % period == 0
-                    assert b.src_row0 == max(0, r - 1) and b.src_row0 + b.src_rows == min(h, r + b.out_rows + 1)
+                    if b.out_rows:
+                        assert b.src_row0 == max(0, r - 1) and b.src_row0 + b.src_rows == min(h, r + b.out_rows + 1)
+                    else:
+                        assert b.src_rows == 0                  # more ranks than CFA periods: an empty band holds nothing
                     r += b.out_rows
                 sizes = [b.out_rows for b in bands[:-1]]
                 assert not sizes or max(sizes) - min(sizes) <= period
+
+
+def test_band_plan_scaled_covers_every_window(orc):
+    """ipk_band_plan_scaled: output rows partitioned exactly, and each band's source range contains the window rows
+    [floor(skip*r), floor(skip*(r+1))] (scaling.rs:86-87, f32 arithmetic restated here) of every output row it owns"""
+    from imagepipe_amd.parallel import band_plan_scaled
+    for h, nh in ((5760, 1440), (4000, 1000), (4000, 999), (101, 50), (37, 2)):
+        skip = np.float32(np.float32(h - 1) / np.float32(nh - 1))
+        for world in (1, 2, 3, 8, 64):
+            bands = band_plan_scaled(h, nh, world)
+            assert sum(b.out_rows for b in bands) == nh
+            r = 0
+            for b in bands:
+                assert b.out_row0 == r
+                for row in range(b.out_row0, b.out_row0 + b.out_rows):
+                    lo = min(h - 1, int(np.floor(np.float32(skip * np.float32(row)))))
+                    hi = min(h - 1, int(np.floor(np.float32(skip * np.float32(row + 1)))))
+                    assert b.src_row0 <= lo and hi < b.src_row0 + b.src_rows, (h, nh, world, row)
+                r += b.out_rows

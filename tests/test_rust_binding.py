@@ -18,7 +18,7 @@ HDR = os.path.join(ROOT, "include", "imagepipe_amd.h")
 RUST_SIZES = {"c_int": 4, "c_uint": 4, "i32": 4, "u32": 4, "f32": 4, "usize": 8, "u64": 8, "i64": 8, "f64": 8, "u8": 1, "c_char": 1, "u16": 2}
 C_TO_RUST = {"int": "c_int", "size_t": "usize", "float": "f32", "char": "c_char", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32",
              "uint64_t": "u64", "int64_t": "i64", "void": "c_void", "ipk_cache": "IpkCache", "ipk_pipeline_desc": "IpkPipelineDesc",
-             "ipk_fused_params": "IpkFusedParams", "ipk_comm": "IpkComm", "ipk_band_plan": "IpkBandPlan"}
+             "ipk_fused_params": "IpkFusedParams", "ipk_comm": "IpkComm", "ipk_band": "IpkBand", "ipk_exchange_fn": "IpkExchangeFn"}
 
 
 def _rust_structs(text):
@@ -130,6 +130,14 @@ def test_rust_extern_block_declares_every_symbol_with_matching_types():
     for _, items in enums:
         for k, v in items:
             assert re.search(r"pub const %s: c_int = %d;" % (k, v), text), "enum constant %s" % k
+    # the callback type of the host transport: argument types in order
+    hdr = re.sub(r"/\*.*?\*/", " ", open(HDR).read(), flags=re.S)
+    m = re.search(r"typedef\s+int\s*\(\s*\*\s*ipk_exchange_fn\s*\)\s*\(([^)]*)\)", hdr)
+    cargs = [" ".join(a.replace("*", " * ").split()).rsplit(" ", 1)[0] for a in m.group(1).split(",")]
+    rm = re.search(r"pub type IpkExchangeFn = Option<unsafe extern \"C\" fn\((.*?)\) -> c_int>;", text)
+    rargs = [a.split(": ", 1)[1] for a in rm.group(1).split(", ")]
+    assert [_map_ctype(a) for a in cargs] == rargs
+    assert "pub const IPK_COMM_ID_BYTES: usize = 128;" in text
 
 
 def test_committed_binding_is_current_and_integration_md_quotes_it():

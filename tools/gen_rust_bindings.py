@@ -56,6 +56,15 @@ def parse_header(text=None):
                 fields.append((ctype, am.group(1), int(am.group(2))) if am else (ctype, f, None))
         structs.append((m.group(2), fields))
     opaque = re.findall(r"typedef\s+struct\s+(\w+)\s+\1\s*;", text)
+    defines = [(m.group(1), int(m.group(2))) for m in re.finditer(r"#define\s+(IPK_\w+)\s+(\d+)\s*$", text, flags=re.M)]
+    fnptrs = []
+    for m in re.finditer(r"typedef\s+(\w+)\s*\(\s*\*\s*(\w+)\s*\)\s*\(([^)]*)\)\s*;", text):
+        args = []
+        for a in " ".join(m.group(3).split()).split(","):
+            a = " ".join(a.replace("*", " * ").split())
+            am = re.match(r"(.*?)(\w+)$", a)
+            args.append((am.group(1).strip(), am.group(2)))
+        fnptrs.append((m.group(2), m.group(1), args))
     funcs = []
     for m in re.finditer(r"IPK_API\s+([\w\s\*]+?)\b(ipk_\w+)\s*\(([^)]*)\)\s*;", text):
         ret = " ".join(m.group(1).replace("*", " * ").split())
@@ -67,6 +76,7 @@ def parse_header(text=None):
                 am = re.match(r"(.*?)(\w+)$", a)
                 args.append((am.group(1).strip(), am.group(2)))
         funcs.append((m.group(2), ret, args))
+    parse_header.defines, parse_header.fnptrs = defines, fnptrs
     return enums, structs, opaque, funcs
 
 
@@ -79,7 +89,7 @@ def rust_type(ctype, struct_names, opaque):
     base = [t for t in toks if t != "const"]
     assert len(base) == 1, ctype
     b = base[0]
-    r = SCALARS.get(b) or (camel(b) if (b in struct_names or b in opaque) else None)
+    r = SCALARS.get(b) or (camel(b) if (b in struct_names or b in opaque or b in [f[0] for f in getattr(parse_header, "fnptrs", [])]) else None)
     assert r, "unmapped C type: " + ctype
     if stars == 0:
         return r
@@ -109,8 +119,15 @@ def generate():
         for k, v in items:
             o.append("pub const %s: c_int = %d;" % (k, v))
         o.append("")
+    for k, v in parse_header.defines:
+        o.append("pub const %s: usize = %d;" % (k, v))
+    o.append("")
     for name in opaque:
         o.append("#[repr(C)] pub struct %s { _private: [u8; 0] }   // opaque: %s" % (camel(name), name))
+    o.append("")
+    for name, ret, args in parse_header.fnptrs:
+        al = ", ".join("%s: %s" % (a, rust_type(ty, sn, opaque)) for ty, a in args)
+        o.append("pub type %s = Option<unsafe extern \"C\" fn(%s) -> %s>;   // %s" % (camel(name), al, rust_type(ret, sn, opaque), name))
     o.append("")
     for name, fields in structs:
         o.append("#[repr(C)]")

@@ -127,6 +127,34 @@ DEF_KERNEL(dep_mul,    DEP16("v_mul_f32 %0, %0, %1"), 16)
 DEF_KERNEL(dep_fma,    DEP16("v_fma_f32 %0, %0, %1, %1"), 16)
 DEF_KERNEL(dep_min,    DEP16("v_min_f32 %0, %0, %1"), 16)
 
+// ---- round 2 additions: candidates for replacing slow-class instructions, and the f64 conversions of the cbrtf branch ----
+DEF_KERNEL(alignbit,   ALL16("v_alignbit_b32 %0, %0, %1, 30"), 16)
+DEF_KERNEL(perm,       ALL16("v_perm_b32 %0, %0, %1, %1"), 16)
+DEF_KERNEL(bfi,        ALL16("v_bfi_b32 %0, %0, %1, %1"), 16)
+DEF_KERNEL(add_lshl,   ALL16("v_add_lshl_u32 %0, %0, %1, 2"), 16)
+DEF_KERNEL(max3_u32,   ALL16("v_max3_u32 %0, %0, %1, %1"), 16)
+DEF_KERNEL(max_u32,    ALL16("v_max_u32 %0, %0, %1"), 16)
+DEF_KERNEL(cmp_u32,    ALL16("v_cmp_lt_u32 vcc, %0, %1"), 16)
+DEF_KERNEL(ashr,       ALL16("v_ashrrev_i32 %0, 3, %0"), 16)
+DEF_KERNEL(mul_lo,     ALL16("v_mul_lo_u32 %0, %0, %1"), 16)
+DEF_KERNEL(rcp_f32,    ALL16("v_rcp_f32 %0, %0"), 16)
+DEF_KERNEL(trunc,      ALL16("v_trunc_f32 %0, %0"), 16)
+DEF_KERNEL(rndne,      ALL16("v_rndne_f32 %0, %0"), 16)
+DEF_KERNEL(ldexp,      ALL16("v_ldexp_f32 %0, %0, 2"), 16)
+DEF_KERNEL(cvt_pk_u8,  ALL16("v_cvt_pk_u8_f32 %0, %1, 0, %0"), 16)
+// the same multiply / fma on DENORMAL operands (integers held as f32 bit patterns): is `as_float(key) * 4.0f` a full-rate shift?
+#define DEN16 a0 = __int_as_float(1 + (int)c); a1 = __int_as_float(2 + (int)c); a2 = __int_as_float(3); a3 = __int_as_float(4); a4 = __int_as_float(5); a5 = __int_as_float(6); a6 = __int_as_float(7); a7 = __int_as_float(8); \
+              b0 = __int_as_float(9); b1 = __int_as_float(10); b2 = __int_as_float(11); b3 = __int_as_float(12); b4 = __int_as_float(13); b5 = __int_as_float(14); b6 = __int_as_float(15); b7 = __int_as_float(16);
+DEF_KERNEL(mul_denorm,   if (i == 0) { DEN16 } ALL16("v_mul_f32 %0, 1.0, %0"), 16)
+DEF_KERNEL(fmaak_denorm, if (i == 0) { DEN16 } ALL16("v_fmaak_f32 %0, %0, %1, 0x00000040"), 16)
+DEF_KERNEL(add_denorm,   if (i == 0) { DEN16 } ALL16("v_add_f32 %0, %0, %0"), 16)
+// f32 <-> f64 conversions (alternating, 16 instructions), f64 rcp, f64 fma with distinct registers
+#define DD8 double d0; double d1; double d2; double d3; double d4; double d5; double d6; double d7;
+#define CVTP(X, D) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(D) : "v"(X)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(X) : "v"(D));
+DEF_KERNEL(cvt_f64_pair, DD8 CVTP(a0, d0) CVTP(a1, d1) CVTP(a2, d2) CVTP(a3, d3) CVTP(a4, d4) CVTP(a5, d5) CVTP(a6, d6) CVTP(a7, d7), 16)
+#define CVTU(X, D) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(D) : "v"(X)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(X) : "v"(*(float *)&D));
+DEF_KERNEL(cvt_f64_up,   DD8 CVTU(a0, d0) CVTU(a1, d1) CVTU(a2, d2) CVTU(a3, d3) CVTU(a4, d4) CVTU(a5, d5) CVTU(a6, d6) CVTU(a7, d7), 16)
+
 struct Entry { const char *name; void (*fn)(float *, float); int nins; };
 #define E(NAME) {#NAME, k_##NAME, n_##NAME}
 
@@ -134,7 +162,9 @@ int main(int argc, char **argv) {
   std::vector<Entry> es = {E(mul), E(mul_e64), E(mul_nd), E(mul_const), E(mul_inl), E(add), E(fma), E(fma_3reg), E(fmac), E(fmaak), E(fmamk), E(min), E(max),
                            E(cnd_e32), E(cnd_e64), E(or_b32), E(xor_b32), E(sub_u32), E(lshr), E(lshl), E(lshl_add), E(add3), E(and_or), E(bfe), E(mul_u24), E(mad_u24),
                            E(cvt_u32), E(cvt_i32), E(cvt_f32u), E(fract), E(floor), E(med3), E(cmp), E(cmp_e64), E(mul_legacy), E(subrev), E(mul_neg), E(add_abs), E(mul_clamp), E(pk_mul),
-                           E(mix_mul_fma), E(mix_mul_min), E(mix_mul_add), E(mix_fma_min), E(dep_mul), E(dep_fma), E(dep_min), E(mix_min_max), E(mix_min_cvt), E(mix_min_cmp), E(mix_cvt_fra), E(mix_min_lshl), E(mix_cnd_min), E(mix_cmp_cnd), E(mix_cvt_cvtf), E(mix_med_fra), E(seq_mmmn), E(seq_mmnn), E(seq_mncf), E(seq_nnmm_blk), E(seq_fmul), E(seq_real), E(dep_real), E(dep2_real), E(mul_vv), E(add_vv), E(min_vv), E(fma_vvv), E(mul_sgpr), E(fma_sgpr), E(fma_sgpr2)};
+                           E(mix_mul_fma), E(mix_mul_min), E(mix_mul_add), E(mix_fma_min), E(dep_mul), E(dep_fma), E(dep_min), E(mix_min_max), E(mix_min_cvt), E(mix_min_cmp), E(mix_cvt_fra), E(mix_min_lshl), E(mix_cnd_min), E(mix_cmp_cnd), E(mix_cvt_cvtf), E(mix_med_fra), E(seq_mmmn), E(seq_mmnn), E(seq_mncf), E(seq_nnmm_blk), E(seq_fmul), E(seq_real), E(dep_real), E(dep2_real), E(mul_vv), E(add_vv), E(min_vv), E(fma_vvv), E(mul_sgpr), E(fma_sgpr), E(fma_sgpr2),
+                           E(alignbit), E(perm), E(bfi), E(add_lshl), E(max3_u32), E(max_u32), E(cmp_u32), E(ashr), E(mul_lo), E(rcp_f32), E(trunc), E(rndne), E(ldexp), E(cvt_pk_u8),
+                           E(mul_denorm), E(fmaak_denorm), E(add_denorm), E(cvt_f64_pair), E(cvt_f64_up)};
   float *out; hipMalloc(&out, 8192 * 256 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int wpsimd : {4}) {
