@@ -215,6 +215,11 @@ __device__ __forceinline__ float input16bit(uint16_t v) { return (float)v / 6553
 
 // ---- SplineFunc::interpolate (src/ops/curves.rs:126-157) -----------------------------------
 constexpr int kSplineMaxKnots = 66;
+// LDS image of a curve (fill_knots): [px | py | c1 | c2 | c3] (kSplineMaxKnots floats each), 2 floats of padding, then one 8-float
+// record {x_i, y_i, c1_i, c2_i, c3_i, -, -, -} per segment of the 3-knot form, 16-byte aligned: a per-lane segment choice is ONE address
+// select and two reads (b128 + b32) instead of five address selects (v_cndmask is a half-rate instruction on gfx950)
+constexpr int kKnotSegRec = 5 * kSplineMaxKnots + 2;
+constexpr int kKnotFloats = kKnotSegRec + 16;
 struct SplineDev {
   int npoints, nseg;
   float px[kSplineMaxKnots], py[kSplineMaxKnots], c1[kSplineMaxKnots], c2[kSplineMaxKnots], c3[kSplineMaxKnots];
@@ -280,12 +285,21 @@ __device__ __forceinline__ float spline_interpolate_lds(const float *__restrict_
 // The 3-knot form alone (no dispatch on the knot count): for callers that know the curve has 3 knots, or 2 knots padded by
 // the host to (x0, x1, x1) / (y0, y1, y1) -- then `up` implies val >= x2, so the unused second segment is never evaluated
 // into the result and every decision is the 2-knot one.
+#ifndef IPK_OPT_SPLINE_REC
+#define IPK_OPT_SPLINE_REC 1
+#endif
 __device__ __forceinline__ float spline_interpolate_3(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
   const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
   const bool up = x1 < val, down = x1 > val;
+#if IPK_OPT_SPLINE_REC
+  const float *rec = lds_knots + kKnotSegRec + (up ? 8 : 0);
+  const float4 q = *reinterpret_cast<const float4 *>(rec);
+  const float bx = q.x, by = q.y, k1 = q.z, k2 = q.w, k3 = rec[4];
+#else
   const int i = up ? 1 : 0;
   const float bx = lds_knots[i], by = lds_knots[kSplineMaxKnots + i];
   const float k1 = lds_knots[2 * kSplineMaxKnots + i], k2 = lds_knots[3 * kSplineMaxKnots + i], k3 = lds_knots[4 * kSplineMaxKnots + i];
+#endif
   float r = spline_poly(by, k1, k2, k3, val - bx);
   r = (!up && !down) ? s.py[1] : r;                    // exact knot hit
   r = !(val > x0) ? s.py[0] : r;                       // val <= first, or NaN
@@ -315,6 +329,18 @@ __device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, cons
     return r;
   }
   return spline_interpolate_lds(lds_knots, np, s.nseg, val);
+}
+
+// the LDS image of a curve: called by the first kKnotFloats threads of a block (before its barrier)
+__device__ __forceinline__ void fill_knots(float *__restrict__ lds, const SplineDev &s, int i) {
+  if (i < kSplineMaxKnots) {
+    lds[i] = s.px[i]; lds[kSplineMaxKnots + i] = s.py[i]; lds[2 * kSplineMaxKnots + i] = s.c1[i];
+    lds[3 * kSplineMaxKnots + i] = s.c2[i]; lds[4 * kSplineMaxKnots + i] = s.c3[i];
+  }
+  if (i < 2) {
+    float *r = lds + kKnotSegRec + 8 * i;
+    r[0] = s.px[i]; r[1] = s.py[i]; r[2] = s.c1[i]; r[3] = s.c2[i]; r[4] = s.c3[i]; r[5] = 0.0f; r[6] = 0.0f; r[7] = 0.0f;
+  }
 }
 
 // ---- division by a positive constant, 4 instructions instead of the ~11 of an IEEE divide ---------

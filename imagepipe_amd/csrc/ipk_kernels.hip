@@ -18,6 +18,14 @@ using namespace ipkd;
 #ifndef IPK_ABLATE
 #define IPK_ABLATE 0
 #endif
+// Round-2 instruction-class substitutions (each measured on the same box against its =0 build, profiles/README.md):
+//   (tried, no gain: LDS table addresses by an f32 fma on denormal operands -- exact integer arithmetic at the full issue rate --
+//    instead of the half-rate v_lshl_add_u32: 0.628 vs 0.628 ms on noise, 0.499 vs 0.502 on photo-like data)
+//   IPK_OPT_NOZEROADD  the fused kernel's demosaic sums start from their first tap instead of `0.0 + tap` (see demosaic_inner_px)
+//   IPK_OPT_SPLINE_REC per-segment curve records in LDS: one address select instead of five (ipk_device.hpp)
+#ifndef IPK_OPT_NOZEROADD
+#define IPK_OPT_NOZEROADD 1
+#endif
 
 namespace ipk {
 
@@ -1084,13 +1092,20 @@ __device__ __forceinline__ float4 demosaic_edge_dispatch(const float t[9], uint3
 
 // Interior pixel, all nine taps valid: the four tile roles written out.  Sums start from 0.0 and
 // add taps in the reference's order; /2 and /4 are exact as *0.5 / *0.25; count 1 is sum/1.0.
-template <int ROLE>   // 0: R site, 1: G on the R row, 2: G on the B row, 3: B site
+// Z = true keeps the reference's `sums[c] = 0.0; sums[c] += tap` literally (demosaic.rs:99-108).  Z = false starts each sum from its first
+// tap: `0.0 + t` differs from `t` only for t = -0.0 (gives +0.0), so the two forms can differ only in the SIGN of an exactly-zero channel.
+// The staged OpDemosaic (its output is the RGBE OpBuffer itself) uses Z = true; the fused kernel feeds the channels into
+// camera_to_lab, where a zero's sign cannot reach a result: r*mul keeps a zero a zero, the matrix sums are +-0 or dominated by their
+// nonzero terms, and the Lab lookup maps +0 and -0 to the same value (pointwise4_fast's `oor` test sends -0 down the linear branch,
+// which yields table[0] bit for bit) -- checked by the parity tests with -0.0 samples and a zero black level (tests/test_gpu_fused.py).
+template <int ROLE, bool Z = true>   // 0: R site, 1: G on the R row, 2: G on the B row, 3: B site
 __device__ __forceinline__ float4 demosaic_inner_px(float nw, float n, float ne, float w, float c, float e, float sw, float s, float se) {
-  const float own = 0.0f + c;
-  const float cross = ((((0.0f + n) + w) + e) + s) * 0.25f;
-  const float diag = ((((0.0f + nw) + ne) + sw) + se) * 0.25f;
-  const float horiz = ((0.0f + w) + e) * 0.5f;
-  const float vert = ((0.0f + n) + s) * 0.5f;
+  const float zero = Z ? 0.0f : -0.0f;                       // -0.0 + t == t for every t (including -0.0 and NaN): the compiler folds it away
+  const float own = zero + c;
+  const float cross = ((((zero + n) + w) + e) + s) * 0.25f;
+  const float diag = ((((zero + nw) + ne) + sw) + se) * 0.25f;
+  const float horiz = ((zero + w) + e) * 0.5f;
+  const float vert = ((zero + n) + s) * 0.5f;
   if (ROLE == 0) return make_float4(own, cross, diag, 0.0f);
   if (ROLE == 1) return make_float4(horiz, own, vert, 0.0f);
   if (ROLE == 2) return make_float4(vert, own, horiz, 0.0f);
@@ -1612,12 +1627,13 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
   constexpr bool DEMO = OUT == 3;                        // demosaic only (staged OpDemosaic)
+  constexpr bool ZA = DEMO || !IPK_OPT_NOZEROADD;        // literal `0.0 + tap` sums where the demosaic result itself is the output
   constexpr bool GUARD_NORM = sizeof(SrcT) == 4 && !DEMO;
   // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB), curve knots, and one 3 KB staging
   // buffer per wave that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
   __shared__ float s_lab[DEMO ? 4 : kLutPairs + 4];
   __shared__ float s_gam[DEMO ? 4 : kLutPairs + 4];
-  __shared__ float s_knots[5 * kSplineMaxKnots];         // base-curve knots
+  __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];   // base-curve knots + the 3-knot form's segment records
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
   __shared__ __attribute__((aligned(16))) float s_cells[GEN ? kGenMaxCells * kGenCellFloats : 4];   // generic-CFA cell records
   if (GEN) for (uint32_t i = threadIdx.x; i < a.gen_pw * a.gen_ph * kGenCellFloats; i += blockDim.x) s_cells[i] = a.gen_cells[i];
@@ -1629,11 +1645,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
-  if (threadIdx.x < kSplineMaxKnots) {
-    const int i = threadIdx.x;
-    s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
-    s_knots[3 * kSplineMaxKnots + i] = a.spline.c2[i]; s_knots[4 * kSplineMaxKnots + i] = a.spline.c3[i];
-  }
+  if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -1780,6 +1792,8 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // iteration old.
   N = finish_row(issue_row(min(r0 + 1, Hm1)), fN);
   RawRowT raw_next = issue_row(min(r0 + 2, Hm1));
+  // (the ~20 register moves that rotate the row window per iteration would vanish in a 3x unrolled loop; the compiler refuses
+  // `#pragma unroll 3` here -- wave-level ballots and barriers in the body -- and a hand-unrolled body triples the code for ~1 %)
   for (uint32_t r = r0; r < r1; ++r) {
     const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
     const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
@@ -1806,27 +1820,27 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
       demosaic_rot_row_dyn(a.ori, a.roles[2 * (int)(r & 1u) + (int)xo], pw, cw, nw, px);
     } else if (pr == 0) {
       if (xo == 0) {
-        px[0] = demosaic_inner_px<0>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<1>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<0>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<1>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        px[0] = demosaic_inner_px<0, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<1, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<0, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<1, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
       } else {
-        px[0] = demosaic_inner_px<1>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<0>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<1>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<0>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        px[0] = demosaic_inner_px<1, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<0, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<1, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<0, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
       }
     } else {
       if (xo == 0) {
-        px[0] = demosaic_inner_px<2>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<3>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<2>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<3>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        px[0] = demosaic_inner_px<2, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<3, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<2, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<3, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
       } else {
-        px[0] = demosaic_inner_px<3>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<2>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<3>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<2>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        px[0] = demosaic_inner_px<3, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+        px[1] = demosaic_inner_px<2, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+        px[2] = demosaic_inner_px<3, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+        px[3] = demosaic_inner_px<2, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
       }
     }
     // frame-edge pixels: taps outside the image are skipped, not mirrored (demosaic.rs:103-104)
@@ -2084,17 +2098,13 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) {
   __shared__ float s_lab[kLutPairs + 4];
   __shared__ float s_gam[kLutPairs + 4];
-  __shared__ float s_knots[5 * kSplineMaxKnots];
+  __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
   for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
-  if (threadIdx.x < kSplineMaxKnots) {
-    const int i = threadIdx.x;
-    s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
-    s_knots[3 * kSplineMaxKnots + i] = a.spline.c2[i]; s_knots[4 * kSplineMaxKnots + i] = a.spline.c3[i];
-  }
+  if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -2168,7 +2178,7 @@ template <typename SrcT, int OUT>
 __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npix, const LutPair *__restrict__ gamma_reverse) {
   __shared__ float s_lab[kLutPairs + 4];
   __shared__ float s_gam[kLutPairs + 4];
-  __shared__ float s_knots[5 * kSplineMaxKnots];
+  __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
   __shared__ float s_expand[sizeof(SrcT) == 1 ? 256 : 4];              // expand_srgb_gamma(input8bit(i)), the 256 possible RGB8 samples
   constexpr int STG = OUT == 0 ? 768 : (OUT == 1 ? 192 : 384);
@@ -2178,11 +2188,7 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
-  if (threadIdx.x < kSplineMaxKnots) {
-    const int i = threadIdx.x;
-    s_knots[i] = a.spline.px[i]; s_knots[kSplineMaxKnots + i] = a.spline.py[i]; s_knots[2 * kSplineMaxKnots + i] = a.spline.c1[i];
-    s_knots[3 * kSplineMaxKnots + i] = a.spline.c2[i]; s_knots[4 * kSplineMaxKnots + i] = a.spline.c3[i];
-  }
+  if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

@@ -154,6 +154,31 @@ def test_fused_rejects_four_colour_filters(ipa):
         ipa.raw_to_srgb(src, width=36, height=36, cfa="RGXB")
 
 
+@pytest.mark.parametrize("cfa", ["RGGB", "GBRG"])
+def test_fused_negative_zero_samples_with_zero_black_level(ipa, orc, cfa):
+    """f32 mosaics may hold -0.0; with a zero black level the normalised sample is -0.0 too.  The reference's demosaic sums start at
+    +0.0 (`0.0 + -0.0 = +0.0`); the fused kernel starts its sums from the first tap (ipk_kernels.hip demosaic_inner_px<.., Z = false>),
+    which can only change the SIGN of an exactly-zero channel -- and that sign must not reach any output bit.  Frames made of 0.0 /
+    -0.0 / tiny / ordinary samples in every arrangement the 3x3 window can see, at both row parities; the staged demosaic (whose output IS
+    the RGBE buffer) keeps the literal sums -- tests/test_gpu_stages.py::test_demosaic_full_vs_oracle holds -0.0 samples at widths >= 256."""
+    rng = np.random.default_rng(77)
+    h, w = 64, 520
+    vals = np.array([0.0, -0.0, -0.0, 0.0, 1e-30, -1e-30, 0.25, 1.0, 0.5, -0.0], np.float32)
+    raw = vals[rng.integers(0, vals.size, size=(h, w))]
+    raw[10:20, 100:300] = -0.0                                   # whole neighbourhoods of negative zeros
+    raw[30:40, 100:300] = 0.0
+    raw[44:50, :] = np.where(rng.integers(0, 2, size=(6, w)) == 0, np.float32(-0.0), np.float32(0.0))
+    kw = dict(blacklevels=[0.0] * 4, whitelevels=[1.0] * 4)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa, is_float=True, **kw))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa, **kw)), "fused, -0.0 samples")
+    pipe.allow_fused = False
+    assert_bits_equal(pipe.run().numpy(), got.numpy(), "staged == fused with -0.0 samples")
+    ww, hh, o8 = pipe.output_8bit()
+    assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), orc.pipeline_output_8bit(_oracle_desc(orc, raw, cfa, **kw)))
+
+
 # ---------------------------------------------------------------------------------------------
 # generic-CFA mode of the fused kernel: X-Trans and other three-colour filters
 # ---------------------------------------------------------------------------------------------
@@ -555,7 +580,10 @@ def test_fused_extreme_levels_fall_back_to_true_division(ipa, orc):
     for wb, scale in [((2.0, 0.0, 1.5, 1.0), 1.0), ((1e30, 1.0, 1e-30, 1.0), 1.0), ((2.0, 1.0, 1.5, np.nan), 1e25), ((-2.0, 1.0, -1.5, 1.0), -3.0)]:
         cm = (util.cam_matrix() * np.float32(scale)).astype(np.float32)
         kw = dict(wb_coeffs=wb, cam_to_xyz_normalized=cm)
-        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "RGGB", is_float=True, **kw))
+        # the op's public field, set after OpToLab::new (which would replace abnormal as-shot coefficients by neutralwb(),
+        # colorspaces.rs:33-39); run() normalises whatever it finds there (:100)
+        pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "RGGB", is_float=True, cam_to_xyz_normalized=cm))
+        pipe.ops.tolab.wb_coeffs = list(wb)
         assert_bits_equal(pipe.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "RGGB", **kw)), "params %r" % ((wb, scale),))
 
 

@@ -4,7 +4,7 @@ for rep in 1 2; do
 for d in ${DATA:-noise photo smooth}; do
   for v in main ${VARIANTS}; do
     if [ $v = main ]; then so=""; else so="$PWD/imagepipe_amd/csrc/build/ablate/lib$v.so"; fi
-    IPK_SO_OVERRIDE=$so python bench.py --no-cpu-baseline --no-check --steps 20 --data $d "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$d $v', d['roofline']['kernel_ms'], 'ms')"
+    IPK_SO_OVERRIDE=$so python bench.py --no-cpu-baseline --no-check --no-extras --steps 20 --data $d "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$d $v', d['roofline']['kernel_ms'], 'ms')"
   done
 done
 done

@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../imagepipe_amd/csrc"
 mkdir -p build/ablate
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I../../include"
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize "$@" -c ipk_kernels.hip -o build/ablate/k_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ablate/lib$name.so build/ablate/k_$name.o build/ipk_api.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ablate/lib$name.so build/ablate/k_$name.o build/ipk_api.o build/ipk_comm.o -ldl
 echo build/ablate/lib$name.so
