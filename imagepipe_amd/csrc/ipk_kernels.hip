@@ -244,6 +244,8 @@ struct TransformArgs {
   // optional fused OpGoFloat (CFA branch, gofloat.rs:122-130/158-166): the source is the raw sensor frame
   int norm; float min0, range0; uint64_t src_pitch, src_x, src_y;
   int norm_fast; float inv_range0;    // fused OpGoFloat: the host validated cdiv_fast for range0 (else IEEE division)
+  int norm_light;                     // f32 sources: 2^-70 <= |black| <= 2^70, so a nonzero v - black is at least half an ulp of black (>= 2^-95):
+                                      // no dividend can be tiny, and the per-row guard shrinks to one comparison on the row's minimum
   // output-row band [out_r0, out_r1) of the fused gofloat + scaled_demosaic kernels (multi-GPU sharding of one frame):
   // dst row 0 = output row out_r0; the source slab's first row is folded into src_y (which may wrap: pointer arithmetic mod 2^64)
   uint32_t out_r0, out_r1;
@@ -485,19 +487,29 @@ __global__ void k_raw_scaled_demosaic(const T *__restrict__ src, TransformArgs a
 // change a sum that started at +0.0).  Same taps, same order (y outer, x inner), same arithmetic per tap.
 template <typename T> struct Row8;
 struct __attribute__((packed, aligned(4))) Row8F4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(2))) Row8U4 { uint32_t x, y, z, w; };
+// load(): eight samples as floats.  issue() / expand() / touch(): the same in two steps for software-pipelined loops -- issue() only
+// loads (raw registers), touch() makes the raw registers a use (the s_waitcnt lands there), expand() converts.
 template <> struct Row8<float> {
-  static __device__ __forceinline__ void load(const float *p, float d[8]) {
-    const Row8F4 lo = *reinterpret_cast<const Row8F4 *>(p), hi = *reinterpret_cast<const Row8F4 *>(p + 4);
-    d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+  struct Raw { Row8F4 lo, hi; };
+  static __device__ __forceinline__ Raw issue(const float *p) { return Raw{*reinterpret_cast<const Row8F4 *>(p), *reinterpret_cast<const Row8F4 *>(p + 4)}; }
+  static __device__ __forceinline__ void touch(const Raw &r) {
+    asm volatile("" ::"v"(r.lo.x), "v"(r.lo.y), "v"(r.lo.z), "v"(r.lo.w), "v"(r.hi.x), "v"(r.hi.y), "v"(r.hi.z), "v"(r.hi.w));
   }
+  static __device__ __forceinline__ void expand(const Raw &r, float d[8]) {
+    d[0] = r.lo.x; d[1] = r.lo.y; d[2] = r.lo.z; d[3] = r.lo.w; d[4] = r.hi.x; d[5] = r.hi.y; d[6] = r.hi.z; d[7] = r.hi.w;
+  }
+  static __device__ __forceinline__ void load(const float *p, float d[8]) { expand(issue(p), d); }
 };
-struct __attribute__((packed, aligned(2))) us8u { uint16_t v[8]; };
 template <> struct Row8<uint16_t> {
-  static __device__ __forceinline__ void load(const uint16_t *p, float d[8]) {
-    const us8u t = *reinterpret_cast<const us8u *>(p);
-    #pragma unroll
-    for (int k = 0; k < 8; ++k) d[k] = (float)t.v[k];
+  typedef Row8U4 Raw;
+  static __device__ __forceinline__ Raw issue(const uint16_t *p) { return *reinterpret_cast<const Row8U4 *>(p); }
+  static __device__ __forceinline__ void touch(const Raw &r) { asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w)); }
+  static __device__ __forceinline__ void expand(const Raw &r, float d[8]) {
+    d[0] = (float)(r.x & 0xFFFFu); d[1] = (float)(r.x >> 16); d[2] = (float)(r.y & 0xFFFFu); d[3] = (float)(r.y >> 16);
+    d[4] = (float)(r.z & 0xFFFFu); d[5] = (float)(r.z >> 16); d[6] = (float)(r.w & 0xFFFFu); d[7] = (float)(r.w >> 16);
   }
+  static __device__ __forceinline__ void load(const uint16_t *p, float d[8]) { expand(issue(p), d); }
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
@@ -633,28 +645,56 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
   uint32_t kend = 0;
   #pragma unroll
   for (uint32_t k = 0; k < 8; ++k) if (__builtin_amdgcn_ballot_w64(kshift + nx > k) != 0) kend = k + 1;
-  for (uint32_t row = a.out_r0 + blockIdx.y; row < a.out_r1; row += gridDim.y) {
-    const uint32_t from_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)row)));
-    const uint32_t to_y = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)(row + 1))));
-    const float center_y = a.tly + (a.skip_y_y * (float)row) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
-    for (uint32_t y = from_y; y <= to_y; ++y) {         // wave-uniform bounds
+  // The window rows this block walks -- output row after output row (stride gridDim.y), from_y..to_y inside each (scaling.rs:93) -- form
+  // ONE stream, software-pipelined: the loads of the row after next are issued at the end of an iteration, the next row's are awaited
+  // after the current row's arithmetic and BEFORE the output row's store (gfx9 counts loads and stores in one vmcnt, and a wait with a
+  // younger store in flight becomes vmcnt(0)).  Before, every window row paid its full HBM latency in front of its arithmetic (load,
+  // s_waitcnt vmcnt(0), compute): the kernel ran at 3.1 TB/s; a frame is only ~18 window rows per wave, so occupancy could not hide it.
+  struct Cur { uint32_t row, y, ty; bool valid; };
+  auto ywin = [&](uint32_t r, uint32_t &fy, uint32_t &ty) {
+    fy = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)r)));
+    ty = min(a.height - 1, f32_as_u32_sat(floorf(a.tly + a.skip_y_y * (float)(r + 1))));
+  };
+  auto next_of = [&](const Cur &c) -> Cur {
+    if (c.y < c.ty) return Cur{c.row, c.y + 1, c.ty, true};
+    const uint32_t nr = c.row + gridDim.y;
+    if (nr >= a.out_r1) return Cur{c.row, c.y, c.ty, false};            // past the end: re-reads a valid row, never consumed
+    uint32_t f, tt; ywin(nr, f, tt);
+    return Cur{nr, f, tt, true};
+  };
+  auto rowptr = [&](uint32_t y) { return src + (size_t)((uint64_t)y + a.src_y) * a.src_pitch + a.src_x + lx; };
+  auto centre = [&](uint32_t r) { return a.tly + (a.skip_y_y * (float)r) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f); };
+  Cur c0; c0.row = a.out_r0 + blockIdx.y; c0.valid = true;
+  if (c0.row >= a.out_r1) return;
+  ywin(c0.row, c0.y, c0.ty);
+  typename Row8<T>::Raw cur = Row8<T>::issue(rowptr(c0.y));
+  Cur c1 = next_of(c0);
+  typename Row8<T>::Raw nxt = Row8<T>::issue(rowptr(c1.y));
+  float center_y = centre(c0.row);
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+  for (;;) {
+    const uint32_t y = c0.y;
+    {
       const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
       const float dy2 = delta_y * delta_y;
       float d[8];
-      Row8<T>::load(src + (size_t)((uint64_t)y + a.src_y) * a.src_pitch + a.src_x + lx, d);
+      Row8<T>::expand(cur, d);
       const uint32_t cell = (y % ph) * pw + xm;
       #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = d[k] - a.min0;
       bool fastdiv = a.norm_fast != 0;
       if (sizeof(T) == 4 && fastdiv) {
-        bool g = false;
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) g |= cdiv_guard(d[k]);
-        // the weights form multiplies every sample by 0 or 1: -inf (which the guard lets through to the division's fixup, and
-        // .min(1.0) keeps) would turn the other colours' sums into NaN.  NaN and +inf become 1.0 under .min(1.0) and are harmless.
+        // Dividends outside the division's proven zone.  Huge positive ones, +inf and NaN clip to 1.0 whatever the division does; the
+        // weights form multiplies every sample by 0 or 1, so -inf (kept by .min(1.0)) would turn the other colours' sums into NaN: one
+        // comparison on the row's minimum covers the negative side.  Tiny nonzero dividends need the per-sample exponent test -- unless
+        // the black level rules them out (norm_light: a nonzero v - black is then at least half an ulp of black; 45 -> 10 instructions
+        // per window row, a quarter of this kernel's arithmetic).
         const float dmin = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-        g |= !(dmin >= -0x1p100f);
+        bool g = !(dmin >= -0x1p100f);
+        if (!a.norm_light) {
+          #pragma unroll
+          for (int k = 0; k < 8; ++k) g |= cdiv_guard(d[k]);
+        }
         fastdiv = __builtin_amdgcn_ballot_w64(g) == 0;
       }
       if (fastdiv) {
@@ -696,9 +736,23 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
         }
       }
     }
-    float4 o;
-    o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
-    if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)(row - a.out_r0) * a.nwidth + col] = o;
+    const bool row_end = c0.y == c0.ty;                     // wave-uniform
+    Row8<T>::touch(nxt);                                    // the wait for the next row's samples: nothing younger is in flight
+    __builtin_amdgcn_sched_barrier(0);
+    if (row_end) {
+      float4 o;
+      o.x = (n0 > 0.0f) ? s0 / n0 : 0.0f; o.y = (n1 > 0.0f) ? s1 / n1 : 0.0f; o.z = (n2 > 0.0f) ? s2 / n2 : 0.0f; o.w = (n3 > 0.0f) ? s3 / n3 : 0.0f;
+      // lanes past the row shadow its last pixel (same value to the same address): the store needs no predicate
+      (void)lane_in;
+      reinterpret_cast<float4 *>(dst)[(size_t)(c0.row - a.out_r0) * a.nwidth + col] = o;
+      s0 = s1 = s2 = s3 = n0 = n1 = n2 = n3 = 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!c1.valid) break;
+    const Cur c2 = next_of(c1);
+    const typename Row8<T>::Raw n2r = Row8<T>::issue(rowptr(c2.y));
+    if (row_end) center_y = centre(c1.row);
+    c0 = c1; c1 = c2; cur = nxt; nxt = n2r;
   }
 }
 template <typename T>
@@ -716,6 +770,7 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
   a.has_cfa = 1; a.norm = 1; a.min0 = black0; a.range0 = white0 - black0; a.src_pitch = owidth; a.src_x = x; a.src_y = y;
   a.norm_fast = norm_fast; a.inv_range0 = 1.0f / a.range0;
+  a.norm_light = (std::fabs(black0) >= 0x1p-70f && std::fabs(black0) <= 0x1p70f) ? 1 : 0;
   // whole frame, or the output-row band [band_out_row0, +band_out_rows) of a frame sharded across GPUs: `src` then points at sensor
   // row y + band_src_row0 (the slab's first row), which is folded into src_y; window bounds still clamp against the full height
   a.out_r0 = 0; a.out_r1 = (uint32_t)nheight;
@@ -726,7 +781,12 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   if (a.skip_x_x >= 1.0f && a.skip_x_x <= 7.0f && a.skip_y_y >= 1.0f && a.skip_y_y <= 7.0f && width >= 8 &&
       (reinterpret_cast<uintptr_t>(dst4) & 15) == 0) {
     const unsigned gx = (unsigned)((nwidth + 255) / 256);
-    const unsigned want = std::max(1u, 4096u / gx);                          // ~16 blocks of 256 threads per CU in total
+#ifdef IPK_DEV_KNOBS
+    const unsigned total_blocks = getenv("IPK_DEV_W8_BLOCKS") ? (unsigned)atoi(getenv("IPK_DEV_W8_BLOCKS")) : 4096u;
+#else
+    const unsigned total_blocks = 4096u;
+#endif
+    const unsigned want = std::max(1u, total_blocks / gx);                   // ~16 blocks of 256 threads per CU in total
     const dim3 grid(gx, (unsigned)std::min<size_t>(out_rows, want), 1);      // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
 #ifndef IPK_W8_SELECT
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
