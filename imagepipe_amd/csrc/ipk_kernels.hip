@@ -607,10 +607,18 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
 // proven zone of the fast normalisation (f32 sources: NaN, inf, absurd magnitudes; the same wave-uniform test as above) takes
 // the select form, which never multiplies such a sample.  ~150 instead of ~265 instructions per window row.
 constexpr uint32_t kW8MaxCells = 144;
+// A cell's record is 8 float4 (128 bytes = one full cycle of the 32 LDS banks): with that stride the few DIFFERENT cells the lanes of a wave
+// read in one ds_read_b128 (x phases 0 / 2 / 4 of a 6-wide pattern at scale 4) all fall on the same banks -- measured 15 conflict cycles
+// per LDS instruction, the LDS busy for 61 of the kernel's 72 us (profiles/r02_c5_counters.json).  One float4 of padding per cell moves
+// neighbouring cells 16 bytes apart modulo 128: SQ_LDS_BANK_CONFLICT 21.6 M -> 0 cycles per launch, 0.072 -> 0.063 ms.
+constexpr uint32_t kW8CellF4 = 9;
+#ifndef IPK_W8M_WAVES
+#define IPK_W8M_WAVES 1
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
+__global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
                                                                 uint32_t pw, uint32_t ph, float *__restrict__ dst) {
-  extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw][8 columns][4 colours] one-hot weights
+  extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
   __shared__ uint16_t s_bits[kW8MaxCells];                            // the same colours, 2 bits per column (select form)
   for (uint32_t i = threadIdx.x; i < pw * ph; i += blockDim.x) {
     const uint32_t y = i / pw, x = i % pw;
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
       const uint32_t c = cfa48[y * 48 + (x + k) % 48] & 3u;
       bits |= c << (2 * k);
       #pragma unroll
-      for (uint32_t cc = 0; cc < 4; ++cc) s_m[(i * 8 + k) * 4 + cc] = (c == cc) ? 1.0f : 0.0f;
+      for (uint32_t cc = 0; cc < 4; ++cc) s_m[(i * kW8CellF4 + k) * 4 + cc] = (c == cc) ? 1.0f : 0.0f;
     }
     s_bits[i] = (uint16_t)bits;
   }
@@ -698,10 +706,11 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8m(const T *__rest
         fastdiv = __builtin_amdgcn_ballot_w64(g) == 0;
       }
       if (fastdiv) {
-        const float4 *m = reinterpret_cast<const float4 *>(s_m) + cell * 8;
+        const float4 *m = reinterpret_cast<const float4 *>(s_m) + cell * kW8CellF4;
         #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
-          if (k < kend) {                                 // wave-uniform
+          if (k < kend) {                                 // wave-uniform.  (Tried: one instantiation of the row stream per tap count, taps as straight-line
+                                                        // code -- 103 VGPRs, 4 waves per SIMD, 0.074 ms against 0.063: the latency-bound stream wants occupancy)
             // gofloat.rs:126.  cdiv_fast without its div_fixup: that only repairs zero / inf / NaN dividends, and here 0 gives 0
             // either way while +inf and NaN give NaN, which .min(1.0) turns into the same 1.0 as inf.min(1.0)
             const float q0 = d[k] * a.inv_range0;
@@ -784,13 +793,13 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
 #ifdef IPK_DEV_KNOBS
     const unsigned total_blocks = getenv("IPK_DEV_W8_BLOCKS") ? (unsigned)atoi(getenv("IPK_DEV_W8_BLOCKS")) : 4096u;
 #else
-    const unsigned total_blocks = 4096u;
+    const unsigned total_blocks = 5376u;                                     // 21 blocks per CU = 3 full rounds of the 7 resident ones; measured flat 3584 .. 7168
 #endif
     const unsigned want = std::max(1u, total_blocks / gx);                   // ~16 blocks of 256 threads per CU in total
     const dim3 grid(gx, (unsigned)std::min<size_t>(out_rows, want), 1);      // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
 #ifndef IPK_W8_SELECT
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
-      hipLaunchKernelGGL(k_raw_scaled_demosaic_w8m<T>, grid, dim3(256), (size_t)pw * ph * 32 * sizeof(float), s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      hipLaunchKernelGGL(k_raw_scaled_demosaic_w8m<T>, grid, dim3(256), (size_t)pw * ph * kW8CellF4 * 4 * sizeof(float), s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       return;
     }
 #endif
