@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
 constexpr uint32_t kW8MaxCells = 144;
 // A cell's record is 8 float4 (128 bytes = one full cycle of the 32 LDS banks): with that stride the few DIFFERENT cells the lanes of a wave
 // read in one ds_read_b128 (x phases 0 / 2 / 4 of a 6-wide pattern at scale 4) all fall on the same banks -- measured 15 conflict cycles
-// per LDS instruction, the LDS busy for 61 of the kernel's 72 us (profiles/r02_c5_counters.json).  One float4 of padding per cell moves
+// per LDS instruction, the LDS busy for 61 of the kernel's 72 us (profiles/r02_c5_pmc.json).  One float4 of padding per cell moves
 // neighbouring cells 16 bytes apart modulo 128: SQ_LDS_BANK_CONFLICT 21.6 M -> 0 cycles per launch, 0.072 -> 0.063 ms.
 constexpr uint32_t kW8CellF4 = 9;
 #ifndef IPK_W8M_WAVES
