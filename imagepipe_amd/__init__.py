@@ -595,6 +595,15 @@ class Pipeline:
         self.last_used_fused = bool(used.value)
         return out, fw, fh
 
+    def run_timed(self, out_type=OUT_F32):
+        """do_timing! (pipeline.rs:68-80): one run with per-stage hipEvent times; returns (output tensor, [(stage name, ms), ...])"""
+        _lib.check(lib().ipk_timing_begin(), "ipk_timing_begin")
+        data, _w, _h = self._run(out_type)
+        arr = (_lib.StageTime * 16)()
+        n = C.c_int(0)
+        _lib.check(lib().ipk_timing_end(arr, 16, C.byref(n)), "ipk_timing_end")
+        return data, [(arr[i].name.decode(), float(arr[i].ms)) for i in range(min(n.value, 16))]
+
     def run(self, cache: Optional[PipelineCache] = None, out: Optional[torch.Tensor] = None) -> OpBuffer:
         """Pipeline::run(cache) (pipeline.rs:311-375)"""
         data, w, h = self._run(OUT_F32, out, cache)

@@ -52,6 +52,11 @@ class PipelineDesc(C.Structure):
     ]
 
 
+class StageTime(C.Structure):
+    """ipk_stage_time"""
+    _fields_ = [("name", C.c_char * 88), ("ms", C.c_float)]
+
+
 class Band(C.Structure):
     """ipk_band"""
     _fields_ = [("out_row0", _sz), ("out_rows", _sz), ("src_row0", _sz), ("src_rows", _sz)]
@@ -158,6 +163,8 @@ SIGNATURES = {
     "ipk_cache_contains": (C.c_int, [_vp, C.c_char_p]),
     "ipk_cache_stats": (C.c_int, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ipk_cache_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int)]),
+    "ipk_timing_begin": (C.c_int, []),
+    "ipk_timing_end": (C.c_int, [C.POINTER(StageTime), C.c_int, C.POINTER(C.c_int)]),
     "ipk_band_plan": (C.c_int, [_sz, C.c_int, C.c_int, _bp]),
     "ipk_band_plan_scaled": (C.c_int, [_sz, _sz, C.c_int, _bp]),
     "ipk_raw_scaled_demosaic_band": (C.c_int, [_vp, C.c_int, _sz, _sz, _sz, _sz, C.c_float, C.c_float, C.c_char_p, _sz, _sz, _bp, _vp, _vp]),

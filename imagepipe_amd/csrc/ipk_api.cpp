@@ -1001,6 +1001,47 @@ static int run_fastpath(const ipk_pipeline_desc *d, const void *src, void *dst, 
                               sc.width, sc.height, 3, nullptr, static_cast<uint8_t *>(dst), stream);
 }
 
+// ---- do_timing! (src/pipeline.rs:68-80): per-stage times of the pipeline driver, hipEvents on the caller's stream ----------------
+namespace {
+struct TimingSession { bool active = false; std::vector<std::pair<std::string, hipEvent_t>> marks; };
+thread_local TimingSession g_timing;
+struct StageTimer {                    // marks are no-ops unless ipk_timing_begin() armed this thread
+  hipStream_t s; bool on; const char *rest = nullptr;
+  explicit StageTimer(hipStream_t st) : s(st), on(g_timing.active) { if (on) mark("(start)"); }
+  void mark(const char *name) {
+    if (!on) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, s) != hipSuccess) { on = false; return; }
+    g_timing.marks.emplace_back(name, e);
+  }
+  ~StageTimer() { if (rest) mark(rest); }
+};
+}  // namespace
+int ipk_timing_begin(void) {
+  for (auto &m : g_timing.marks) (void)hipEventDestroy(m.second);
+  g_timing.marks.clear();
+  g_timing.active = true;
+  return IPK_OK;
+}
+int ipk_timing_end(ipk_stage_time *out, int max_stages, int *n_stages) {
+  if (!n_stages || (max_stages > 0 && !out)) return fail(IPK_ERR_INVALID, "null argument");
+  g_timing.active = false;
+  int n = 0, rc = IPK_OK;
+  auto &mk = g_timing.marks;
+  if (!mk.empty() && hipEventSynchronize(mk.back().second) != hipSuccess) rc = fail(IPK_ERR_HIP, "hipEventSynchronize failed");
+  for (size_t i = 1; i < mk.size() && rc == IPK_OK; ++i) {
+    if (mk[i].first == "(start)") continue;                       // a second pipeline call inside one session starts a new sequence
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, mk[i - 1].second, mk[i].second) != hipSuccess) { rc = fail(IPK_ERR_HIP, "hipEventElapsedTime failed"); break; }
+    if (n < max_stages) { std::snprintf(out[n].name, sizeof(out[n].name), "%s", mk[i].first.c_str()); out[n].ms = ms; }
+    ++n;
+  }
+  for (auto &m : mk) (void)hipEventDestroy(m.second);
+  mk.clear();
+  *n_stages = n;
+  return rc;
+}
+
 int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused, void *stream) {
   REQUIRE_INIT();
   if (!d || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
@@ -1008,10 +1049,12 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   if (ipk_pipeline_takes_fastpath(d, out_type) == 1) {
     if (used_fused) *used_fused = 0;
     if (d->width < 1 || d->height < 1) return fail(IPK_ERR_INVALID, "empty source");
+    StageTimer tmf(S(stream)); tmf.rest = "fastpath";
     return run_fastpath(d, src, dst, out_type, stream);
   }
   size_t dw, dh, fw, fh;
   int rc = ipk_pipeline_sizes(d, &dw, &dh, &fw, &fh); if (rc) return rc;
+  StageTimer tm(S(stream));
   // output_8bit forces linear=false (pipeline.rs:405), output_16bit linear=true (:452)
   const int linear = out_type == IPK_OUT_U8 ? 0 : (out_type == IPK_OUT_U16 ? 1 : d->linear);
   ipk::Rect r;
@@ -1039,6 +1082,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       std::memcpy(fp.cam_to_xyz_normalized, d->cam_to_xyz_normalized, sizeof(fp.cam_to_xyz_normalized));
       fp.exposure = d->exposure; fp.npoints = d->npoints; std::memcpy(fp.points, d->points, sizeof(fp.points));
       fp.linear = linear; fp.out_type = out_type;
+      tm.rest = "fused gofloat+demosaic+to_lab+basecurve+from_lab+gamma(+transform)";
       if (transform_noop) {
         rc = ipk_raw_to_srgb(&fp, src, dst, stream);
         if (rc == IPK_OK && used_fused) *used_fused = 1;
@@ -1077,6 +1121,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   // scale <= 1: pass-through, demosaic.rs:39-44) and OpRotateCrop are no-ops ----
   if (d->allow_fused && !raw && rcop.noop() && r.x == 0 && r.y == 0 && r.width == d->width && r.height == d->height &&
       r.width * r.height >= 256 && ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale <= 1.0f) {
+    tm.rest = "fused gofloat+to_lab+basecurve+from_lab+gamma(+transform)";
     if (transform_noop) {
       rc = ipk_raster_to_srgb(src, d->src_type, r.width, r.height, d->wb_coeffs, d->cam_to_xyz_normalized, d->exposure, d->points, d->npoints,
                               linear, out_type, dst, stream);
@@ -1156,6 +1201,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       : ipk_gofloat_other_u16(static_cast<const uint16_t *>(src), d->width, r.x, r.y, w, h, static_cast<float *>(buf), stream);
   }
   if (rc < 0) return rc;
+  tm.mark(demosaic_done ? "gofloat+demosaic" : "gofloat");
   // demosaic
   if (!demosaic_done) {
     void *o = nullptr; size_t ow, oh;
@@ -1163,6 +1209,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     rc = ipk_demosaic_run(static_cast<const float *>(buf), w, h, colors, d->cfa, dw, dh, static_cast<float *>(o), &ow, &oh, stream);
     if (rc < 0) return rc;
     if (rc == IPK_NOOP) sc.release(o); else { sc.release(buf); buf = o; w = ow; h = oh; colors = 4; }
+    tm.mark("demosaic");
   }
   // rotatecrop
   {
@@ -1176,6 +1223,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       if (rc < 0) return rc;
       sc.release(buf); buf = o; w = ow; h = oh;
     }
+    tm.mark("rotatecrop");
   }
   const size_t n3 = w * h * 3 * sizeof(float);
   const bool f32_out0 = out_type == IPK_OUT_F32;
@@ -1188,6 +1236,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
                              linear, static_cast<float *>(o), stream);
     if (rc < 0) return rc;
     sc.release(buf); buf = o; colors = 3; chained = true;
+    tm.mark("to_lab+basecurve+from_lab+gamma");
   }
   // tolab
   if (!chained) {
@@ -1196,6 +1245,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     rc = ipk_tolab(static_cast<const float *>(buf), w, h, monochrome, d->wb_coeffs, d->cam_to_xyz_normalized, static_cast<float *>(o), stream);
     if (rc < 0) return rc;
     sc.release(buf); buf = o; colors = 3;
+    tm.mark("to_lab");
   }
   // basecurve
   if (!chained) {
@@ -1204,6 +1254,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     rc = ipk_basecurve(static_cast<const float *>(buf), w, h, d->exposure, d->points, d->npoints, static_cast<float *>(o), stream);
     if (rc < 0) return rc;
     if (rc == IPK_NOOP) sc.release(o); else { sc.release(buf); buf = o; }
+    tm.mark("basecurve");
   }
   // the last f32 stage writes straight into dst when the caller wants f32
   const bool gamma_runs = !linear;
@@ -1216,6 +1267,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     rc = ipk_fromlab(static_cast<const float *>(buf), w, h, static_cast<float *>(o), stream);
     if (rc < 0) return rc;
     sc.release(buf); buf = o;
+    tm.mark("from_lab");
   }
   // gamma
   if (gamma_runs && !chained) {
@@ -1225,10 +1277,12 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     rc = ipk_gamma(static_cast<const float *>(buf), w, h, 3, 0, static_cast<float *>(o), stream);
     if (rc < 0) return rc;
     sc.release(buf); buf = o;
+    tm.mark("gamma");
   }
   // transform -- for the 8- and 16-bit outputs after the quantise loop instead of before it: output8bit / output16bit act
   // per sample, so the permutation commutes with them and then moves 3 or 6 bytes per pixel instead of 12
   if (!transform_noop && !f32_out) {
+    tm.rest = "quantise+transform";
     void *q = nullptr; size_t ow, oh;
     rc = sc.get(w * h * 3 * (out_type == IPK_OUT_U8 ? 1 : 2), &q); if (rc) return rc;
     rc = out_type == IPK_OUT_U8 ? ipk_output8bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint8_t *>(q), stream)
@@ -1246,9 +1300,11 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     rc = ipk_rotate_buffer(static_cast<const float *>(buf), w, h, orientation, static_cast<float *>(o), &ow, &oh, stream);
     if (rc < 0) return rc;
     sc.release(buf); buf = o; w = ow; h = oh;
+    tm.mark("transform");
   }
   if (w != fw || h != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", w, h, fw, fh);
   // quantise (pipeline.rs:408-414 / :455-461)
+  if (out_type != IPK_OUT_F32) tm.rest = "quantise";
   if (out_type == IPK_OUT_U8) rc = ipk_output8bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint8_t *>(dst), stream);
   else if (out_type == IPK_OUT_U16) rc = ipk_output16bit(static_cast<const float *>(buf), w * h * 3, static_cast<uint16_t *>(dst), stream);
   else rc = IPK_OK;

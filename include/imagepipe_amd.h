@@ -338,6 +338,14 @@ IPK_API int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *
  * conversion if the depths differ (image 0.24: c*257, (c+128)/257 -- crate absent, parity unpinned) and
  * scale_down_srgb / scale_down_srgb16 (scaling.rs:162-182) if a size limit applies.  Returns 1 / 0. */
 IPK_API int ipk_pipeline_takes_fastpath(const ipk_pipeline_desc *d, int out_type);
+/* do_timing! (src/pipeline.rs:68-80: the reference logs the wall time of every op of Pipeline::run): ipk_timing_begin arms the calling
+ * thread, the following ipk_pipeline_run call(s) on it bracket every stage they enqueue with hipEvents on their stream, ipk_timing_end
+ * waits for the last one and returns the stages in execution order under the reference's op names ("gofloat", "demosaic", "rotatecrop",
+ * "to_lab", "basecurve", "from_lab", "gamma", "transform"; merged stages are joined with '+', the one-launch paths start with "fused",
+ * the output loops are "quantise").  *n_stages receives the number of stages (may exceed max_stages; the surplus is dropped). */
+typedef struct { char name[88]; float ms; } ipk_stage_time;
+IPK_API int ipk_timing_begin(void);
+IPK_API int ipk_timing_end(ipk_stage_time *out, int max_stages, int *n_stages);
 /* Same with HOST source and destination buffers; synchronous. */
 IPK_API int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int out_type, int *used_fused);
 /* A batch of n same-shaped HOST frames through one descriptor (a caller looping Pipeline::run / output_8bit over a shoot,

@@ -599,6 +599,33 @@ def test_fused_denormal_and_huge_samples_take_the_guarded_path(ipa, orc):
         assert_bits_equal(pipe.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "BGGR", **kw)), "wild samples")
 
 
+def test_per_stage_timing_uses_the_reference_op_names(ipa):
+    """do_timing! (pipeline.rs:68-80): ipk_timing_begin / ipk_timing_end bracket every stage of the driver with hipEvents; stage
+    names are the reference's op names, in its op order"""
+    raw = util.noise_u16(util.SEED + 700, 600, 800)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "RGGB"))
+    out, st = pipe.run_timed()
+    assert pipe.last_used_fused and len(st) == 1 and st[0][0].startswith("fused gofloat+demosaic+to_lab") and st[0][1] > 0
+    pipe.allow_fused = False
+    out2, st = pipe.run_timed()
+    assert [n for n, _ in st] == ["gofloat", "demosaic", "rotatecrop", "to_lab", "basecurve", "from_lab", "gamma"]
+    assert all(ms >= 0 for _, ms in st) and sum(ms for _, ms in st) > 0
+    import torch
+    assert torch.equal(out.view(torch.int32), out2.view(torch.int32))
+    pipe.ops.transform.rotation = 1
+    _, st = pipe.run_timed(ipa.OUT_U8)
+    assert [n for n, _ in st][-1] == "quantise+transform" and "gamma" in [n for n, _ in st]
+    pipe.allow_fused = True; pipe.ops.transform.rotation = 0
+    pipe.globals.settings.maxwidth = 200
+    _, st = pipe.run_timed()
+    assert [n for n, _ in st] == ["gofloat+demosaic", "rotatecrop", "to_lab+basecurve+from_lab+gamma"]
+    # an unarmed run records nothing, and a session ends cleanly with no run at all
+    import ctypes as C
+    pipe.run()
+    n = C.c_int(-1)
+    assert ipa.lib().ipk_timing_begin() == 0 and ipa.lib().ipk_timing_end(None, 0, C.byref(n)) == 0 and n.value == 0
+
+
 def test_errors_are_reported_not_computed(ipa):
     import ctypes as C
     import torch
