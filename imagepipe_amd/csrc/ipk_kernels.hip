@@ -615,7 +615,9 @@ constexpr uint32_t kW8CellF4 = 9;
 #ifndef IPK_W8M_WAVES
 #define IPK_W8M_WAVES 1
 #endif
-template <typename T>
+// KU = the window columns every lane of every wave has (floor(skip) + 1, capped at 5): their taps are straight-line code; further columns (a
+// window whose phase wraps, the shifted loads at the right frame edge) sit behind one wave-uniform branch.
+template <typename T, uint32_t KU>
 __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
                                                                 uint32_t pw, uint32_t ph, float *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
@@ -642,12 +644,11 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
   const uint32_t nx = to_x - from_x + 1;
   const uint32_t lx = min(from_x, a.width - 8);
   const uint32_t kshift = from_x - lx;
-  float ax[8], axm[8];                                   // 1 - dx*dx of sample lx + k; axm: the same, -inf outside the window
+  float axm[8];                                          // 1 - dx*dx of sample lx + k, -inf outside the lane's window
   #pragma unroll
   for (uint32_t k = 0; k < 8; ++k) {
     const float delta_x = tb_div((float)(lx + k) - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
-    ax[k] = 1.0f - (delta_x * delta_x);
-    axm[k] = ((k - kshift) < nx) ? ax[k] : -__builtin_inff();
+    axm[k] = ((k - kshift) < nx) ? 1.0f - (delta_x * delta_x) : -__builtin_inff();
   }
   const uint32_t xm = lx % pw;
   uint32_t kend = 0;
@@ -683,7 +684,11 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
   for (;;) {
     const uint32_t y = c0.y;
     {
-      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
+      // (y - center_y) / skip_y_y (scaling.rs:105).  This kernel only runs for tl = (0, 0) and 1 <= skip <= 7 (launcher): y and the
+      // centre are then zero or at least 2^-25 in magnitude, so a nonzero difference is at least 2^-49 and at most the frame height --
+      // inside the three-step division's proven zone without the exponent test tb_div carries for rotated transforms
+      const float dyn = (float)y - center_y;
+      const float delta_y = a.fast_y ? cdiv_fast(dyn, a.skip_y_y, a.inv_skip_y_y) : dyn / a.skip_y_y;
       const float dy2 = delta_y * delta_y;
       float d[8];
       Row8<T>::expand(cur, d);
@@ -697,8 +702,12 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
         // comparison on the row's minimum covers the negative side.  Tiny nonzero dividends need the per-sample exponent test -- unless
         // the black level rules them out (norm_light: a nonzero v - black is then at least half an ulp of black; 45 -> 10 instructions
         // per window row, a quarter of this kernel's arithmetic).
-        const float dmin = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-        bool g = !(dmin >= -0x1p100f);
+        // d < -2^100 (or -inf) as an unsigned comparison of the bit patterns: negative floats order by magnitude, and the only other
+        // patterns above 0xF1800000 are sign-bit NaNs, which may take the literal path too (4 integer max instead of a float min tree
+        // whose every operand the compiler canonicalises first)
+        const uint32_t umax = max(max(max(__float_as_uint(d[0]), __float_as_uint(d[1])), max(__float_as_uint(d[2]), __float_as_uint(d[3]))),
+                                  max(max(__float_as_uint(d[4]), __float_as_uint(d[5])), max(__float_as_uint(d[6]), __float_as_uint(d[7]))));
+        bool g = umax > 0xF1800000u;
         if (!a.norm_light) {
           #pragma unroll
           for (int k = 0; k < 8; ++k) g |= cdiv_guard(d[k]);
@@ -707,22 +716,25 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
       }
       if (fastdiv) {
         const float4 *m = reinterpret_cast<const float4 *>(s_m) + cell * kW8CellF4;
+        auto tap = [&](uint32_t k) {
+          // gofloat.rs:126.  cdiv_fast without its div_fixup: that only repairs zero / inf / NaN dividends, and here 0 gives 0
+          // either way while +inf and NaN give NaN, which .min(1.0) turns into the same 1.0 as inf.min(1.0)
+          const float q0 = d[k] * a.inv_range0;
+          const float q = __builtin_fmaf(__builtin_fmaf(-q0, a.range0, d[k]), a.inv_range0, q0);
+          const float factor = fmaxf(axm[k] - dy2, 0.0f);                   // scaling.rs:106-107; 0 outside the window
+          const float t = rs_min(q, 1.0f) * factor;
+          const float4 mk = m[k];
+          s0 = __builtin_fmaf(t, mk.x, s0); n0 = __builtin_fmaf(factor, mk.x, n0);
+          s1 = __builtin_fmaf(t, mk.y, s1); n1 = __builtin_fmaf(factor, mk.y, n1);
+          s2 = __builtin_fmaf(t, mk.z, s2); n2 = __builtin_fmaf(factor, mk.z, n2);
+          if (a.components > 3) { s3 = __builtin_fmaf(t, mk.w, s3); n3 = __builtin_fmaf(factor, mk.w, n3); }
+        };
         #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-          if (k < kend) {                                 // wave-uniform.  (Tried: one instantiation of the row stream per tap count, taps as straight-line
-                                                        // code -- 103 VGPRs, 4 waves per SIMD, 0.074 ms against 0.063: the latency-bound stream wants occupancy)
-            // gofloat.rs:126.  cdiv_fast without its div_fixup: that only repairs zero / inf / NaN dividends, and here 0 gives 0
-            // either way while +inf and NaN give NaN, which .min(1.0) turns into the same 1.0 as inf.min(1.0)
-            const float q0 = d[k] * a.inv_range0;
-            const float q = __builtin_fmaf(__builtin_fmaf(-q0, a.range0, d[k]), a.inv_range0, q0);
-            const float factor = fmaxf(axm[k] - dy2, 0.0f);                 // scaling.rs:106-107; 0 outside the window
-            const float t = rs_min(q, 1.0f) * factor;
-            const float4 mk = m[k];
-            s0 = __builtin_fmaf(t, mk.x, s0); n0 = __builtin_fmaf(factor, mk.x, n0);
-            s1 = __builtin_fmaf(t, mk.y, s1); n1 = __builtin_fmaf(factor, mk.y, n1);
-            s2 = __builtin_fmaf(t, mk.z, s2); n2 = __builtin_fmaf(factor, mk.z, n2);
-            if (a.components > 3) { s3 = __builtin_fmaf(t, mk.w, s3); n3 = __builtin_fmaf(factor, mk.w, n3); }
-          }
+        for (uint32_t k = 0; k < KU; ++k) tap(k);          // every lane's window has these columns (or weight 0 for them)
+        if (kend > KU) {                                   // wave-uniform, rare: a wrapped window phase, the frame's right edge
+          #pragma unroll
+          for (uint32_t k = KU; k < 8; ++k)
+            if (k < kend) tap(k);
         }
       } else {
         const uint32_t bits = s_bits[cell];
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
           if (k < kend) {
             const bool in = (k - kshift) < nx;
             const float q = d[k] / a.range0;
-            float factor = ax[k] - dy2;
+            float factor = axm[k] - dy2;                  // -inf outside the window: the selects below zero it either way
             factor = (factor < 0.0f) ? 0.0f : factor;
             factor = in ? factor : 0.0f;
             float t = rs_min(q, 1.0f) * factor;
@@ -799,7 +811,10 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
     const dim3 grid(gx, (unsigned)std::min<size_t>(out_rows, want), 1);      // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
 #ifndef IPK_W8_SELECT
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
-      hipLaunchKernelGGL(k_raw_scaled_demosaic_w8m<T>, grid, dim3(256), (size_t)pw * ph * kW8CellF4 * 4 * sizeof(float), s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      const size_t lds = (size_t)pw * ph * kW8CellF4 * 4 * sizeof(float);
+      if (a.skip_x_x >= 4.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 5>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      else if (a.skip_x_x >= 2.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 3>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      else hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 2>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       return;
     }
 #endif
