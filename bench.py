@@ -317,7 +317,8 @@ def main():
                                   "one frame per GPU per step" if weak else "%d frames per step, frame i on rank i mod N" % B),
                    "baseline_config": "BASELINE.json configs[%d]" % cidx,
                    "frame": [W, H], "src": args.src, "out": args.out, "frames_per_step": B, "prewarm_ms": args.prewarm_ms,
-                   "sharding": "independent frames, no data-path collective", "host_glibc": glibc_version()},
+                   "sharding": "independent frames, no data-path collective", "host_glibc": glibc_version(),
+                   "host_cbrtf_matches_device": ipa.lib().ipk_host_libm_matches(None) == 1},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "k_fused_bayer", "kernel_ms": round(kernel_ms, 4), "kernel_ms_median": round(median_ms / wl.launches_per_step, 4),

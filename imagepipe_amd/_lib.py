@@ -77,6 +77,7 @@ SIGNATURES = {
     "ipk_is_initialized": (C.c_int, []),
     "ipk_last_error": (C.c_char_p, []),
     "ipk_device_cus": (C.c_int, []),
+    "ipk_host_libm_matches": (C.c_int, [_szp]),
     "ipk_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
     "ipk_free": (C.c_int, [_vp]),
     "ipk_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),

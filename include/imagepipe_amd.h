@@ -73,6 +73,11 @@ IPK_API void ipk_shutdown(void);
 IPK_API int ipk_is_initialized(void);
 /* Human-readable description of the last failure on this thread (never NULL). */
 IPK_API const char *ipk_last_error(void);
+/* 1 when this host's libm cbrtf equals the device's cube-root routine (a port of glibc 2.35's, src/color_conversions.rs:103-104,123 call
+ * the platform's) on the 65 536 arguments of (1, 8) ipk_init compares; 0 when it does not -- results are then still deterministic but not
+ * bit-identical to a reference built on THIS host for Lab ratios above 1 (the count goes to *mismatches_of_65536, may be NULL);
+ * -1 if the check could not run. */
+IPK_API int ipk_host_libm_matches(size_t *mismatches_of_65536);
 /* Number of compute units of the selected device (0 before ipk_init). */
 IPK_API int ipk_device_cus(void);
 

@@ -117,3 +117,11 @@ def test_output8bit_packed_form_is_exact_on_every_f32(L):
         n = C.c_uint64(); first = C.c_uint32()
         assert L.ipk_selftest_quant8(variant, C.byref(n), C.byref(first)) == 0
         assert (n.value == 0) == expect_zero, (variant, n.value, hex(first.value))
+
+
+def test_init_time_libm_check_agrees_with_the_exhaustive_one(ipa):
+    """ipk_init compares the host's cbrtf with the device routine on 65 536 arguments and reports it (ipk_host_libm_matches); on this
+    host (glibc 2.35, the routine the device ports) they agree -- the exhaustive tests above say the same for every argument"""
+    import ctypes as C
+    n = C.c_size_t(123)
+    assert ipa.lib().ipk_host_libm_matches(C.byref(n)) == 1 and n.value == 0
