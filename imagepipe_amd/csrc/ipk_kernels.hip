@@ -26,6 +26,10 @@ using namespace ipkd;
 #ifndef IPK_OPT_NOZEROADD
 #define IPK_OPT_NOZEROADD 1
 #endif
+//   IPK_OPT_LINSKIP    lab_to_xyz's linear branches behind wave-uniform tests (see pointwise4_fast)
+#ifndef IPK_OPT_LINSKIP
+#define IPK_OPT_LINSKIP 1
+#endif
 
 namespace ipk {
 
@@ -1478,6 +1482,28 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const f2 gx = cdiv2s(ca, rc_hi(500.0f), rc_lo(500.0f)) + gy;
     const f2 gz = gy - cdiv2s(cb, rc_hi(200.0f), rc_lo(200.0f));
     const f2 gx3 = gx * gx * gx, gy3 = gy * gy * gy, gz3 = gz * gz * gz;
+#if IPK_OPT_LINSKIP
+    // lab_to_xyz's linear branches (color_conversions.rs:183-187: f^3 <= e, L* <= k*e -- only the darkest tones) are evaluated for a
+    // channel only when some lane of the wave takes one in this pixel pair: 6 + 9 + 6 instructions per pixel (a tenth of the kernel's
+    // arithmetic) that bright and mid-tone frames never need.  NaN compares false and lands in the branch, as in the literal form.
+    const bool xb0 = gx3.x > kLabE, xb1 = gx3.y > kLabE, zb0 = gz3.x > kLabE, zb1 = gz3.y > kLabE;
+    const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
+    f2 xq = gx3, yq = gy3, zq = gz3;
+    if (__builtin_amdgcn_ballot_w64(!(xb0 && xb1)) != 0) {
+      const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
+      xq = F2(xb0 ? gx3.x : lx.x, xb1 ? gx3.y : lx.y);
+    }
+    if (__builtin_amdgcn_ballot_w64(!(yb0 && yb1)) != 0) {
+      const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
+      const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
+      if (has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
+      yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
+    }
+    if (__builtin_amdgcn_ballot_w64(!(zb0 && zb1)) != 0) {
+      const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
+      zq = F2(zb0 ? gz3.x : lz.x, zb1 ? gz3.y : lz.y);
+    }
+#else
     const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
     const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
     const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
@@ -1487,6 +1513,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const f2 xq = F2(gx3.x > kLabE ? gx3.x : lx.x, gx3.y > kLabE ? gx3.y : lx.y);
     const f2 yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
     const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
+#endif
     const f2 X = xq * S2(kWhiteX), Y = yq, Z = zq * S2(kWhiteZ);
     rr[g] = X * S2(par[16]) + Y * S2(par[17]) + Z * S2(par[18]);
     gg[g] = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);

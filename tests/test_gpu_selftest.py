@@ -119,9 +119,8 @@ def test_output8bit_packed_form_is_exact_on_every_f32(L):
         assert (n.value == 0) == expect_zero, (variant, n.value, hex(first.value))
 
 
-def test_init_time_libm_check_agrees_with_the_exhaustive_one(ipa):
+def test_init_time_libm_check_agrees_with_the_exhaustive_one(L):
     """ipk_init compares the host's cbrtf with the device routine on 65 536 arguments and reports it (ipk_host_libm_matches); on this
     host (glibc 2.35, the routine the device ports) they agree -- the exhaustive tests above say the same for every argument"""
-    import ctypes as C
     n = C.c_size_t(123)
-    assert ipa.lib().ipk_host_libm_matches(C.byref(n)) == 1 and n.value == 0
+    assert L.ipk_host_libm_matches(C.byref(n)) == 1 and n.value == 0
