@@ -30,6 +30,10 @@ using namespace ipkd;
 #ifndef IPK_OPT_LINSKIP
 #define IPK_OPT_LINSKIP 1
 #endif
+//   IPK_OPT_LOSKIP     the Lab lookup's negative-ratio branch behind its own wave-uniform test (noise 0.600 -> 0.591 ms, photo 0.470 -> 0.473)
+#ifndef IPK_OPT_LOSKIP
+#define IPK_OPT_LOSKIP 1
+#endif
 
 namespace ipk {
 
@@ -1449,14 +1453,20 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // slots or rows pays ~3 % on all other data for its extra scalar bookkeeping: photo-like +3.6 %, gradient +3.3 %.  Not kept.
   // Also measured without effect (+-1 %): one v_max3 tree + a single branch in front of the 12 per-slot checks; one explicit
   // s_waitcnt lgkmcnt(0) per table stage instead of the compiler's one per consumer.)
+  // (Round 2, again without gain: ONE wave-level test -- the OR of the twelve compare masks -- in front of the per-slot tests: noise 0.591 ->
+  // 0.621 ms, photo 0.473 -> 0.480, smooth 0.572 -> 0.595.)
   #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
     if (__builtin_amdgcn_ballot_w64(oor) != 0) {
       const bool hi = v[k] > 1.0f, lo = oor && !hi;
       if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
-      // the linear branch for negative ratios, evaluated for the whole slot (no third branch): / 116 as the proven two-step
-      // form -- its dividend k*v + 16 is 0 or a multiple of 2^-20 (a difference against 16) and at most 2^61 in magnitude
+      // the linear branch for negative ratios: / 116 as the proven two-step form -- its dividend k*v + 16 is 0 or a multiple of 2^-20
+      // (a difference against 16) and at most 2^61 in magnitude.  (Round 1 evaluated it for every slot that had any out-of-table lane;
+      // ratios below zero need a sample below black AND a negative matrix row sum, so it now has its own wave-uniform test.)
+#if IPK_OPT_LOSKIP
+      if (__builtin_amdgcn_ballot_w64(lo) != 0)
+#endif
       { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
     }
   }
