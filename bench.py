@@ -275,6 +275,11 @@ def main():
     rank, world = ctx.rank, ctx.world
 
     cW, cH, cfa, maxw, cB, cidx = CONFIGS[args.config]
+    # IPK_BENCH_DEV_SMALL=1 (development / tests only): the default run's whole control flow -- extras, the batch leg, the gather -- on
+    # frames small enough for ranks that share one GPU; the numbers of such a run mean nothing
+    dev_small = os.environ.get("IPK_BENCH_DEV_SMALL") == "1"
+    if dev_small and args.config == "c3":
+        cW, cH = 2048, 1024
     W = args.width or cW
     H = args.height or cH
     B = args.batch if args.batch is not None else cB
@@ -331,7 +336,7 @@ def main():
     # HBM traffic per launch: not measurable from inside this process (PMC counters need rocprofv3); taken from the
     # committed rocprofv3 passes of this same command (tools/profile.sh -> profiles/<round>_counters.json: separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note) when the workload matches.
-    headline = (W, H, args.src, args.out, args.data, weak) == (10000, 10000, "f32", "f32", "noise", True)
+    headline = (W, H, args.src, args.out, args.data, weak) == (10000, 10000, "f32", "f32", "noise", True) and not dev_small
     if rank == 0 and headline:
         profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_counters.json")))
         if profs:
@@ -347,7 +352,7 @@ def main():
             result["roofline_valu"] = vm
 
     if extras:
-        result["roofline"]["copy_ceiling_GBps"] = round(copy_ceiling(ctx, 1200 * 1000 * 1000), 1)     # every rank (keeps the ranks in step)
+        result["roofline"]["copy_ceiling_GBps"] = round(copy_ceiling(ctx, (12 if dev_small else 1200) * 1000 * 1000), 1)     # every rank (keeps the ranks in step)
         result["roofline"]["frac_of_copy_ceiling"] = round(achieved / result["roofline"]["copy_ceiling_GBps"], 4)
         other = {}
         for kind in ("smooth", "photo"):
@@ -359,7 +364,8 @@ def main():
         # BASELINE.json configs[3]: 64 x 24 MP frames, frame i -> rank i mod N, compute-only and with the all-gather of the results
         del wl
         torch.cuda.empty_cache()
-        result["batch_64x24MP"] = batch_mode(ctx, ipa, util, 6000, 4000, 64, "f32", "f32", args.data, steps=5, warmup=1, gather=world > 1)
+        bw, bh, bn = (600, 400, 8) if dev_small else (6000, 4000, 64)
+        result["batch_64x24MP"] = batch_mode(ctx, ipa, util, bw, bh, bn, "f32", "f32", args.data, steps=5, warmup=1, gather=world > 1)
 
     if args.config == "c4" or (args.batch is not None and args.batch > world):
         result["with_gather"] = gather_leg(ctx, wl, steps=max(2, args.steps // 4)) if world > 1 else {

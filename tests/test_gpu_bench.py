@@ -42,6 +42,27 @@ def test_bench_two_ranks_control_flow():
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["scaling"] == "weak" and d["value"] > 0
 
 
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_bench_default_control_flow_with_extras(nproc):
+    """the DEFAULT command's whole control flow -- parity check, cold-clock leg, copy ceiling, the other data kinds, the 64-frame batch
+    leg with its gather -- on small frames (IPK_BENCH_DEV_SMALL), alone and with two ranks sharing the GPU: every extra object is present
+    and the ranks stay in step (a rank that skipped a barrier would hang this test)"""
+    env = dict(os.environ, IPK_BENCH_DEV_SMALL="1", IPK_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "bench.py", "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5", "--prewarm-ms", "10"]
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", "29535"] + cmd[1:]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == nproc and d["scaling"] == "weak" and d["config"]["frames_per_step"] == nproc
+    assert "cold_ms" in d["config"] and "copy_ceiling_GBps" in d["roofline"] and set(d["other_data"]) == {"smooth", "photo"}
+    b = d["batch_64x24MP"]
+    assert b["value"] > 0 and b["scaling"] == "strong"
+    if nproc > 1:
+        assert "value" in b["with_gather"] or "error" in b["with_gather"]
+    assert "bit-identical" in d["parity_check"] and "cpu_baseline" in d
+
+
 def test_bench_batch_mode_and_configs():
     """bench.py --batch (BASELINE.json configs[3] shape, small here; the full 64 x 24 MP batch is tests/test_gpu_fused.py's) and the
     per-config modes: one JSON line each, strong scaling for a fixed batch, a roofline object per config"""
