@@ -1453,6 +1453,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // slots or rows pays ~3 % on all other data for its extra scalar bookkeeping: photo-like +3.6 %, gradient +3.3 %.  Not kept.
   // Also measured without effect (+-1 %): one v_max3 tree + a single branch in front of the 12 per-slot checks; one explicit
   // s_waitcnt lgkmcnt(0) per table stage instead of the compiler's one per consumer.)
+  // (Round 2, the queue retried in two forms, all twelve slots counted first (ballot + s_bcnt1), packed by mbcnt rank into the wave's idle
+  // staging buffer when they fit 128 entries, slot-wise otherwise: noise 0.599 -> 0.668 / 0.739 ms, photo 0.482 -> 0.527, nothing-saturated
+  // 0.465 -> 0.513 / 0.483: the counting alone -- twelve more ballots and scalar adds per wave-row -- costs more than the dense evaluation saves.)
   // (Round 2, again without gain: ONE wave-level test -- the OR of the twelve compare masks -- in front of the per-slot tests: noise 0.591 ->
   // 0.621 ms, photo 0.473 -> 0.480, smooth 0.572 -> 0.595.)
   #pragma unroll
