@@ -235,3 +235,28 @@ def test_fastpath_decision(L):
                dict(npoints=1)]:
         assert L.ipk_pipeline_takes_fastpath(C.byref(d(**kw)), 1) == 0, kw
     assert L.ipk_pipeline_takes_fastpath(C.byref(d(maxwidth=64, maxheight=10)), 1) == 1      # settings are not ops
+
+
+def test_multi_gpu_and_timing_entry_points_without_a_gpu(L):
+    """host-only parts of the round-2 entry points: band plans, argument checks, an empty timing session, the RCCL loader's failure
+    mode and the libm report before ipk_init"""
+    from imagepipe_amd import _lib
+    bands = (_lib.Band * 4)()
+    assert L.ipk_band_plan(100, 4, 2, bands) == 0
+    assert [(b.out_row0, b.out_rows, b.src_row0, b.src_rows) for b in bands] == [(0, 26, 0, 27), (26, 26, 25, 28), (52, 24, 51, 26), (76, 24, 75, 25)]
+    assert L.ipk_band_plan(0, 4, 2, bands) == -2 and L.ipk_band_plan(100, 0, 2, bands) == -2 and L.ipk_band_plan(100, 4, 2, None) == -2
+    assert L.ipk_band_plan_scaled(5760, 1440, 4, bands) == 0
+    assert sum(b.out_rows for b in bands) == 1440 and bands[0].src_row0 == 0 and bands[3].src_row0 + bands[3].src_rows == 5760
+    assert all(bands[k].src_row0 + bands[k].src_rows >= bands[k + 1].src_row0 for k in range(3))      # neighbouring source ranges touch or overlap
+    assert L.ipk_band_plan_scaled(5760, 1, 4, bands) == -2
+    n = C.c_int(-1)
+    assert L.ipk_timing_begin() == 0 and L.ipk_timing_end(None, 0, C.byref(n)) == 0 and n.value == 0
+    assert L.ipk_timing_end(None, 0, None) == -2
+    h = C.c_void_p()
+    assert L.ipk_comm_init_host(0, 0, _lib.EXCHANGE_FN(lambda *a: 0), None, C.byref(h)) == -2
+    assert L.ipk_comm_info(None, None, None, None) == -2 and L.ipk_comm_free(None) == 0
+    import torch
+    if not torch.cuda.is_available():
+        idb = C.create_string_buffer(128)
+        assert L.ipk_comm_init_rccl(idb.raw, 0, 1, C.byref(h)) == -1                                 # IPK_ERR_NOT_INIT: no device bound
+        assert L.ipk_host_libm_matches(None) == -1
