@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_raw_scaled_demosaic_w8(const T *__restr
     if (lane_in) reinterpret_cast<float4 *>(dst)[(size_t)(row - a.out_r0) * a.nwidth + col] = o;
   }
 }
-// The same again for filters with a short period (pw x ph cells, pw * ph <= kW8MaxCells: Bayer, X-Trans, 8x2, 12x12 ...): the
+// The same again for filters with a short period (pw x ph cells, pw * ph <= kW8MaxCells: Bayer, X-Trans, 12x12 ...): the
 // colour bins are filled by fused multiply-adds with {0,1} weights instead of selects.  Per pattern cell (row phase, column
 // phase of the lane's first sample) LDS holds the one-hot colour of each of the 8 window columns as four floats; a tap then costs
 // s_c = fma(t, m_c, s_c) and n_c = fma(factor, m_c, n_c) per colour -- exact: t * 1 and t * 0 are exact, x + (+-0) = x, and a sum

@@ -267,7 +267,7 @@ typedef struct {
 
 /* src: device pointer to the sensor data (element (0,0) of the uncropped frame, or of the band's
  * first source row); dst: device pointer to width*rows*3 elements of out_type.
- * Any colour filter without a fourth colour is accepted (the four RGGB phases, X-Trans, 8x2, 12x12 ...); fails with
+ * Any colour filter without a fourth colour is accepted (the four RGGB phases, X-Trans, 12x12 ...; 16-letter patterns are refused, see ipk_cfa_shift); fails with
  * IPK_ERR_UNSUPPORTED for RGBE-style filters (callers then run the staged ops). */
 IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
 /* ipk_raw_to_srgb followed by OpTransform (src/ops/transform.rs:56-73) for the given rawloader orientation, without a pass over the
