@@ -122,7 +122,9 @@ IPK_API int ipk_spline_new(const float *pts, int npts, float *px, float *py, flo
  * crop_bottom, crop_left, rotation */
 IPK_API int ipk_rotatecrop_calc_size(const float *params5, float input_ratio, size_t width, size_t height,
                                      int reverse, size_t *nwidth, size_t *nheight);
-/* rawloader CFA::shift as used by RawImage::cropped_cfa() (call site src/ops/demosaic.rs:13) */
+/* rawloader CFA::shift as used by RawImage::cropped_cfa() (call site src/ops/demosaic.rs:13).  Pattern strings: 4 (2x2), 36 (6x6) or 144
+ * (12x12) letters R G B E (M = G, Y = E), row-major.  16-letter patterns return IPK_ERR_UNSUPPORTED here and everywhere else: rawloader's
+ * tile shape for them (8x2 or 2x8) cannot be verified without its source. */
 IPK_API int ipk_cfa_shift(const char *pattern, int x, int y, char *out /* >= strlen+1 */);
 /* Orientation::to_flips / from_flips (call sites src/ops/transform.rs:58-66,106);
  * flips3 = transpose, flip_x, flip_y */
