@@ -216,16 +216,19 @@ static int host_halo(ipk_comm *c, uint8_t *slab, size_t row_bytes, const ipk_ban
 }
 
 int ipk_host_band_exchange_halo(ipk_comm *c, void *slab, size_t row_bytes, const ipk_band *bands) {
-  if (!bands_ok(c, bands) || !slab || !row_bytes) return internal_fail(IPK_ERR_INVALID, "bad host_band_exchange_halo arguments");
+  if (!bands_ok(c, bands) || !row_bytes) return internal_fail(IPK_ERR_INVALID, "bad host_band_exchange_halo arguments");
+  if (!bands[c->rank].out_rows) return IPK_OK;          // more ranks than CFA periods: an empty band holds and exchanges nothing
+  if (!slab) return internal_fail(IPK_ERR_INVALID, "bad host_band_exchange_halo arguments");
   if (c->transport != 1) return internal_fail(IPK_ERR_INVALID, "host slabs need the host transport (RCCL moves device memory)");
   return host_halo(c, static_cast<uint8_t *>(slab), row_bytes, bands);
 }
 
 int ipk_band_exchange_halo(ipk_comm *c, void *slab, size_t row_bytes, const ipk_band *bands, void *stream) {
   int rc = ipk::internal_require_init(); if (rc) return rc;
-  if (!bands_ok(c, bands) || !slab || !row_bytes) return internal_fail(IPK_ERR_INVALID, "bad band_exchange_halo arguments");
+  if (!bands_ok(c, bands) || !row_bytes) return internal_fail(IPK_ERR_INVALID, "bad band_exchange_halo arguments");
   const ipk_band &b = bands[c->rank];
   if (!b.out_rows) return IPK_OK;
+  if (!slab) return internal_fail(IPK_ERR_INVALID, "bad band_exchange_halo arguments");
   const int up = neighbour_up(bands, c->rank), down = neighbour_down(bands, c->rank, c->nranks);
   const HaloRows h = halo_rows(b);
   uint8_t *s = static_cast<uint8_t *>(slab);

@@ -260,3 +260,15 @@ def test_multi_gpu_and_timing_entry_points_without_a_gpu(L):
         idb = C.create_string_buffer(128)
         assert L.ipk_comm_init_rccl(idb.raw, 0, 1, C.byref(h)) == -1                                 # IPK_ERR_NOT_INIT: no device bound
         assert L.ipk_host_libm_matches(None) == -1
+
+
+@pytest.mark.parametrize("nranks,w,h", [(1, 64, 37), (2, 64, 37), (3, 300, 50), (8, 300, 12)])
+def test_multi_gpu_entry_points_from_a_plain_cpp_host(nranks, w, h):
+    """tests/cpp/comm_test.cpp: ranks as threads, the host transport's callback a shared-memory mailbox, host slabs and frames -- the
+    band plan, halo exchange and in-place gather through the C ABI with no Python in the data path (8 ranks on 12 rows: empty bands)"""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "comm_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    r = subprocess.run([exe, str(nranks), str(w), str(h)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "COMM_OK" in r.stdout, r.stdout + r.stderr

@@ -112,6 +112,18 @@ def test_scaled_path_banded_over_ranks_matches_oracle(cfa, H, W, nW, nH, nproc):
     assert r.returncode == 0 and "BANDED_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("nranks,w,h", [(2, 600, 150), (3, 1024, 258), (4, 300, 26)])
+def test_banded_frame_from_a_plain_cpp_host(nranks, w, h):
+    """tests/cpp/comm_test.cpp in gpu mode: ranks are threads of ONE C++ process sharing device 0 (no Python, no torch): device slabs,
+    ipk_band_exchange_halo, the band kernel into its rows of the frame, ipk_band_gather_begin / ipk_comm_wait -- every rank's gathered
+    frame equals the whole-frame launch bit for bit"""
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "comm_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    r = subprocess.run([exe, str(nranks), str(w), str(h), "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "COMM_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_rccl_transport_single_rank():
     """the RCCL transport end to end on the one GPU of this box: ncclGetUniqueId, ncclCommInitRank (one rank), a self ncclSend/ncclRecv
     group and an ncclAllGather on device buffers (ipk_comm_selftest), the band entry points as no-ops"""
