@@ -595,7 +595,20 @@ int ipk_tolab(const float *src4, size_t width, size_t height, int monochrome, co
   float mul[4], cm[12];
   if (monochrome) { ipk::srgb_d65_43(cm); mul[0] = mul[1] = mul[2] = mul[3] = 1.0f; }                     // colorspaces.rs:90-101
   else { std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul); }
-  ipk::launch_tolab(src4, width * height, mul, cm, g.lut_pairs[ipk::kLutXyzLab], dst3, g.num_cus, S(stream));
+  // the fused kernels' per-pixel form (proven multiply/fma divisions, literal redo behind a wave-uniform branch) when the parameters
+  // are finite and ordinary; else the literal kernel.  Round 2: 0.67 -> see DESIGN.md section 5 (the staged path of caching callers)
+  bool ok = true;
+  for (int i = 0; i < 4; ++i) ok = ok && std::fabs(mul[i]) <= 0x1p20f;
+  for (int i = 0; i < 12; ++i) ok = ok && std::fabs(cm[i]) <= 0x1p20f;
+  if (ok && width * height >= 256) {
+    ipk::FusedLaunch f;
+    std::memset(&f, 0, sizeof(f));
+    f.src = src4; f.dst = dst3; f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33; f.fast_ok = 1; f.has_curve = 0; f.linear = 1;
+    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.num_cus = g.num_cus;
+    ipk::launch_tolab_fast(f, width * height, S(stream));
+  } else {
+    ipk::launch_tolab(src4, width * height, mul, cm, g.lut_pairs[ipk::kLutXyzLab], dst3, g.num_cus, S(stream));
+  }
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }

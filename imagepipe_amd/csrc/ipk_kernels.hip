@@ -1414,7 +1414,8 @@ struct FastBad { bool b; };
 // Where the sample bounds come from: u16 sources -- the host walks all 65 536 values; f32 sources (CMN variants only) --
 // |black| >= range/64 makes a nonzero v - black at least |black| * 2^-25 >= range * 2^-31, and finish_row's single
 // comparison flags a row with a dividend below -2^20 * range; a row window holding a flagged row takes the literal form.
-template <bool PXG>
+// TOLAB_ONLY: stop behind OpToLab and hand back the Lab pixels (L, A, B in r, g, b) -- the staged ipk_tolab on the same arithmetic.
+template <bool PXG, bool TOLAB_ONLY = false>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
                                                 const float *__restrict__ s_gam, const float *__restrict__ s_knots,
                                                 const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false) {
@@ -1484,6 +1485,10 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
     const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
     const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+    if (TOLAB_ONLY) {
+      o[2 * g].r = L.x; o[2 * g].g = A.x; o[2 * g].b = B.x; o[2 * g + 1].r = L.y; o[2 * g + 1].g = A.y; o[2 * g + 1].b = B.y;
+      continue;
+    }
     if (has_curve && IPK_ABLATE < 3) {
       if (curve3) L = F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
       else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
@@ -1532,6 +1537,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     gg[g] = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);
     bb[g] = X * S2(par[22]) + Y * S2(par[23]) + Z * S2(par[24]);
   }
+  if (TOLAB_ONLY) return bad;
   if (!linear && IPK_ABLATE < 2) {
     float pos[12], v1[12], v2[12];
     #pragma unroll
@@ -2219,12 +2225,15 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 // owns pixels L, 64+L, 128+L, 192+L of the chunk, so every load (16 B per lane) and store (12 B per lane) is contiguous
 // across the wave and nothing needs staging.
 // ------------------------------------------------------------------------------------------
+// TOLAB_ONLY: OpToLab alone (the staged ipk_tolab, for callers that memoise the Lab buffer): same loads, same fast form with the literal
+// redo behind a wave-uniform branch, stops behind xyz_to_lab; only the Lab table lives in LDS (32 KB: several blocks per CU).
+template <bool TOLAB_ONLY>
 __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) {
   __shared__ float s_lab[kLutPairs + 4];
-  __shared__ float s_gam[kLutPairs + 4];
+  __shared__ float s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
-  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
+  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; if (!TOLAB_ONLY) s_gam[i] = a.gam_table[i]; }
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
@@ -2249,12 +2258,14 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
     bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
     if (a.fast_ok) {
-      bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0);
+      bad |= pointwise4_fast<true, TOLAB_ONLY>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
+        PixOut e;
+        if (TOLAB_ONLY) camera_to_lab(s_lab, a.tolab, px[j].x, px[j].y, px[j].z, px[j].w, e.r, e.g, e.b);
+        else e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
         if (bad) o[j] = e;
       }
     }
@@ -2283,7 +2294,16 @@ int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
   const size_t chunks = (npix + 255) / 256;
   const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
   const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
-  hipLaunchKernelGGL(k_pointwise_chain, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
+  hipLaunchKernelGGL(k_pointwise_chain<false>, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
+  return 0;
+}
+// OpToLab::run on the fast form (the staged op): f.fast_ok / f.mul4 / f.cm12 / f.lab_table as for the chain
+int launch_tolab_fast(const FusedLaunch &f, size_t npix, hipStream_t s) {
+  FusedArgs a = chain_args(f);
+  const size_t chunks = (npix + 255) / 256;
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256) * 2u;                 // two 1024-thread blocks per CU fit (34 KB of LDS each)
+  const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
+  hipLaunchKernelGGL(k_pointwise_chain<true>, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
   return 0;
 }
 
