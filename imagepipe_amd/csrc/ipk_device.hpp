@@ -186,6 +186,9 @@ __device__ __forceinline__ float lut_interp_plain(const float *__restrict__ tab,
 __device__ __forceinline__ float gamma_sample_plain(const float *__restrict__ gam, float v) {
   return lut_interp_plain(gam, rs_min(rs_max(v, 0.0f), 1.0f));
 }
+__device__ __forceinline__ float gamma_sample_plain(const LutPair *__restrict__ gam, float v) {   // the same step on a pair table
+  return lut_interp(gam, rs_min(rs_max(v, 0.0f), 1.0f));
+}
 
 // OpGamma's per-sample step (src/ops/gamma.rs:22): apply_srgb_gamma(v.max(0).min(1)); the clamp makes
 // the out-of-table branch of lookup unreachable.
@@ -301,6 +304,8 @@ __device__ __forceinline__ float spline_interpolate_3(const SplineDev &s, const 
   const float k1 = lds_knots[2 * kSplineMaxKnots + i], k2 = lds_knots[3 * kSplineMaxKnots + i], k3 = lds_knots[4 * kSplineMaxKnots + i];
 #endif
   float r = spline_poly(by, k1, k2, k3, val - bx);
+  // (tried, round 2: these three selects behind one wave-uniform test, per pixel or per pixel pair -- 4 instructions fewer per pixel on
+  // mid-tones: noise 0.591 -> 0.596 ms, photo 0.472 -> 0.477, smooth 0.570 -> 0.576.  A test that skips this little costs more than it saves.)
   r = (!up && !down) ? s.py[1] : r;                    // exact knot hit
   r = !(val > x0) ? s.py[0] : r;                       // val <= first, or NaN
   r = (val >= x2) ? s.py[2] : r;                       // val >= end

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <cstring>
 #include <cmath>
+#include <type_traits>
 #include "ipk_device.hpp"
 #include "ipk_launch.hpp"
 
@@ -34,8 +35,40 @@ using namespace ipkd;
 #ifndef IPK_OPT_LOSKIP
 #define IPK_OPT_LOSKIP 1
 #endif
+//   IPK_OPT_LABPAIRS / IPK_OPT_GAMPAIRS   the LDS copy of a lookup table as {v[i], v[i+1]-v[i]} pairs (64 KB) instead of the plain 8193 floats
+//                      (32 KB): one ds_read_b64 per lookup -- 2 LDS cycles per wave when conflict-free, banks mod 64 -- instead of a ds_read2_b32
+//                      (4 cycles, banks mod 32), and the subtraction of color_conversions.rs:112 is done once per table entry, when the block
+//                      fills its LDS, instead of once per lookup (the same f32 subtraction on the same operands)
+#ifndef IPK_OPT_LABPAIRS
+#define IPK_OPT_LABPAIRS 1
+#endif
+//                      Measured against the plain builds on one box (tools/ab.sh): Lab pairs noise 0.5917 -> 0.5898 ms, photo 0.4748 -> 0.4686, smooth
+//                      0.5735 -> 0.5679; gamma pairs as well (u8 output) noise 0.5941 -> 0.5898, photo 0.4696 -> 0.4636.  Halving the LDS cycles
+//                      buys 1 %: the kernel is not waiting for its LDS.  Variants without the room keep a plain table: generic CFA (cell
+//                      records in LDS), and the gamma table when the output is f32 (48 KB of staging; 64 + 64 + 48 KB > 160 KB).
+#ifndef IPK_OPT_GAMPAIRS
+#define IPK_OPT_GAMPAIRS 1
+#endif
 
 namespace ipk {
+
+#if IPK_OPT_LABPAIRS
+typedef LutPair LabTab;
+#else
+typedef float LabTab;
+#endif
+#if IPK_OPT_GAMPAIRS
+typedef LutPair GamTab;
+#else
+typedef float GamTab;
+#endif
+// a block's LDS copy of a plain 8193-float table, in either form (all threads of the block; before its barrier)
+__device__ __forceinline__ void fill_lds_table(float *__restrict__ lds, const float *__restrict__ plain) {
+  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) lds[i] = plain[i];
+}
+__device__ __forceinline__ void fill_lds_table(LutPair *__restrict__ lds, const float *__restrict__ plain) {
+  for (int i = threadIdx.x; i < kLutPairs; i += blockDim.x) { const float v1 = plain[i], v2 = plain[i + 1]; lds[i] = make_float2(v1, v2 - v1); }
+}
 
 // ------------------------------------------------------------------------------------------
 // helpers
@@ -1415,9 +1448,9 @@ struct FastBad { bool b; };
 // |black| >= range/64 makes a nonzero v - black at least |black| * 2^-25 >= range * 2^-31, and finish_row's single
 // comparison flags a row with a dividend below -2^20 * range; a row window holding a flagged row takes the literal form.
 // TOLAB_ONLY: stop behind OpToLab and hand back the Lab pixels (L, A, B in r, g, b) -- the staged ipk_tolab on the same arithmetic.
-template <bool PXG, bool TOLAB_ONLY = false>
-__device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const float *__restrict__ s_lab,
-                                                const float *__restrict__ s_gam, const float *__restrict__ s_knots,
+template <bool PXG, bool TOLAB_ONLY = false, typename LT, typename GT>
+__device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const LT *__restrict__ s_lab,
+                                                const GT *__restrict__ s_gam, const float *__restrict__ s_knots,
                                                 const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false) {
   bool bad = false;
   float v[12], f[12];
@@ -1539,7 +1572,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   }
   if (TOLAB_ONLY) return bad;
   if (!linear && IPK_ABLATE < 2) {
-    float pos[12], v1[12], v2[12];
+    float pos[12]; LutPair e[12];
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float c[6] = {__builtin_amdgcn_fmed3f(rr[g].x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(rr[g].y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gg[g].x, 0.0f, 1.0f),
@@ -1548,16 +1581,16 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       for (int k = 0; k < 6; ++k) pos[6 * g + k] = c[k] * kLutMaxF;
     }
     #pragma unroll
-    for (int k = 0; k < 12; ++k) { const uint32_t key = f32_as_u32_sat(pos[k]); v1[k] = s_gam[key]; v2[k] = s_gam[key + 1]; }
+    for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_gam, f32_as_u32_sat(pos[k]));
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
       float w[6];
       #pragma unroll
       for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_fractf(pos[6 * g + k]);
-      const float *p1 = v1 + 6 * g, *p2 = v2 + 6 * g;
-      rr[g] = F2(p1[0], p1[1]) + F2(w[0], w[1]) * (F2(p2[0], p2[1]) - F2(p1[0], p1[1]));
-      gg[g] = F2(p1[2], p1[3]) + F2(w[2], w[3]) * (F2(p2[2], p2[3]) - F2(p1[2], p1[3]));
-      bb[g] = F2(p1[4], p1[5]) + F2(w[4], w[5]) * (F2(p2[4], p2[5]) - F2(p1[4], p1[5]));
+      const LutPair *p = e + 6 * g;
+      rr[g] = F2(p[0].x, p[1].x) + F2(w[0], w[1]) * F2(p[0].y, p[1].y);
+      gg[g] = F2(p[2].x, p[3].x) + F2(w[2], w[3]) * F2(p[2].y, p[3].y);
+      bb[g] = F2(p[4].x, p[5].x) + F2(w[4], w[5]) * F2(p[4].y, p[5].y);
     }
   }
   #pragma unroll
@@ -1569,7 +1602,8 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
 }
 
 // The literal per-pixel evaluation (device functions of ipk_device.hpp: true divisions, the reference's control flow).
-__device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const float *__restrict__ s_lab, const float *__restrict__ s_gam,
+template <typename LT, typename GT>
+__device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const LT *__restrict__ s_lab, const GT *__restrict__ s_gam,
                                                   const float *__restrict__ s_knots, const float4 &p) {
   float l, ca, cb;
   camera_to_lab(s_lab, a.tolab, p.x, p.y, p.z, p.w, l, ca, cb);
@@ -1759,19 +1793,20 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   constexpr bool DEMO = OUT == 3;                        // demosaic only (staged OpDemosaic)
   constexpr bool ZA = DEMO || !IPK_OPT_NOZEROADD;        // literal `0.0 + tap` sums where the demosaic result itself is the output
   constexpr bool GUARD_NORM = sizeof(SrcT) == 4 && !DEMO;
-  // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB), curve knots, and one 3 KB staging
-  // buffer per wave that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
-  __shared__ float s_lab[DEMO ? 4 : kLutPairs + 4];
-  __shared__ float s_gam[DEMO ? 4 : kLutPairs + 4];
+  // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB; pairs when the output is 8/16-bit), curve knots, and one staging
+  // buffer per wave (3 KB for f32) that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
+  // (the generic-CFA variants also hold their cell records in LDS and keep both tables plain)
+  typedef typename std::conditional<GEN, float, LabTab>::type LabT;
+  typedef typename std::conditional<GEN || OUT == 0, float, GamTab>::type GamT;   // f32 output: 48 KB of staging, no room for two pair tables
+  __shared__ LabT s_lab[DEMO ? 4 : kLutPairs + 4];
+  __shared__ GamT s_gam[DEMO ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];   // base-curve knots + the 3-knot form's segment records
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
   __shared__ __attribute__((aligned(16))) float s_cells[GEN ? kGenMaxCells * kGenCellFloats : 4];   // generic-CFA cell records
   if (GEN) for (uint32_t i = threadIdx.x; i < a.gen_pw * a.gen_ph * kGenCellFloats; i += blockDim.x) s_cells[i] = a.gen_cells[i];
   constexpr int STG = DEMO ? 1024 : (OUT == 0 ? 768 : (OUT == 1 ? 192 : 384));   // dwords of staging per wave: one output row segment
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * STG : 4];
-  if (!DEMO) {
-    for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
-  }
+  if (!DEMO) { fill_lds_table(s_lab, a.lab_table); fill_lds_table(s_gam, a.gam_table); }
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
@@ -2229,11 +2264,12 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 // redo behind a wave-uniform branch, stops behind xyz_to_lab; only the Lab table lives in LDS (32 KB: several blocks per CU).
 template <bool TOLAB_ONLY>
 __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) {
-  __shared__ float s_lab[kLutPairs + 4];
-  __shared__ float s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
+  __shared__ LabTab s_lab[kLutPairs + 4];
+  __shared__ GamTab s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
-  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; if (!TOLAB_ONLY) s_gam[i] = a.gam_table[i]; }
+  fill_lds_table(s_lab, a.lab_table);
+  if (!TOLAB_ONLY) fill_lds_table(s_gam, a.gam_table);
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
@@ -2320,14 +2356,14 @@ struct __attribute__((packed, aligned(1))) rgb8x4 { uint32_t w[3]; };
 struct __attribute__((packed, aligned(2))) rgb16x4 { uint32_t w[6]; };
 template <typename SrcT, int OUT>
 __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npix, const LutPair *__restrict__ gamma_reverse) {
-  __shared__ float s_lab[kLutPairs + 4];
-  __shared__ float s_gam[kLutPairs + 4];
+  __shared__ LabTab s_lab[kLutPairs + 4];
+  __shared__ typename std::conditional<OUT == 0, float, GamTab>::type s_gam[kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
   __shared__ float s_expand[sizeof(SrcT) == 1 ? 256 : 4];              // expand_srgb_gamma(input8bit(i)), the 256 possible RGB8 samples
   constexpr int STG = OUT == 0 ? 768 : (OUT == 1 ? 192 : 384);
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[16 * STG];
-  for (int i = threadIdx.x; i < kLutPairs + 1; i += blockDim.x) { s_lab[i] = a.lab_table[i]; s_gam[i] = a.gam_table[i]; }
+  fill_lds_table(s_lab, a.lab_table); fill_lds_table(s_gam, a.gam_table);
   if (sizeof(SrcT) == 1) for (int i = threadIdx.x; i < 256; i += blockDim.x) s_expand[i] = lut_interp(gamma_reverse, input8bit((uint8_t)i));
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
