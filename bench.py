@@ -140,7 +140,8 @@ class Ctx:
 
 def timed(ctx, step, steps, warmup, prewarm_ms=0.0):
     """W untimed warm-ups, then EXACTLY `steps` steps between barrier + synchronize on both sides.  Returns (wall seconds for the
-    K steps, max over ranks; mean and median HIP-event milliseconds per step on the launch stream, max over ranks)."""
+    K steps, max over ranks; mean HIP-event milliseconds per step over that region and the median of a second, per-step-evented pass of K
+    steps, on the launch stream, max over ranks)."""
     torch = ctx.torch
     ctx.barrier()
     if prewarm_ms > 0:
@@ -154,16 +155,24 @@ def timed(ctx, step, steps, warmup, prewarm_ms=0.0):
     for _ in range(warmup):
         step()
     ctx.barrier()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_a.record()
+    for i in range(steps):
+        step()
+    ev_b.record()
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    mean_ms = ev_a.elapsed_time(ev_b) / steps
+    # the median comes from a second pass of K steps with an event between every two (outside the timed region: each event is a marker
+    # in the queue that costs the GPU a few microseconds of idle time, which matters for the 0.1 ms configurations)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     for i in range(steps):
         evs[i].record()
         step()
     evs[steps].record()
     ctx.barrier()
-    elapsed = time.perf_counter() - t0
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
-    mean_ms = evs[0].elapsed_time(evs[steps]) / steps
     median_ms = per[steps // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
     elapsed, mean_ms, median_ms = ctx.max_over_ranks([elapsed, mean_ms, median_ms])
     return elapsed, mean_ms, median_ms

@@ -45,8 +45,8 @@ struct Context {
   std::map<std::string, DevCfa> cfa_cache;
   std::map<std::string, float *> rot_cells;              // generic-CFA cell records laid out for a rotated space (pattern, orientation, frame phase)
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
-  // last: the stream its most recent user enqueued on; done: recorded on that stream when the block came back (pool_put)
-  struct Block { void *p; size_t bytes; bool busy; hipStream_t last; hipEvent_t done; bool recorded; };
+  // last: the stream its most recent user enqueued on; clean: the device has been drained since the block came back
+  struct Block { void *p; size_t bytes; bool busy; hipStream_t last; bool clean; };
   std::vector<Block> pool;
   std::mutex mu;
 };
@@ -113,40 +113,59 @@ int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
   return IPK_OK;
 }
 
-// scratch pool: buffers are handed out and returned in stream order -- a block goes back as soon as its last user is
-// enqueued (pool_put records an event on that stream), and the next user on the SAME stream runs after it.  A user on a
-// different stream makes ITS stream wait for that event (hipStreamWaitEvent: no host stall, nothing done under the lock that
-// blocks, and the previous stream's handle is never touched again -- the caller may have destroyed it).
+// scratch pool: buffers are handed out and returned in stream order -- a block goes back as soon as its last user is enqueued, and
+// the next user on the SAME stream runs after it.  Nothing is enqueued for the hand-over (round 2 recorded an event per returned
+// block; each such marker cost the queue ~5 us of idle time between two runs -- a tenth of a 2160x1440 preview).  A stream never
+// takes a block another stream used last: it gets a new one, so after a few runs every stream of a multi-stream caller owns the blocks it
+// cycles through.  Only when memory runs out is the device drained, after which every idle block may go anywhere.  No stream handle is
+// ever touched except the caller's current one (a previous one may have been destroyed).
+static int pool_pick(size_t bytes, hipStream_t stream) {
+  int best = -1;
+  for (size_t i = 0; i < g.pool.size(); ++i) {
+    const auto &b = g.pool[i];
+    if (!b.busy && b.bytes >= bytes && (b.clean || b.last == stream) && (best < 0 || b.bytes < g.pool[best].bytes)) best = (int)i;
+  }
+  return best;
+}
 int pool_get(size_t bytes, void **out, hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g.mu);
-  int best = -1;
-  for (size_t i = 0; i < g.pool.size(); ++i)
-    if (!g.pool[i].busy && g.pool[i].bytes >= bytes && (best < 0 || g.pool[i].bytes < g.pool[best].bytes)) best = (int)i;
-  if (best >= 0) {
-    auto &b = g.pool[best];
-    if (b.last != stream && b.recorded) HIPCHK(hipStreamWaitEvent(stream, b.done, 0));
-    b.busy = true; b.last = stream; *out = b.p; return IPK_OK;
+  int best = pool_pick(bytes, stream);
+  if (best < 0) {
+    bool foreign_fits = false;
+    for (const auto &b : g.pool) foreign_fits = foreign_fits || (!b.busy && b.bytes >= bytes);
+    // nothing fits on any stream: the idle blocks are all too small for this frame size, so they go before a larger one is allocated
+    // (a long-running process that moves between frame sizes keeps only what its current size needs; hipFree waits for their users)
+    if (!foreign_fits)
+      for (size_t i = g.pool.size(); i-- > 0;)
+        if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) == hipSuccess) {
+      g.pool.push_back({p, bytes, true, stream, false});
+      *out = p;
+      return IPK_OK;
+    }
+    (void)hipGetLastError();
+    // out of memory: drain the device -- every idle block is then free of users -- and look again, dropping what is too small
+    if (hipDeviceSynchronize() != hipSuccess) return fail(IPK_ERR_HIP, "hipDeviceSynchronize failed");
+    for (auto &b : g.pool) if (!b.busy) b.clean = true;
+    best = pool_pick(bytes, stream);
+    if (best < 0) {
+      for (size_t i = g.pool.size(); i-- > 0;)
+        if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
+      if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+      g.pool.push_back({p, bytes, true, stream, false});
+      *out = p;
+      return IPK_OK;
+    }
   }
-  // nothing fits: the idle blocks are all too small for this frame size, so they go before a larger one is allocated
-  // (a long-running process that moves between frame sizes keeps only what its current size needs).  hipFree waits for
-  // the device work that still uses them.
-  for (size_t i = g.pool.size(); i-- > 0;)
-    if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); (void)hipEventDestroy(g.pool[i].done); g.pool.erase(g.pool.begin() + (long)i); }
-  void *p = nullptr;
-  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-  hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(p); return fail(IPK_ERR_HIP, "hipEventCreate failed"); }
-  g.pool.push_back({p, bytes, true, stream, ev, false});
-  *out = p;
+  auto &b = g.pool[best];
+  b.busy = true; b.last = stream; b.clean = false; *out = b.p;
   return IPK_OK;
 }
 void pool_put(void *p, hipStream_t stream) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g.mu);
-  for (auto &b : g.pool) if (b.p == p) {
-    b.recorded = hipEventRecord(b.done, stream) == hipSuccess;             // a failed record (dead stream) leaves "nothing to wait for"
-    b.last = stream; b.busy = false; return;
-  }
+  for (auto &b : g.pool) if (b.p == p) { b.last = stream; b.busy = false; return; }
 }
 struct Scratch {                       // RAII: returns its buffers to the pool
   hipStream_t stream;
@@ -325,7 +344,7 @@ void ipk_shutdown(void) {
   g.cfa_cache.clear();
   for (auto &kv : g.rot_cells) (void)hipFree(kv.second);
   g.rot_cells.clear();
-  for (auto &b : g.pool) { (void)hipFree(b.p); (void)hipEventDestroy(b.done); }
+  for (auto &b : g.pool) (void)hipFree(b.p);
   g.pool.clear();
   host_lanes_release();
   g.ready = false; g.device = -1; g.num_cus = 0;
