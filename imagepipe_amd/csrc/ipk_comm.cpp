@@ -270,7 +270,7 @@ static int gather_on(ipk_comm *c, void *frame, size_t out_row_bytes, const ipk_b
   const ipk_band &mine = bands[me];
   if (c->transport == 0) {
     bool equal = root < 0;
-    for (int k = 1; k < n && equal; ++k) equal = bands[k].out_rows == bands[0].out_rows;
+    for (int k = 0; k < n && equal; ++k) equal = bands[k].out_rows == bands[0].out_rows && bands[k].out_row0 == (size_t)k * bands[0].out_rows;
     if (equal && bands[0].out_rows) {
       // equal bands lie rank after rank in the frame: the in-place ncclAllGather layout (sendbuff = recvbuff + rank * count)
       const size_t count = bands[0].out_rows * out_row_bytes;
