@@ -130,3 +130,214 @@ def test_transform_buffer_rotated_against_a_second_restatement(orc):
         want = _transform_buffer(src, w, h, tl, tr, bl, nw, nh, 3)
         got = orc.transform_buffer(src.reshape(h, w, 3), w, h, tl, tr, bl, nw, nh, 3)
         util.assert_bits_equal(np.asarray(got).ravel(), want, "transform_buffer %r" % (tl,))
+
+
+# ---- the colour path: TransformLookup tables, to_lab, basecurve, from_lab, gamma, quantisation ----------------------------------
+# Plain Python, one numpy float32 scalar operation per Rust operation, Rust's left-to-right association; cbrtf / powf / exp2f are the
+# platform libm's through ctypes -- what Rust's f32::cbrt / powf / exp2 call -- NOT numpy's vectorised versions.
+import ctypes
+import ctypes.util
+import math
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m"))
+for _n in ("cbrtf", "exp2f"):
+    getattr(_libm, _n).restype = ctypes.c_float; getattr(_libm, _n).argtypes = [ctypes.c_float]
+_libm.powf.restype = ctypes.c_float; _libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+cbrtf = lambda v: F(_libm.cbrtf(ctypes.c_float(float(v))))
+powf = lambda v, e: F(_libm.powf(ctypes.c_float(float(v)), ctypes.c_float(float(e))))
+exp2f = lambda v: F(_libm.exp2f(ctypes.c_float(float(v))))
+
+
+def _rmin(a, b):    # f32::min: a NaN operand is ignored
+    return b if np.isnan(a) else (a if np.isnan(b) else (a if a < b else b))
+
+
+def _rmax(a, b):
+    return b if np.isnan(a) else (a if np.isnan(b) else (a if a > b else b))
+
+
+def _f_lab(v):      # color_conversions.rs:120-124
+    e = F(F(216.0) / F(24389.0)); k = F(F(24389.0) / F(27.0))
+    return cbrtf(v) if v > e else F(F(F(k * v) + F(16.0)) / F(116.0))
+
+
+def _f_gamma(v):    # :134-140
+    if v < F(0.0031308):
+        return F(v * F(12.92))
+    return F(F(F(1.055) * powf(v, F(F(1.0) / F(2.4)))) - F(0.055))
+
+
+def _f_gamma_rev(v):  # :126-132
+    if v < F(0.04045):
+        return F(v / F(12.92))
+    return powf(F(F(v + F(0.055)) / F(1.055)), F(2.4))
+
+
+class _Lookup:      # color_conversions.rs:79-115
+    def __init__(self, fn):
+        self.max = 8191; self.fn = fn
+        self.table = [fn(F(F(i) / F(self.max))) for i in range(self.max + 2)]
+
+    def lookup(self, val):
+        if val < 0.0 or val > 1.0:
+            return self.fn(val)
+        pos = F(val * F(self.max))
+        key = 0 if np.isnan(pos) else int(pos)
+        a = F(pos - np.trunc(pos))
+        v1, v2 = self.table[key], self.table[key + 1]
+        return F(v1 + F(a * F(v2 - v1)))
+
+
+_TABLES = {}
+
+
+def _tab(name):
+    if name not in _TABLES:
+        _TABLES[name] = _Lookup({"lab": _f_lab, "gamma": _f_gamma, "rev": _f_gamma_rev}[name])
+    return _TABLES[name]
+
+
+_SRGB = [[F(0.4124564), F(0.3575761), F(0.1804375)], [F(0.2126729), F(0.7151522), F(0.0721750)], [F(0.0193339), F(0.1191920), F(0.9503041)]]
+_WHITE = (F(0.95047), F(1.000), F(1.08883))
+
+
+def _inverse(m):    # color_conversions.rs:20-39
+    det = F(F(F(m[0][0] * F(F(m[1][1] * m[2][2]) - F(m[2][1] * m[1][2]))) - F(m[0][1] * F(F(m[1][0] * m[2][2]) - F(m[1][2] * m[2][0])))) +
+            F(m[0][2] * F(F(m[1][0] * m[2][1]) - F(m[1][1] * m[2][0]))))
+    inv = F(F(1.0) / det)
+    d = lambda a, b, c, e: F(F(a * b) - F(c * e))
+    return [[F(d(m[1][1], m[2][2], m[2][1], m[1][2]) * inv), F(-d(m[0][1], m[2][2], m[0][2], m[2][1]) * inv), F(d(m[0][1], m[1][2], m[0][2], m[1][1]) * inv)],
+            [F(-d(m[1][0], m[2][2], m[1][2], m[2][0]) * inv), F(d(m[0][0], m[2][2], m[0][2], m[2][0]) * inv), F(-d(m[0][0], m[1][2], m[1][0], m[0][2]) * inv)],
+            [F(d(m[1][0], m[2][1], m[2][0], m[1][1]) * inv), F(-d(m[0][0], m[2][1], m[2][0], m[0][1]) * inv), F(d(m[0][0], m[1][1], m[1][0], m[0][1]) * inv)]]
+
+
+def _normalize_wbs(v):   # ops/colorspaces.rs:12-27
+    def normal(x):
+        return np.isfinite(x) and x != 0 and abs(x) >= np.finfo(np.float32).tiny
+    return [F(x / v[1]) if normal(x) else F(1.0) for x in v]
+
+
+def _camera_to_lab(mul, cm, p):    # color_conversions.rs:42-55, 156-169
+    r, g, b, e = [_rmin(F(p[i] * mul[i]), F(1.0)) for i in range(4)]
+    x, y, z = [F(F(F(F(r * cm[i][0]) + F(g * cm[i][1])) + F(b * cm[i][2])) + F(e * cm[i][3])) for i in range(3)]
+    xr, yr, zr = F(x / _WHITE[0]), F(y / _WHITE[1]), F(z / _WHITE[2])
+    t = _tab("lab")
+    fx, fy, fz = t.lookup(xr), t.lookup(yr), t.lookup(zr)
+    l = F(F(F(116.0) * fy) - F(16.0)); a = F(F(500.0) * F(fx - fy)); bb = F(F(200.0) * F(fy - fz))
+    return F(l / F(100.0)), F(F(a + F(127.0)) / F(255.0)), F(F(bb + F(127.0)) / F(255.0))
+
+
+def _lab_to_rgb(m, l, a, b):       # :58-65, 172-191
+    cl = F(l * F(100.0)); ca = F(F(a * F(255.0)) - F(127.0)); cb = F(F(b * F(255.0)) - F(127.0))
+    fy = F(F(cl + F(16.0)) / F(116.0)); fx = F(F(ca / F(500.0)) + fy); fz = F(fy - F(cb / F(200.0)))
+    e = F(F(216.0) / F(24389.0)); k = F(F(24389.0) / F(27.0))
+    fx3 = F(F(fx * fx) * fx)
+    xr = fx3 if fx3 > e else F(F(F(F(116.0) * fx) - F(16.0)) / k)
+    yr = F(F(fy * fy) * fy) if cl > F(k * e) else F(cl / k)
+    fz3 = F(F(fz * fz) * fz)
+    zr = fz3 if fz3 > e else F(F(F(F(116.0) * fz) - F(16.0)) / k)
+    x, y, z = F(xr * _WHITE[0]), F(yr * _WHITE[1]), F(zr * _WHITE[2])
+    return [F(F(F(x * m[i][0]) + F(y * m[i][1])) + F(z * m[i][2])) for i in range(3)]
+
+
+class _Spline:      # ops/curves.rs:68-157
+    def __init__(self, p):
+        pts = []
+        if len(p) == 0 or (p[0][0] > 0.0 and p[0][1] > 0.0):
+            pts.append((F(0.0), F(0.0)))
+        pts += [(F(x), F(y)) for x, y in p]
+        if len(p) == 0 or (p[-1][0] < 1.0 and p[-1][1] < 1.0):
+            pts.append((F(1.0), F(1.0)))
+        dxs = [F(pts[i + 1][0] - pts[i][0]) for i in range(len(pts) - 1)]
+        dys = [F(pts[i + 1][1] - pts[i][1]) for i in range(len(pts) - 1)]
+        sl = [F(dy / dx) for dx, dy in zip(dxs, dys)]
+        c1 = [sl[0]]
+        for i in range(len(dxs) - 1):
+            m, nx = sl[i], sl[i + 1]
+            if F(m * nx) <= 0.0:
+                c1.append(F(0.0))
+            else:
+                common = F(dxs[i] + dxs[i + 1])
+                c1.append(F(F(F(3.0) * common) / F(F(F(common + dxs[i + 1]) / m) + F(F(common + dxs[i]) / nx))))
+        c1.append(sl[-1])
+        c2, c3 = [], []
+        for i in range(len(c1) - 1):
+            inv = F(F(1.0) / dxs[i])
+            common = F(F(F(c1[i] + c1[i + 1]) - sl[i]) - sl[i])
+            c2.append(F(F(F(sl[i] - c1[i]) - common) * inv))
+            c3.append(F(F(common * inv) * inv))
+        self.pts, self.c1, self.c2, self.c3 = pts, c1, c2, c3
+
+    def interpolate(self, val):
+        if val >= self.pts[-1][0]:
+            return self.pts[-1][1]
+        if val <= self.pts[0][0]:
+            return self.pts[0][1]
+        low, high = 0, len(self.c3) - 1
+        while low <= high:
+            mid = (low + high) // 2
+            xh = self.pts[mid][0]
+            if xh < val:
+                low = mid + 1
+            elif xh > val:
+                high = mid - 1
+            else:
+                return self.pts[mid][1]
+        i = max(0, high)
+        d = F(val - self.pts[i][0])
+        return F(F(F(self.pts[i][1] + F(self.c1[i] * d)) + F(F(self.c2[i] * d) * d)) + F(F(F(self.c3[i] * d) * d) * d))
+
+
+def test_lookup_tables_against_a_second_restatement(orc):
+    """every entry of the three TransformLookup tables, built with the platform libm through ctypes"""
+    import oracle
+    for which, name in ((oracle.LUT_XYZ_LAB, "lab"), (oracle.LUT_SRGB_GAMMA, "gamma"), (oracle.LUT_SRGB_GAMMA_REVERSE, "rev")):
+        util.assert_bits_equal(orc.lut_table(which), np.array(_tab(name).table, np.float32), "table " + name)
+    vals = np.concatenate([util.uniform_f32(util.SEED + 70, 600, -0.2, 1.6), np.array([0.0, -0.0, 1.0, 0.5, np.nan, 2.0, 8.0, 1e-30, 1 - 2 ** -24], np.float32)])
+    for which, name in ((oracle.LUT_XYZ_LAB, "lab"), (oracle.LUT_SRGB_GAMMA, "gamma")):
+        util.assert_bits_equal(orc.lookup(which, vals), np.array([_tab(name).lookup(v) for v in vals], np.float32), "lookup " + name)
+
+
+def test_xyz_d65_33_against_a_second_restatement(orc):
+    util.assert_bits_equal(orc.const_xyz_d65_33(), np.array(_inverse(_SRGB), np.float32), "inverse(SRGB_D65_33)")
+
+
+def test_tolab_fromlab_gamma_against_a_second_restatement(orc):
+    n = 700
+    px = util.uniform_f32(util.SEED + 71, n * 4, -0.06, 1.0).reshape(1, n, 4)
+    px[0, :, 3] = 0.0
+    px[0, :40, :3] *= np.float32(0.02)                       # dark tones: the linear branches of both Lab directions
+    px[0, 40:60, 2] = 1.0                                      # clipped blue: ratios above 1, cbrtf
+    wb = np.array([2.0, 1.0, 1.5, np.nan], np.float32)
+    cam = util.cam_matrix()
+    mul = _normalize_wbs([F(v) for v in wb])
+    util.assert_bits_equal(orc.normalize_wbs(wb), np.array(mul, np.float32), "normalize_wbs")
+    cm = [[F(v) for v in row] for row in cam]
+    lab = np.array([_camera_to_lab(mul, cm, px[0, i]) for i in range(n)], np.float32).reshape(1, n, 3)
+    util.assert_bits_equal(orc.tolab(px, wb, cam), lab, "to_lab")
+    sp = _Spline([(0.5, 0.6)])
+    cur = lab.copy()
+    cur[0, :, 0] = [sp.interpolate(v) for v in lab[0, :, 0]]
+    util.assert_bits_equal(orc.basecurve(lab, 0.0, [(0.5, 0.6)]), cur, "basecurve")
+    m = _inverse(_SRGB)
+    rgb = np.array([_lab_to_rgb(m, *cur[0, i]) for i in range(n)], np.float32).reshape(1, n, 3)
+    util.assert_bits_equal(orc.fromlab(cur), rgb, "from_lab")
+    g = _tab("gamma")
+    out = np.array([g.lookup(_rmin(_rmax(v, F(0.0)), F(1.0))) for v in rgb.ravel()], np.float32).reshape(1, n, 3)
+    util.assert_bits_equal(orc.gamma(rgb), out, "gamma")
+    # quantisation, color_conversions.rs:323-330
+    q8 = [int(_rmin(_rmax(F(v * F(256.0)), F(0.0)), F(255.0))) for v in out.ravel()]
+    q16 = [int(_rmin(_rmax(F(math.copysign(math.floor(abs(float(F(v * F(65535.0)))) + 0.5), float(v))), F(0.0)), F(65535.0))) for v in rgb.ravel() if np.isfinite(v)]
+    assert orc.output8bit(out.ravel()).tolist() == q8
+    assert orc.output16bit(rgb.ravel()[np.isfinite(rgb.ravel())]).tolist() == q16
+
+
+@pytest.mark.parametrize("points,exposure", [([(0.5, 0.6)], 0.0), ([], 0.5), ([(0.3, 0.2), (0.6, 0.8)], 0.0), ([(0.0, 0.1)], 0.0), ([(1.0, 0.9)], 0.2),
+                                             ([(0.2, 0.3), (0.4, 0.35), (0.7, 0.9)], -0.3)])
+def test_spline_against_a_second_restatement(orc, points, exposure):
+    pts = [(F(x), F(F(y) * exp2f(F(exposure)))) for x, y in points]
+    sp = _Spline(pts)
+    vals = np.concatenate([util.uniform_f32(util.SEED + 72, 400, -0.1, 1.1), np.array([0.0, 1.0, 0.5, 0.3, 0.6, 0.2, 0.4, 0.7, -0.0], np.float32)])
+    buf = np.zeros((1, vals.size, 3), np.float32); buf[0, :, 0] = vals; buf[0, :, 1] = 0.25; buf[0, :, 2] = 0.75
+    want = buf.copy(); want[0, :, 0] = [sp.interpolate(v) for v in vals]
+    util.assert_bits_equal(orc.basecurve(buf, exposure, points), want, "basecurve %r" % (points,))
