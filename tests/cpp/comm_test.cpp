@@ -1,10 +1,13 @@
 // The multi-GPU entry points of the C ABI driven from a plain C++ host -- no Python, no torch: what the north_star's Rust caller does.
-//   comm_test <nranks> <width> <height> [gpu]
+//   comm_test <nranks> <width> <height> [gpu|rccl]
 // N "ranks" are threads of this process; the host transport's exchange callback (ipk_exchange_fn, MPI_Sendrecv semantics) is a
 // mailbox in shared memory.  Without `gpu`: host slabs and frames (ipk_host_band_exchange_halo / ipk_host_band_gather) -- runs anywhere.
 // With `gpu` (the ranks share device 0, which is why the transport is the host one: RCCL wants one GPU per rank): device slabs, the
 // band form of the fused kernel writing into its rows of the frame, ipk_band_gather_begin / ipk_comm_wait in place -- and every rank's
 // gathered frame must equal, bit for bit, what ONE ipk_raw_to_srgb launch computes for the whole frame.
+// With `rccl`: the same on the library's RCCL transport (ipk_comm_unique_id / ipk_comm_init_rccl: grouped ncclSend/ncclRecv, in-place
+// ncclAllGather) -- which needs one GPU per rank with the real RCCL, so the caller (tests/test_gpu_bench.py) puts the test double
+// tests/cpp/mock_rccl.cpp first on LD_LIBRARY_PATH; plus a gather to one root.
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +49,8 @@ int main(int argc, char **argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: comm_test nranks width height [gpu]\n"); return 2; }
   const int n = std::atoi(argv[1]);
   const size_t W = std::atol(argv[2]), H = std::atol(argv[3]);
-  const bool gpu = argc > 4 && std::strcmp(argv[4], "gpu") == 0;
+  const bool rccl = argc > 4 && std::strcmp(argv[4], "rccl") == 0;
+  const bool gpu = rccl || (argc > 4 && std::strcmp(argv[4], "gpu") == 0);
   std::vector<uint16_t> raw(W * H);
   uint64_t s = 0x9E3779B97F4A7C15ull;
   for (auto &v : raw) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (uint16_t)((s >> 33) % 16384); }
@@ -77,6 +81,8 @@ int main(int argc, char **argv) {
     ipk_free(dsrc); ipk_free(ddst);
   }
 
+  uint8_t id[IPK_COMM_ID_BYTES];
+  if (rccl && ipk_comm_unique_id(id) != 0) { std::fprintf(stderr, "unique id: %s\n", ipk_last_error()); return 3; }
   Mailbox mb;
   std::vector<int> results((size_t)n, 0);
   std::vector<std::thread> th;
@@ -85,7 +91,8 @@ int main(int argc, char **argv) {
     [&] {
       Ctx ctx{&mb, rank};
       ipk_comm *comm = nullptr;
-      CHECK(ipk_comm_init_host(rank, n, exchange, &ctx, &comm));
+      if (rccl) CHECK(ipk_comm_init_rccl(id, rank, n, &comm));
+      else CHECK(ipk_comm_init_host(rank, n, exchange, &ctx, &comm));
       const ipk_band b = bands[(size_t)rank];
       const size_t top = b.out_row0 - b.src_row0;
       if (!gpu) {
@@ -116,6 +123,15 @@ int main(int argc, char **argv) {
         CHECK(ipk_memcpy_d2h(got.data(), frame, got.size() * 4, nullptr));
         CHECK(ipk_stream_sync(nullptr));
         if (std::memcmp(got.data(), whole.data(), got.size() * 4) != 0) { std::fprintf(stderr, "rank %d: banded frame differs from the whole-frame launch\n", rank); ok = false; }
+        // the same bands gathered to ONE root (the last rank): it ends up with the frame, nobody else's buffer is written
+        std::vector<float> part(W * H * 3, -7.0f);
+        std::memcpy(part.data() + b.out_row0 * W * 3, whole.data() + b.out_row0 * W * 3, b.out_rows * W * 3 * 4);
+        std::vector<float> before = part;
+        CHECK(ipk_memcpy_h2d(frame, part.data(), part.size() * 4, nullptr));
+        CHECK(ipk_band_gather(comm, frame, W * 3 * 4, bands.data(), n - 1, nullptr));
+        CHECK(ipk_memcpy_d2h(part.data(), frame, part.size() * 4, nullptr));
+        CHECK(ipk_stream_sync(nullptr));
+        if (std::memcmp(part.data(), rank == n - 1 ? whole.data() : before.data(), part.size() * 4) != 0) { std::fprintf(stderr, "rank %d: rooted gather wrong\n", rank); ok = false; }
         ipk_free(slab); ipk_free(frame);
       }
       ipk_comm_free(comm);
@@ -124,6 +140,6 @@ int main(int argc, char **argv) {
   });
   for (auto &t : th) t.join();
   for (int r = 0; r < n; ++r) if (!results[(size_t)r]) { std::fprintf(stderr, "rank %d failed\n", r); return 1; }
-  std::printf("COMM_OK nranks=%d %zux%zu %s\n", n, W, H, gpu ? "gpu" : "host");
+  std::printf("COMM_OK nranks=%d %zux%zu %s\n", n, W, H, rccl ? "rccl" : (gpu ? "gpu" : "host"));
   return 0;
 }

@@ -124,6 +124,22 @@ def test_banded_frame_from_a_plain_cpp_host(nranks, w, h):
     assert r.returncode == 0 and "COMM_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("nranks,w,h", [(2, 600, 150), (3, 1024, 258), (4, 300, 26), (4, 512, 64), (8, 256, 96)])
+def test_rccl_transport_protocol_with_several_ranks(nranks, w, h):
+    """The library's RCCL transport with 2..8 ranks on this single-GPU box: comm_test in rccl mode (ranks = threads sharing device 0) with
+    the TEST DOUBLE tests/cpp/mock_rccl.cpp first on LD_LIBRARY_PATH -- the real RCCL refuses two ranks on one device.  The double keeps
+    NCCL's group / FIFO-matching / in-place all-gather semantics and fails on a count mismatch, so what is verified here is ipk_comm.cpp's
+    side: peers, offsets, counts and stream order of the grouped ncclSend/ncclRecv halo exchange, the in-place ncclAllGather (equal bands:
+    4 x 512 x 64) and the ragged and rooted gathers, ipk_comm_selftest included.  The real RCCL is driven by the single-rank test below."""
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "comm_test")
+    mock = os.path.join(ROOT, "tests", "cpp", "build", "mockrccl")
+    if not os.path.exists(exe) or not os.path.exists(os.path.join(mock, "librccl.so.1")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    env = dict(os.environ, LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(nranks), str(w), str(h), "rccl"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "COMM_OK" in r.stdout and "rccl" in r.stdout, r.stdout + r.stderr
+
+
 def test_rccl_transport_single_rank():
     """the RCCL transport end to end on the one GPU of this box: ncclGetUniqueId, ncclCommInitRank (one rank), a self ncclSend/ncclRecv
     group and an ncclAllGather on device buffers (ipk_comm_selftest), the band entry points as no-ops"""
