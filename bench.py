@@ -14,7 +14,9 @@ rank i mod N with no data-path collective; value = all frames' pixels / max-rank
                          --width 6000 --height 4000), with a second figure that includes the all-gather of the f32 results
   --config c5 / c5b      configs[4]: 8640x5760 X-Trans -> 2160x1440 (scaled demosaic + point-wise chain) / the same at full size
 The default run also reports, as extra objects of the same line: the cold-clock time, the median, the measured device-copy
-ceiling, two more data kinds (smooth, photo), the 64 x 24 MP batch (configs[3]) and the VALU-issue model of the kernel.
+ceiling, two more data kinds (smooth, photo), the 64 x 24 MP batch (configs[3]) and the VALU-issue model of the kernel; with N > 1 also
+`band_mode`: ONE frame row-sharded over the N GPUs on the library's RCCL transport (halo exchange, band kernel, all-gather), measured in child
+processes so that it cannot cost the line.
 """
 import argparse
 import ctypes
@@ -62,6 +64,7 @@ def parse():
                          "the same workload without it is reported as config.cold_ms")
     ap.add_argument("--band", action="store_true",
                     help="additionally time ONE frame row-sharded over the N GPUs with the halo exchange (extra 'band_mode' object)")
+    ap.add_argument("--band-child", nargs=4, metavar=("RANK", "WORLD", "LOCAL_RANK", "IDHEX"), default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -276,6 +279,8 @@ def valu_model(kernel_ms):
 
 def main():
     args = parse()
+    if args.band_child:
+        return band_child(args)
     ctx = Ctx(args)
     torch = ctx.torch
     import imagepipe_amd as ipa
@@ -376,6 +381,12 @@ def main():
         bw, bh, bn = (600, 400, 8) if dev_small else (6000, 4000, 64)
         result["batch_64x24MP"] = batch_mode(ctx, ipa, util, bw, bh, bn, "f32", "f32", args.data, steps=5, warmup=1, gather=world > 1)
 
+    if extras and world > 1:
+        # ONE frame row-sharded over the N GPUs on the library's RCCL transport, in child processes (so that it cannot cost this line)
+        torch.cuda.empty_cache()
+        result["band_mode"] = band_children(ctx, args, W, H)
+        ctx.barrier()
+
     if args.config == "c4" or (args.batch is not None and args.batch > world):
         result["with_gather"] = gather_leg(ctx, wl, steps=max(2, args.steps // 4)) if world > 1 else {
             "note": "one GPU: every result is already resident on it, the gather is a no-op"}
@@ -454,6 +465,101 @@ def band_leg(ctx, ipa, util, wl, args):
     return {"ms_per_frame": round(eb / args.steps * 1e3, 4), "value": round(args.steps * H * W / 1e6 / eb, 1), "unit": "MP/s",
             "scaling": "strong", "rows_per_rank": band.out_rows, "halo_bytes_per_neighbour": W * (4 if wl.is_float else 2),
             "transport": comm.transport, "gather": "none (bands stay on their GPUs)"}
+
+
+def band_child(args):
+    """Child process of band_children(): ONE frame row-sharded over the N GPUs through the C entry points on the library's RCCL transport
+    (ipk_comm_init_rccl with the id the parents exchanged): ipk_band_plan, ipk_band_exchange_halo in place on the slab, the band form of the fused
+    kernel writing into its rows of the frame, ipk_band_gather to every rank.  Rank 0 also computes the whole frame in one launch and compares.
+    Its own process, so that nothing it does -- a hang, a crash inside RCCL -- can cost the parent its bench line."""
+    import ctypes as C
+    rank, world, local_rank = int(args.band_child[0]), int(args.band_child[1]), int(args.band_child[2])
+    import torch
+    torch.cuda.set_device(local_rank)
+    import imagepipe_amd as ipa
+    from imagepipe_amd import _lib, parallel as par
+    import util
+    ipa.init(local_rank)
+    L = _lib.load()
+    h = C.c_void_p()
+    _lib.check(L.ipk_comm_init_rccl(bytes.fromhex(args.band_child[3]), rank, world, C.byref(h)), "ipk_comm_init_rccl")
+    comm = par.Comm.__new__(par.Comm)
+    comm.handle, comm.rank, comm.world, comm.transport, comm.group = h, rank, world, "rccl", None
+    comm.selftest()
+    W, H = args.width, args.height
+    bands = par.band_plan(H, world, 2)
+    band = bands[rank]
+    src = synth_frame(torch, H, W, args.data, util.SEED + 77).to(torch.float32)          # the same frame on every rank (same seed)
+    slab, own = par.alloc_slab(band, W, torch.float32, "cuda")
+    own.copy_(src[band.out_row0: band.out_row0 + band.out_rows])
+    kw = dict(width=W, height=H, is_float=True, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    plan_b = ipa.FusedPlan(band=(band.src_row0, band.src_rows, band.out_row0, band.out_rows), **kw)
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    out_b = frame[band.out_row0: band.out_row0 + band.out_rows].reshape(-1)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def compute():
+        comm.exchange_halo(slab, bands, st)
+        if band.out_rows:
+            plan_b.run(slab.view(-1), out_b, st)
+
+    def timeit(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    t_compute = timeit(compute, args.steps, 3)
+    t_gather = timeit(lambda: (compute(), comm.gather(frame, bands, root=-1, stream=st)), max(2, args.steps // 4), 1)
+    same = None
+    if rank == 0:
+        whole = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+        ipa.FusedPlan(**kw).run(src.view(-1), whole, st)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(frame.view(-1).view(torch.int32), whole.view(torch.int32)))
+    comm.close()
+    if rank == 0:
+        print("BAND_CHILD " + json.dumps({
+            "frame": [W, H], "ranks": world, "transport": "rccl (ipk_comm: grouped ncclSend/ncclRecv halo rows in place, " +
+            ("ncclAllGather in place" if all(b.out_rows == bands[0].out_rows for b in bands) else "grouped ncclSend/ncclRecv gather") + ")",
+            "ms_per_frame": round(t_compute, 4), "value": round(H * W / 1e6 / (t_compute * 1e-3), 1), "unit": "MP/s", "scaling": "strong",
+            "ms_per_frame_with_all_gather_f32": round(t_gather, 4), "rows_per_rank": band.out_rows, "halo_bytes_per_neighbour": W * 4,
+            "gathered_frame_bit_identical_to_one_launch": same}), flush=True)
+
+
+def band_children(ctx, args, W, H):
+    """N > 1: the banded single-frame mode measured in CHILD processes (one per rank, on the rank's GPU), see band_child(); a child that fails or
+    does not finish in time costs only this sub-object."""
+    import subprocess
+    try:
+        import imagepipe_amd as ipa
+        from imagepipe_amd import _lib
+        box = [None]
+        if ctx.rank == 0:
+            idb = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(_lib.load().ipk_comm_unique_id(idb), "ipk_comm_unique_id")
+            box = [idb.raw.hex()]
+        ctx.dist.broadcast_object_list(box, src=0)
+        cmd = [sys.executable, os.path.abspath(__file__), "--band-child", str(ctx.rank), str(ctx.world), str(ctx.local_rank), box[0],
+               "--width", str(W), "--height", str(H), "--steps", str(max(4, args.steps // 2)), "--data", args.data]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+            out, err, rc = r.stdout, r.stderr, r.returncode
+        except subprocess.TimeoutExpired as e:
+            out, err, rc = (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), "timeout after 300 s", -9
+        res = None
+        for line in out.splitlines():
+            if line.startswith("BAND_CHILD "):
+                res = json.loads(line[len("BAND_CHILD "):])
+        if res is None:
+            res = {"error": "rank %d child rc=%s: %s" % (ctx.rank, rc, (err or out)[-400:])}
+        return res
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def cpu_baseline(util, data, seconds):

@@ -60,6 +60,9 @@ def test_bench_default_control_flow_with_extras(nproc):
     assert b["value"] > 0 and b["scaling"] == "strong"
     if nproc > 1:
         assert "value" in b["with_gather"] or "error" in b["with_gather"]
+        # the banded single-frame leg runs in child processes on the RCCL transport: with two ranks on ONE GPU RCCL refuses the communicator,
+        # and the leg must report that instead of costing the line
+        assert "band_mode" in d and ("value" in d["band_mode"] or "error" in d["band_mode"]), d.get("band_mode")
     assert "bit-identical" in d["parity_check"] and "cpu_baseline" in d
 
 
@@ -138,6 +141,22 @@ def test_rccl_transport_protocol_with_several_ranks(nranks, w, h):
     env = dict(os.environ, LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([exe, str(nranks), str(w), str(h), "rccl"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "COMM_OK" in r.stdout and "rccl" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_band_child_on_the_real_rccl_with_one_rank():
+    """bench.py's banded single-frame leg (the child process `bench.py --gpus N` starts per rank on the library's RCCL transport), here with the
+    one rank this box allows: real ncclCommInitRank with an id whose root lives in THIS process, ipk_comm_selftest, halo exchange, band kernel,
+    gather -- and the frame compared with one whole-frame launch"""
+    import ctypes as C
+    from imagepipe_amd import _lib
+    idb = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    _lib.check(_lib.load().ipk_comm_unique_id(idb), "ipk_comm_unique_id")
+    r = subprocess.run([sys.executable, "bench.py", "--band-child", "0", "1", "0", idb.raw.hex(), "--width", "2048", "--height", "1024", "--steps", "4"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("BAND_CHILD ")]
+    assert r.returncode == 0 and line, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(line[-1][len("BAND_CHILD "):])
+    assert d["gathered_frame_bit_identical_to_one_launch"] is True and d["ranks"] == 1 and d["value"] > 0
 
 
 def test_rccl_transport_single_rank():
