@@ -1377,7 +1377,11 @@ __device__ __forceinline__ float4 demosaic_gen_px(const float *__restrict__ cell
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
   #pragma unroll
   // the weights are 0 or 1, so t * w is exact and the fused form rounds the same sum once: s + t*w bit for bit, in one instruction instead of two
+#ifdef IPK_GEN_NOFMA   // development A/B only
+  for (int i = 0; i < 9; ++i) { s0 = s0 + t[i] * w[i]; s1 = s1 + t[i] * w[9 + i]; s2 = s2 + t[i] * w[18 + i]; }
+#else
   for (int i = 0; i < 9; ++i) { s0 = __builtin_fmaf(t[i], w[i], s0); s1 = __builtin_fmaf(t[i], w[9 + i], s1); s2 = __builtin_fmaf(t[i], w[18 + i], s2); }
+#endif
   return make_float4(__builtin_fmaf(s0, w[28], s0 * w[31]), __builtin_fmaf(s1, w[29], s1 * w[32]), __builtin_fmaf(s2, w[30], s2 * w[33]), 0.0f);
 }
 // The literal form (demosaic.rs:99-114) from the packed tap colours: frame-edge pixels (taps outside the image are
