@@ -840,3 +840,18 @@ def test_full_size_rotated_space_equals_rotating_the_normal_result(ipa, H, W, cf
         assert (got.width, got.height) == (want.width, want.height)
         assert torch.equal(got.data.view(torch.int32), want.data.view(torch.int32)), (rotation, fliph)
         del got, want
+
+
+@pytest.mark.parametrize("cfa", ["RGGB", XT])
+@pytest.mark.parametrize("shape,is_float", [((10, 150001), False), ((12, 131072), True), ((120011, 10), False), ((65537, 12), True), ((10, 65535), False)])
+def test_fused_extreme_aspect_ratios(ipa, orc, cfa, shape, is_float):
+    """frames that are one strip wide and very tall, or ten rows high and wider than any strip / segment plan has seen: the wave-strip
+    walker's task grid, its 32-bit indices and the row-band bookkeeping at their ends of the range (reference: any usize dimensions >= 10)"""
+    h, w = shape
+    raw = util.noise_u16(util.SEED + h + w, h, w)
+    if is_float:
+        raw = raw.astype(np.float32)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa, is_float=is_float))
+    got = pipe.run()
+    assert pipe.last_used_fused and (got.width, got.height) == (w, h)
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa)), "extreme shape %s %dx%d" % (cfa[:4], w, h))
