@@ -341,3 +341,71 @@ def test_spline_against_a_second_restatement(orc, points, exposure):
     buf = np.zeros((1, vals.size, 3), np.float32); buf[0, :, 0] = vals; buf[0, :, 1] = 0.25; buf[0, :, 2] = 0.75
     want = buf.copy(); want[0, :, 0] = [sp.interpolate(v) for v in vals]
     util.assert_bits_equal(orc.basecurve(buf, exposure, points), want, "basecurve %r" % (points,))
+
+
+# ---- white-balance helpers: temp_to_xyz / xyz_to_temp / OpToLab::set_temp / get_temp, host-only f64 + f32 maths -----------
+import json
+import os
+
+_CIE = [(w, float(x), float(y), float(z)) for w, x, y, z in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cie1931_2deg_5nm.json")))]
+
+
+def _temp_to_xyz(temp):          # color_conversions.rs:276-292 (f64 throughout, f32 at the end)
+    c1, c2 = 3.7417717905326694e-16, 0.014387773457709927
+    xyz = [0.0, 0.0, 0.0]
+    t = float(F(temp))
+    for w, vx, vy, vz in _CIE:
+        wl = float(w) / 1.0e9
+        p5 = wl * wl; p5 = p5 * p5; p5 = p5 * wl                        # powi(5): square, square, times x
+        power = c1 / (p5 * (math.exp(c2 / (t * wl)) - 1.0))
+        xyz[0] += power * vx; xyz[1] += power * vy; xyz[2] += power * vz
+    m = max(max(xyz[0], xyz[1]), xyz[2])
+    return [F(v / m) for v in xyz]
+
+
+def _xyz_to_temp(xyz):           # :294-310
+    lo, hi = F(1000.0), F(40000.0)
+    temp = F(0.0); new = [F(0.0)] * 3
+    while F(hi - lo) > 1.0:
+        temp = F(F(hi + lo) / F(2.0))
+        new = _temp_to_xyz(temp)
+        if F(new[2] / new[0]) > F(xyz[2] / xyz[0]):
+            hi = temp
+        else:
+            lo = temp
+    return temp, F(F(new[1] / new[0]) / F(xyz[1] / xyz[0]))
+
+
+def test_white_balance_helpers_against_a_second_restatement(orc):
+    for temp in (2000.0, 3200.0, 5003.5, 6504.0, 10000.0, 25000.0):
+        util.assert_bits_equal(orc.temp_to_xyz(temp), np.array(_temp_to_xyz(temp), np.float32), "temp_to_xyz %g" % temp)
+    for xyz in ([0.95047, 1.0, 1.08883], [1.0, 0.9, 0.4], [0.8, 1.0, 1.3], _temp_to_xyz(4321.0)):
+        xyz = [F(v) for v in xyz]
+        t, ti = _xyz_to_temp(xyz)
+        got = orc.xyz_to_temp(np.array(xyz, np.float32))
+        assert (np.float32(got[0]), np.float32(got[1])) == (t, ti), (xyz, got, t, ti)
+    # OpToLab::set_temp / get_temp (ops/colorspaces.rs:59-85)
+    xyz_to_cam = np.array([[0.9, -0.3, -0.1], [-0.4, 1.2, 0.2], [-0.1, 0.2, 0.7], [0.0, 0.0, 0.0]], np.float32)
+    for temp, tint in ((5000.0, 1.0), (3000.0, 1.1), (7500.0, 0.93)):
+        xyz = _temp_to_xyz(temp)
+        xyz = [xyz[0], F(xyz[1] / F(tint)), xyz[2]]
+        wb = []
+        for i in range(4):
+            acc = F(0.0)
+            for j in range(3):
+                acc = F(acc + F(xyz_to_cam[i][j] * xyz[j]))
+            with np.errstate(all="ignore"):
+                wb.append(F(F(1.0) / acc))                            # f32::recip; the E row is all zeros: 1/0 = inf -> not normal -> 1.0
+        with np.errstate(all="ignore"):
+            want = _normalize_wbs(wb)
+        util.assert_bits_equal(orc.tolab_set_temp(xyz_to_cam, temp, tint), np.array(want, np.float32), "set_temp %g" % temp)
+    cam_to_xyz = util.cam_matrix()
+    for wbv in ([2.0, 1.0, 1.5, 0.0], [1.7, 1.0, 2.2, float("nan")], [2.4, 1.0, 1.2, 1.0]):
+        acc = [F(0.0)] * 3
+        for i in range(3):
+            for j in range(4):
+                if F(wbv[j]) > 0.0:
+                    acc[i] = F(acc[i] + F(F(cam_to_xyz[i][j]) / F(wbv[j])))
+        t, ti = _xyz_to_temp(acc)
+        got = orc.tolab_get_temp(cam_to_xyz, np.array(wbv, np.float32))
+        assert (np.float32(got[0]), np.float32(got[1])) == (t, ti), (wbv, got, t, ti)
