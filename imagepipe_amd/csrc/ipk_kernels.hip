@@ -1538,6 +1538,10 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // (Round 2, the queue retried in two forms, all twelve slots counted first (ballot + s_bcnt1), packed by mbcnt rank into the wave's idle
   // staging buffer when they fit 128 entries, slot-wise otherwise: noise 0.599 -> 0.668 / 0.739 ms, photo 0.482 -> 0.527, nothing-saturated
   // 0.465 -> 0.513 / 0.483: the counting alone -- twelve more ballots and scalar adds per wave-row -- costs more than the dense evaluation saves.)
+  // (Round 2, the instruction mix per 256-pixel wave-row, tools/pmc_mix.sh: 920 VALU + 76 scalar + 62 branch/wait + 46 LDS + 6 memory = 1110 at 2.2
+  // wave-cycles each.  ONE s_waitcnt lgkmcnt(0) per table stage (compiler-visible builtin + scheduling barrier; the plain table's subtraction
+  // moved behind it) instead of the compiler's one per consumer removes 19 of them: noise 0.586 -> 0.594 ms, photo 0.470 -> 0.473 -- the
+  // progressive waits let the first lerps start while the last reads are still in flight, and a wait that is already satisfied costs little.)
   // (Round 2, again without gain: ONE wave-level test -- the OR of the twelve compare masks -- in front of the per-slot tests: noise 0.591 ->
   // 0.621 ms, photo 0.473 -> 0.480, smooth 0.572 -> 0.595.)
   #pragma unroll
