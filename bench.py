@@ -203,9 +203,13 @@ class FusedBatch:
         self.stream = torch.cuda.current_stream().cuda_stream
         self.in_b = 4.0 if self.is_float else 2.0
         self.out_b = {"f32": 12.0, "u8": 3.0, "u16": 6.0}[out_kind]
-        self.launches_per_step = max(1, len(self.mine))
+        self.launches_per_step = max(1, len(self.mine))        # frames per step on this rank: kernel_ms is the time per FRAME
+        self.batch = ipa.FusedBatchPlan(self.plan, self.srcs, self.dsts) if len(self.mine) > 1 and os.environ.get("IPK_BENCH_NO_BATCH_LAUNCH") != "1" else None
 
     def step(self):
+        if self.batch is not None:                      # several frames on this rank: ipk_raw_to_srgb_batch, one persistent launch per 64 frames
+            self.batch.run(self.stream)
+            return
         for s, d in zip(self.srcs, self.dsts):
             self.plan.run(s, d, self.stream)
 
@@ -437,6 +441,7 @@ def batch_mode(ctx, ipa, util, W, H, B, src_kind, out_kind, data, steps, warmup,
     out = {"config": "BASELINE.json configs[3]: %d x %dx%d RGGB %s frames per step, frame i on rank i mod N, no data-path collective" % (B, W, H, src_kind),
            "value": round(mp / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "scaling": "strong",
            "frames_on_rank0": len(wl.mine), "kernel_ms": round(kernel_ms, 4),
+           "launch": "ipk_raw_to_srgb_batch: one persistent launch per 64 frames of a rank (kernel_ms = time per frame)" if wl.batch is not None else "one launch per frame",
            "frac": round(wl.alg_bytes_per_launch() / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if gather:
         out["with_gather"] = gather_leg(ctx, wl, steps=2)

@@ -663,6 +663,25 @@ class FusedPlan:
         return out
 
 
+class FusedBatchPlan:
+    """ipk_raw_to_srgb_batch over fixed lists of same-shaped frames: the pointer arrays are built once, run() is one C call (one persistent
+    launch per 64 frames where the kernel has a batch variant)."""
+
+    def __init__(self, plan: "FusedPlan", srcs, outs):
+        assert len(srcs) == len(outs)
+        self.plan, self.srcs, self.outs = plan, list(srcs), list(outs)          # keeps the tensors alive
+        n = len(self.srcs)
+        self._n = n
+        self._s = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in self.srcs])
+        self._d = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in self.outs])
+
+    def run(self, stream=None):
+        rc = lib().ipk_raw_to_srgb_batch(self.plan._ref, self._s, self._d, self._n, stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        if rc < 0:
+            _lib.check(rc, "ipk_raw_to_srgb_batch")
+        return self.outs
+
+
 def raw_to_srgb(src: torch.Tensor, *, out: Optional[torch.Tensor] = None, **kw):
     """The fused kernel through the C ABI (ipk_raw_to_srgb); `band` = (src_row0, src_rows, out_row0, out_rows)."""
     plan = FusedPlan(**kw)

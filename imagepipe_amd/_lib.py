@@ -128,6 +128,7 @@ SIGNATURES = {
     "ipk_output8bit": (C.c_int, [_vp, _sz, _vp, _vp]),
     "ipk_output16bit": (C.c_int, [_vp, _sz, _vp, _vp]),
     "ipk_raw_to_srgb": (C.c_int, [C.POINTER(FusedParams), _vp, _vp, _vp]),
+    "ipk_raw_to_srgb_batch": (C.c_int, [C.POINTER(FusedParams), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _sz, _vp]),
     "ipk_raw_to_srgb_oriented": (C.c_int, [C.POINTER(FusedParams), _vp, C.c_int, _vp, _szp, _szp, _vp]),
     "ipk_pipeline_sizes": (C.c_int, [C.POINTER(PipelineDesc), _szp, _szp, _szp, _szp]),
     "ipk_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int), _vp]),

@@ -732,7 +732,9 @@ static int get_rot_cells(const char *pat, const ipk::Cfa &cfa, int ori, size_t w
 // ori = 0: the frame as it is.  ori = Rotate90 / Rotate270 (Bayer filters, whole frames): the mosaic is first permuted into the
 // output orientation (1 channel: 2 or 4 bytes per pixel instead of the 12 of the result) and the kernel works in rotated space,
 // so that dst receives OpTransform's output directly; IPK_ERR_UNSUPPORTED (nothing launched) when no such variant exists.
-static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, void *stream, int ori) {
+// nbatch > 0: the frames srcs[0..nbatch) -> dsts[0..nbatch), all with the geometry and parameters of *p (src / dst = the first pair)
+static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, void *stream, int ori,
+                      size_t nbatch = 0, const void *const *srcs = nullptr, void *const *dsts = nullptr) {
   REQUIRE_INIT();
   if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
   if (p->src_type != IPK_SRC_U16 && p->src_type != IPK_SRC_F32) return fail(IPK_ERR_INVALID, "fused path takes u16 or f32 CFA data");
@@ -761,6 +763,17 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.src = base; f.dst = dst;
   f.src_is_u16 = p->src_type == IPK_SRC_U16;
   f.src_aligned4 = (reinterpret_cast<uintptr_t>(base) % 4 == 0) && (p->owidth % 2 == 0);
+  f.batch_n = 0; f.batch_src = nullptr; f.batch_dst = nullptr;
+  std::vector<const void *> bases;
+  if (nbatch) {
+    const size_t off = static_cast<size_t>(base - static_cast<const char *>(src));
+    for (size_t i = 0; i < nbatch; ++i) {
+      if (!srcs[i] || !dsts[i]) return fail(IPK_ERR_INVALID, "null frame pointer in the batch");
+      bases.push_back(static_cast<const char *>(srcs[i]) + off);
+      f.src_aligned4 = f.src_aligned4 && reinterpret_cast<uintptr_t>(bases.back()) % 4 == 0;
+    }
+    f.batch_n = (int)nbatch; f.batch_src = bases.data(); f.batch_dst = dsts;
+  }
   f.width = p->width; f.height = p->height; f.owidth = p->owidth;
   f.ori = 0; f.roles[0] = f.roles[1] = f.roles[2] = f.roles[3] = 0;
   Scratch rot(S(stream));
@@ -842,6 +855,15 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   return IPK_OK;
 }
 int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream) { return fused_impl(p, src, dst, stream, 0); }
+// A batch of same-shaped frames through one descriptor: Pipeline::run over a shoot.  One persistent launch per 64 frames where the
+// kernel has a batch variant (ordinary Bayer parameters), one launch per frame otherwise -- the results are the single-frame ones.
+int ipk_raw_to_srgb_batch(const ipk_fused_params *p, const void *const *srcs, void *const *dsts, size_t n, void *stream) {
+  if (!p || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
+  if (n == 0) return IPK_OK;
+  if (n > (size_t)1 << 20) return fail(IPK_ERR_INVALID, "batch too large");
+  if (p->band_out_rows != 0) return fail(IPK_ERR_INVALID, "a batch takes whole frames, not bands");
+  return fused_impl(p, srcs[0], dsts[0], stream, 0, n, srcs, dsts);
+}
 int ipk_raw_to_srgb_oriented(const ipk_fused_params *p, const void *src, int orientation, void *dst, size_t *out_width, size_t *out_height, void *stream) {
   if (!p || !out_width || !out_height) return fail(IPK_ERR_INVALID, "null argument");
   if (orientation == IPK_OR_NORMAL || orientation == IPK_OR_UNKNOWN) { *out_width = p->width; *out_height = p->height; return fused_impl(p, src, dst, stream, 0); }

@@ -1190,6 +1190,7 @@ struct FusedArgs {
   uint64_t owidth;            // source row pitch (elements)
   uint32_t row_off;           // image row held by slab row 0
   uint32_t out_r0, out_r1;    // output rows [out_r0, out_r1)
+  uint32_t n_frames;          // batch launches (k_fused_bayer_batch): frames behind the BatchPtrs argument
   float min0, range0;         // blacklevels[0], whitelevels[0]-blacklevels[0]
   float inv_range0;           // RN(1/range0) for the 4-instruction division
   int exact_norm;             // 1: normalise with true divisions (host could not validate the fast form for range0)
@@ -1838,8 +1839,11 @@ struct RgbeStage {
 // normalisation, gamma on unless the output is 16-bit (output_16bit forces linear).  Runtime-uniform flags cost scalar
 // branches in the row loop; with them folded away the f32 kernel is 4 % faster.  Anything else runs the CMN = false variant.
 // ROT = the launch works in rotated space (see OriFlips): any of the seven non-Normal orientations, wave-uniform dispatch on a.ori.
-template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
-__global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
+// the frames of a batch launch: up to kBatchMax per launch, passed by value as the second kernel argument (1 KB of kernarg)
+constexpr int kBatchMax = 64;
+struct BatchPtrs { const void *src[kBatchMax]; void *dst[kBatchMax]; };
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG, bool CMN, bool ROT, bool BATCH>
+__device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const BatchPtrs *bp) {
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
   constexpr bool DEMO = OUT == 3;                        // demosaic only (staged OpDemosaic)
@@ -1871,290 +1875,306 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) {
   // run of tasks -- block b -> run b % 8, position b / 8 -- so that vertically adjacent row segments share an L2 left the HBM fetch
   // at 453 -> 452 MB per launch: the two halo rows a segment shares with its neighbour are read ~0.1 ms apart and do not survive in
   // a 4 MB L2 that streams 1.6 GB.  Time unchanged on uniform data, +4 % on a frame whose saturated region then lands on one XCD.)
-  const uint32_t task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (task >= a.n_strips * a.n_segs) return;             // whole wave leaves together
-  const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
+  // One task = one strip x row segment of one frame.  A single-frame launch gives every wave exactly one task.  A BATCH launch (the frames of
+  // ipk_raw_to_srgb_batch, same shape and parameters, pointers in the second kernel argument) is persistent: 16 waves per CU walk the tasks of
+  // all frames with stride = the number of waves, so a block fills its LDS tables once for the whole batch and no CU idles between frames.
+  const uint32_t per_frame = a.n_strips * a.n_segs;
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const uint32_t n_tasks = BATCH ? per_frame * a.n_frames : per_frame;
+  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gt < n_tasks; gt += n_waves) {   // whole waves enter and leave together
+    const uint32_t frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
+    const uint32_t task = BATCH ? gt - frame * per_frame : gt;
+    const void *const frame_src = BATCH ? bp->src[frame] : a.src;
+    void *const frame_dst = BATCH ? bp->dst[frame] : a.dst;
+    const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
 
-  // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each.  FULL: every strip is 64 lanes wide and the
-  // last one is shifted left to stay inside the frame; the columns it shares with its neighbour are computed by
-  // both waves (identical values written twice), which keeps every lane active and every access unpredicated.
-  const uint32_t lc0 = FULL ? 0u : strip * a.lc_base + min(strip, a.lc_rem);
-  const uint32_t nl = FULL ? 64u : a.lc_base + (strip < a.lc_rem ? 1u : 0u);
-  const bool lane_on = FULL ? true : lane < nl;
-  const uint32_t pc0 = FULL ? min(strip * 256u, a.W - 256u) : 4u * lc0;   // first pixel column of the strip
-  // lanes past the strip shadow its last lane: their loads stay in bounds and need no predicate
-  const uint32_t col0 = pc0 + 4u * min(lane, nl - 1);
-  const uint32_t nvalid = FULL ? 4u : min(4u, a.W - col0);
-  // column parity of the lane's pixel j inside the RGGB tile is (j + xo) & 1: col0 - pc0 is a multiple of 4
-  const uint32_t xo = ((uint32_t)a.xoff + pc0) & 1u;
-  // generic-CFA mode: the lane's four pattern-cell columns (float offsets into a row of cell records) never change
-  uint32_t cxo[4] = {0, 0, 0, 0};
-  if (GEN) {
-    #pragma unroll
-    for (int j = 0; j < 4; ++j) cxo[j] = ((col0 + j) % a.gen_pw) * kGenCellFloats;
-  }
-  // generic-CFA mode checks its rows for ordinary samples (gen_sample_bad); u16 sources skip the check when the host did it
-  // for all 65 536 values
-  // (a compile-time false for the Bayer variants, so that they carry no trace of it)
-  const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
-  // rows: this segment's output rows [r0, r1)
-  const uint32_t nrows = a.out_r1 - a.out_r0;
-  const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
-  const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
-  if (r0 >= r1) return;
-
-  // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl); every other lane
-  // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
-  const bool is_first = lane == 0, is_last = lane + 1 == nl;
-  const bool single = FULL ? false : nl == 1;            // one lane carries both halos: second one via h2
-  const int64_t hcol_want = is_first ? (int64_t)pc0 - 1 : (int64_t)pc0 + 4 * (int64_t)nl;
-  const uint32_t hcol = ((is_first || is_last) && hcol_want >= 0 && hcol_want < (int64_t)a.W) ? (uint32_t)hcol_want : col0;
-  const uint32_t h2col = (single && pc0 + 4u * nl < a.W) ? pc0 + 4u * nl : col0;
-
-  const SrcT *src = reinterpret_cast<const SrcT *>(a.src);
-  const float min0 = a.min0, range0 = a.range0, inv_range0 = a.inv_range0;
-  const bool exact_norm = CMN ? false : a.exact_norm != 0;
-  const bool fast_ok = CMN ? true : a.fast_ok != 0, has_curve = CMN ? true : a.has_curve != 0, linear = CMN ? (OUT == 2) : a.linear != 0;
-
-  // One image row is fetched in two steps so that the global loads of row r+2 are in flight while row r is
-  // being computed: issue_row() only loads, finish_row() normalises (OpGoFloat) and gathers the horizontal
-  // neighbours (DPP wave shifts + the strip's two halo columns).
-  struct RawRowT { float v0, v1, v2, v3, h, h2; };
-  auto issue_row = [&](uint32_t row) -> RawRowT {
-    const SrcT *rp = src + (uint64_t)(row - a.row_off) * a.owidth;
-    RawRowT t;
-    load_raw4<SrcT, VEC>(rp + col0, nvalid, t.v0, t.v1, t.v2, t.v3);
-    t.h = (float)rp[hcol];
-    t.h2 = single ? (float)rp[h2col] : 0.0f;
-    return t;
-  };
-  // `flag` (generic-CFA mode): some sample of this row is outside the zone of the arithmetic demosaic form (wave-uniform)
-  auto finish_row = [&](const RawRowT &t, bool &flag) -> RowWin {
-    flag = false;
-    // OpGoFloat: ((v - black) / range).min(1.0)  (gofloat.rs:126).  The division is cdiv_fast unless the host
-    // could not validate it for this range, or a dividend of this wave is outside the proven zone.
-    const float d0 = t.v0 - min0, d1 = t.v1 - min0, d2 = t.v2 - min0, d3 = t.v3 - min0, dh = t.h - min0, dh2 = t.h2 - min0;
-    RowWin w;
-    float h, h2 = 0.0f;
-    if (DEMO) {                                          // input is an OpBuffer already: no OpGoFloat step
-      w.v0 = t.v0; w.v1 = t.v1; w.v2 = t.v2; w.v3 = t.v3;
-      w.l = dpp_wave_shr1(t.h, w.v3);
-      const float rr0 = dpp_wave_shl1(t.h, w.v0);
-      w.r = is_last ? (single ? t.h2 : t.h) : rr0;
-      if (gen_guard) flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(t.v0) | gen_sample_bad(t.v1) | gen_sample_bad(t.v2) | gen_sample_bad(t.v3) |
-                                                        gen_sample_bad(t.h) | gen_sample_bad(t.h2)) != 0;
-      return w;
+    // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each.  FULL: every strip is 64 lanes wide and the
+    // last one is shifted left to stay inside the frame; the columns it shares with its neighbour are computed by
+    // both waves (identical values written twice), which keeps every lane active and every access unpredicated.
+    const uint32_t lc0 = FULL ? 0u : strip * a.lc_base + min(strip, a.lc_rem);
+    const uint32_t nl = FULL ? 64u : a.lc_base + (strip < a.lc_rem ? 1u : 0u);
+    const bool lane_on = FULL ? true : lane < nl;
+    const uint32_t pc0 = FULL ? min(strip * 256u, a.W - 256u) : 4u * lc0;   // first pixel column of the strip
+    // lanes past the strip shadow its last lane: their loads stay in bounds and need no predicate
+    const uint32_t col0 = pc0 + 4u * min(lane, nl - 1);
+    const uint32_t nvalid = FULL ? 4u : min(4u, a.W - col0);
+    // column parity of the lane's pixel j inside the RGGB tile is (j + xo) & 1: col0 - pc0 is a multiple of 4
+    const uint32_t xo = ((uint32_t)a.xoff + pc0) & 1u;
+    // generic-CFA mode: the lane's four pattern-cell columns (float offsets into a row of cell records) never change
+    uint32_t cxo[4] = {0, 0, 0, 0};
+    if (GEN) {
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) cxo[j] = ((col0 + j) % a.gen_pw) * kGenCellFloats;
     }
-    bool redo = exact_norm;
-    // a dividend outside cdiv_fast's zone either clips to 1.0 (huge positive: exact in both forms) or gives a sample the row
-    // check below rejects, which then redoes the row with true divisions -- so the row check replaces this one when it runs
-    if (GUARD_NORM && !gen_guard) {
-      if (CMN) {
-        // CMN implies |black| >= 2^-70 (host-checked), so a nonzero v - black is at least half an ulp of black: no tiny
-        // dividends.  A huge positive one clips to 1.0 whatever the division does; inf and NaN are v_div_fixup's.  That
-        // leaves dividends below -2^100, one comparison on the minimum of the six.
-        // Without per-pixel guards (PXG == false; f32 only with CMN) the same comparison also keeps every sample above -2^20,
-        // and the host has checked |black| >= range/64, which puts every nonzero sample at 2^-31 or more (see pointwise4_fast).
-        const float lowest = PXG ? -0x1p100f : -0x1p20f * range0;
-        redo = __builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(dh, dh2)) >= lowest)) != 0;
-        if (!PXG) flag = redo;
-      } else {
-        redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
-                                                    cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
+    // generic-CFA mode checks its rows for ordinary samples (gen_sample_bad); u16 sources skip the check when the host did it
+    // for all 65 536 values
+    // (a compile-time false for the Bayer variants, so that they carry no trace of it)
+    const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
+    // rows: this segment's output rows [r0, r1)
+    const uint32_t nrows = a.out_r1 - a.out_r0;
+    const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
+    const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
+    if (r0 >= r1) { if (BATCH) continue; return; }
+
+    // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl); every other lane
+    // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
+    const bool is_first = lane == 0, is_last = lane + 1 == nl;
+    const bool single = FULL ? false : nl == 1;            // one lane carries both halos: second one via h2
+    const int64_t hcol_want = is_first ? (int64_t)pc0 - 1 : (int64_t)pc0 + 4 * (int64_t)nl;
+    const uint32_t hcol = ((is_first || is_last) && hcol_want >= 0 && hcol_want < (int64_t)a.W) ? (uint32_t)hcol_want : col0;
+    const uint32_t h2col = (single && pc0 + 4u * nl < a.W) ? pc0 + 4u * nl : col0;
+
+    const SrcT *src = reinterpret_cast<const SrcT *>(frame_src);
+    const float min0 = a.min0, range0 = a.range0, inv_range0 = a.inv_range0;
+    const bool exact_norm = CMN ? false : a.exact_norm != 0;
+    const bool fast_ok = CMN ? true : a.fast_ok != 0, has_curve = CMN ? true : a.has_curve != 0, linear = CMN ? (OUT == 2) : a.linear != 0;
+
+    // One image row is fetched in two steps so that the global loads of row r+2 are in flight while row r is
+    // being computed: issue_row() only loads, finish_row() normalises (OpGoFloat) and gathers the horizontal
+    // neighbours (DPP wave shifts + the strip's two halo columns).
+    struct RawRowT { float v0, v1, v2, v3, h, h2; };
+    auto issue_row = [&](uint32_t row) -> RawRowT {
+      const SrcT *rp = src + (uint64_t)(row - a.row_off) * a.owidth;
+      RawRowT t;
+      load_raw4<SrcT, VEC>(rp + col0, nvalid, t.v0, t.v1, t.v2, t.v3);
+      t.h = (float)rp[hcol];
+      t.h2 = single ? (float)rp[h2col] : 0.0f;
+      return t;
+    };
+    // `flag` (generic-CFA mode): some sample of this row is outside the zone of the arithmetic demosaic form (wave-uniform)
+    auto finish_row = [&](const RawRowT &t, bool &flag) -> RowWin {
+      flag = false;
+      // OpGoFloat: ((v - black) / range).min(1.0)  (gofloat.rs:126).  The division is cdiv_fast unless the host
+      // could not validate it for this range, or a dividend of this wave is outside the proven zone.
+      const float d0 = t.v0 - min0, d1 = t.v1 - min0, d2 = t.v2 - min0, d3 = t.v3 - min0, dh = t.h - min0, dh2 = t.h2 - min0;
+      RowWin w;
+      float h, h2 = 0.0f;
+      if (DEMO) {                                          // input is an OpBuffer already: no OpGoFloat step
+        w.v0 = t.v0; w.v1 = t.v1; w.v2 = t.v2; w.v3 = t.v3;
+        w.l = dpp_wave_shr1(t.h, w.v3);
+        const float rr0 = dpp_wave_shl1(t.h, w.v0);
+        w.r = is_last ? (single ? t.h2 : t.h) : rr0;
+        if (gen_guard) flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(t.v0) | gen_sample_bad(t.v1) | gen_sample_bad(t.v2) | gen_sample_bad(t.v3) |
+                                                          gen_sample_bad(t.h) | gen_sample_bad(t.h2)) != 0;
+        return w;
       }
-    }
-    if (!redo) {
-      w.v0 = rs_min(cdiv_fast(d0, range0, inv_range0), 1.0f); w.v1 = rs_min(cdiv_fast(d1, range0, inv_range0), 1.0f);
-      w.v2 = rs_min(cdiv_fast(d2, range0, inv_range0), 1.0f); w.v3 = rs_min(cdiv_fast(d3, range0, inv_range0), 1.0f);
-      h = rs_min(cdiv_fast(dh, range0, inv_range0), 1.0f);
-      if (single) h2 = rs_min(cdiv_fast(dh2, range0, inv_range0), 1.0f);
-    } else {
-      w.v0 = rs_min(d0 / range0, 1.0f); w.v1 = rs_min(d1 / range0, 1.0f); w.v2 = rs_min(d2 / range0, 1.0f); w.v3 = rs_min(d3 / range0, 1.0f);
-      h = rs_min(dh / range0, 1.0f);
-      if (single) h2 = rs_min(dh2 / range0, 1.0f);
-    }
-    if (gen_guard) {
-      flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(w.v0) | gen_sample_bad(w.v1) | gen_sample_bad(w.v2) | gen_sample_bad(w.v3) |
-                                         gen_sample_bad(h) | gen_sample_bad(h2)) != 0;
-      if (flag && !redo) {                               // rare: the row's samples again, literally
+      bool redo = exact_norm;
+      // a dividend outside cdiv_fast's zone either clips to 1.0 (huge positive: exact in both forms) or gives a sample the row
+      // check below rejects, which then redoes the row with true divisions -- so the row check replaces this one when it runs
+      if (GUARD_NORM && !gen_guard) {
+        if (CMN) {
+          // CMN implies |black| >= 2^-70 (host-checked), so a nonzero v - black is at least half an ulp of black: no tiny
+          // dividends.  A huge positive one clips to 1.0 whatever the division does; inf and NaN are v_div_fixup's.  That
+          // leaves dividends below -2^100, one comparison on the minimum of the six.
+          // Without per-pixel guards (PXG == false; f32 only with CMN) the same comparison also keeps every sample above -2^20,
+          // and the host has checked |black| >= range/64, which puts every nonzero sample at 2^-31 or more (see pointwise4_fast).
+          const float lowest = PXG ? -0x1p100f : -0x1p20f * range0;
+          redo = __builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(dh, dh2)) >= lowest)) != 0;
+          if (!PXG) flag = redo;
+        } else {
+          redo = redo || __builtin_amdgcn_ballot_w64(cdiv_guard(d0) | cdiv_guard(d1) | cdiv_guard(d2) | cdiv_guard(d3) |
+                                                      cdiv_guard(dh) | cdiv_guard(dh2)) != 0;
+        }
+      }
+      if (!redo) {
+        w.v0 = rs_min(cdiv_fast(d0, range0, inv_range0), 1.0f); w.v1 = rs_min(cdiv_fast(d1, range0, inv_range0), 1.0f);
+        w.v2 = rs_min(cdiv_fast(d2, range0, inv_range0), 1.0f); w.v3 = rs_min(cdiv_fast(d3, range0, inv_range0), 1.0f);
+        h = rs_min(cdiv_fast(dh, range0, inv_range0), 1.0f);
+        if (single) h2 = rs_min(cdiv_fast(dh2, range0, inv_range0), 1.0f);
+      } else {
         w.v0 = rs_min(d0 / range0, 1.0f); w.v1 = rs_min(d1 / range0, 1.0f); w.v2 = rs_min(d2 / range0, 1.0f); w.v3 = rs_min(d3 / range0, 1.0f);
         h = rs_min(dh / range0, 1.0f);
         if (single) h2 = rs_min(dh2 / range0, 1.0f);
       }
-    }
-    w.l = dpp_wave_shr1(h, w.v3);                        // lane 0 keeps its halo (left column)
-    const float rr = dpp_wave_shl1(h, w.v0);             // lane 63 keeps its halo
-    w.r = is_last ? (single ? h2 : h) : rr;
-    return w;
-  };
+      if (gen_guard) {
+        flag = __builtin_amdgcn_ballot_w64(gen_sample_bad(w.v0) | gen_sample_bad(w.v1) | gen_sample_bad(w.v2) | gen_sample_bad(w.v3) |
+                                           gen_sample_bad(h) | gen_sample_bad(h2)) != 0;
+        if (flag && !redo) {                               // rare: the row's samples again, literally
+          w.v0 = rs_min(d0 / range0, 1.0f); w.v1 = rs_min(d1 / range0, 1.0f); w.v2 = rs_min(d2 / range0, 1.0f); w.v3 = rs_min(d3 / range0, 1.0f);
+          h = rs_min(dh / range0, 1.0f);
+          if (single) h2 = rs_min(dh2 / range0, 1.0f);
+        }
+      }
+      w.l = dpp_wave_shr1(h, w.v3);                        // lane 0 keeps its halo (left column)
+      const float rr = dpp_wave_shl1(h, w.v0);             // lane 63 keeps its halo
+      w.r = is_last ? (single ? h2 : h) : rr;
+      return w;
+    };
 
-  const bool store_aligned = (OUT == 0 || OUT == 3) ? true : ((OUT == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
-  const uint32_t Hm1 = a.H - 1, Wm1 = a.W - 1;
-  const bool col_edge = lane_on && (col0 == 0 || col0 + 3 >= Wm1);
+    const bool store_aligned = (OUT == 0 || OUT == 3) ? true : ((OUT == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
+    const uint32_t Hm1 = a.H - 1, Wm1 = a.W - 1;
+    const bool col_edge = lane_on && (col0 == 0 || col0 + 3 >= Wm1);
 
-  const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
-  bool fP = false, fC = false, fN = false;
-  if (r0 > 0) P = finish_row(issue_row(r0 - 1), fP);
-  C = finish_row(issue_row(r0), fC);
-  uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
-  // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
-  // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
-  (void)zero_raw;
-  // Software pipeline: while row r is computed its window (P, C, N = rows r-1, r, r+1) is already in registers; row r+2
-  // is *finished* (the wait for its loads) after the arithmetic of row r and BEFORE that row's stores are issued, and row
-  // r+3 is *issued* after them.  gfx9 counts loads and stores in one vmcnt and the compiler must assume they complete
-  // out of order, so a wait for loads with younger stores in flight becomes vmcnt(0) and exposes the full store latency
-  // every iteration (it was 24 % of the wave's time); here the only stores older than the awaited loads are a whole
-  // iteration old.
-  N = finish_row(issue_row(min(r0 + 1, Hm1)), fN);
-  RawRowT raw_next = issue_row(min(r0 + 2, Hm1));
-  // (the ~20 register moves that rotate the row window per iteration would vanish in a 3x unrolled loop; the compiler refuses
-  // `#pragma unroll 3` here -- wave-level ballots and barriers in the body -- and a hand-unrolled body triples the code for ~1 %)
-  for (uint32_t r = r0; r < r1; ++r) {
-    const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
-    const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
-    const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
-    const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
-    float4 px[4];
-    // interior formulas; role = (row parity, column parity) in the RGGB tile; the column parity of pixel j is
-    // (j + xo) & 1 with a per-strip xo: wave-uniform branches only.
-    const float *rowcells = s_cells + ry * a.gen_pw * kGenCellFloats;
-    if (GEN) {
-      // any filter without a fourth colour: masked sums + proven division, or the literal form for a row window that
-      // holds a sample outside the proven zone
-      const bool literal = fP | fC | fN;
-      #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
-        if (ROT) (void)ori_window_dyn(a.ori, pw, cw, nw, j, t, 0x1FFu);   // rotated space: the cell records are the sensor pixel's, its taps in their original order
-        if (!literal) px[j] = demosaic_gen_px(rowcells + cxo[j], t);
-        else px[j] = demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, 0x1FFu);
-      }
-    } else if (ROT) {
-      // rotated space: the role of a pixel comes from the host's table over (row, column) parity, its taps renamed into the
-      // original orientation's order; both choices are wave-uniform
-      demosaic_rot_row_dyn(a.ori, a.roles[2 * (int)(r & 1u) + (int)xo], pw, cw, nw, px);
-    } else if (pr == 0) {
-      if (xo == 0) {
-        px[0] = demosaic_inner_px<0, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<1, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<0, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<1, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
-      } else {
-        px[0] = demosaic_inner_px<1, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<0, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<1, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<0, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
-      }
-    } else {
-      if (xo == 0) {
-        px[0] = demosaic_inner_px<2, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<3, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<2, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<3, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
-      } else {
-        px[0] = demosaic_inner_px<3, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
-        px[1] = demosaic_inner_px<2, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
-        px[2] = demosaic_inner_px<3, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
-        px[3] = demosaic_inner_px<2, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
-      }
-    }
-    // frame-edge pixels: taps outside the image are skipped, not mirrored (demosaic.rs:103-104)
-    const bool edge_lane = (r == 0) || (r == Hm1) || col_edge;
-    if (__builtin_amdgcn_ballot_w64(edge_lane) != 0) {
-      if (edge_lane) {
+    const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
+    bool fP = false, fC = false, fN = false;
+    if (r0 > 0) P = finish_row(issue_row(r0 - 1), fP);
+    C = finish_row(issue_row(r0), fC);
+    uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
+    // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
+    // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
+    (void)zero_raw;
+    // Software pipeline: while row r is computed its window (P, C, N = rows r-1, r, r+1) is already in registers; row r+2
+    // is *finished* (the wait for its loads) after the arithmetic of row r and BEFORE that row's stores are issued, and row
+    // r+3 is *issued* after them.  gfx9 counts loads and stores in one vmcnt and the compiler must assume they complete
+    // out of order, so a wait for loads with younger stores in flight becomes vmcnt(0) and exposes the full store latency
+    // every iteration (it was 24 % of the wave's time); here the only stores older than the awaited loads are a whole
+    // iteration old.
+    N = finish_row(issue_row(min(r0 + 1, Hm1)), fN);
+    RawRowT raw_next = issue_row(min(r0 + 2, Hm1));
+    // (the ~20 register moves that rotate the row window per iteration would vanish in a 3x unrolled loop; the compiler refuses
+    // `#pragma unroll 3` here -- wave-level ballots and barriers in the body -- and a hand-unrolled body triples the code for ~1 %)
+    for (uint32_t r = r0; r < r1; ++r) {
+      const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
+      const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
+      const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
+      const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
+      float4 px[4];
+      // interior formulas; role = (row parity, column parity) in the RGGB tile; the column parity of pixel j is
+      // (j + xo) & 1 with a per-strip xo: wave-uniform branches only.
+      const float *rowcells = s_cells + ry * a.gen_pw * kGenCellFloats;
+      if (GEN) {
+        // any filter without a fourth colour: masked sums + proven division, or the literal form for a row window that
+        // holds a sample outside the proven zone
+        const bool literal = fP | fC | fN;
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t c = col0 + j;
-          if (c < a.W && (r == 0 || r == Hm1 || c == 0 || c == Wm1)) {
-            const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
-            uint32_t m = 0x1FFu;
-            if (r == 0) m &= ~0x007u;
-            if (r == Hm1) m &= ~0x1C0u;
-            if (c == 0) m &= ~0x049u;
-            if (c == Wm1) m &= ~0x124u;
-            if (ROT) {
-              float to[9];
-              const uint32_t mo = ori_window_dyn(a.ori, pw, cw, nw, j, to, m);
-              const int role = a.roles[2 * (int)(r & 1u) + (int)((j + xo) & 1u)];
-              px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), to, mo) : demosaic_edge_dispatch(to, mo, role >> 1, role & 1);
-            } else
-            px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, m) : demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
+          float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
+          if (ROT) (void)ori_window_dyn(a.ori, pw, cw, nw, j, t, 0x1FFu);   // rotated space: the cell records are the sensor pixel's, its taps in their original order
+          if (!literal) px[j] = demosaic_gen_px(rowcells + cxo[j], t);
+          else px[j] = demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, 0x1FFu);
+        }
+      } else if (ROT) {
+        // rotated space: the role of a pixel comes from the host's table over (row, column) parity, its taps renamed into the
+        // original orientation's order; both choices are wave-uniform
+        demosaic_rot_row_dyn(a.ori, a.roles[2 * (int)(r & 1u) + (int)xo], pw, cw, nw, px);
+      } else if (pr == 0) {
+        if (xo == 0) {
+          px[0] = demosaic_inner_px<0, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+          px[1] = demosaic_inner_px<1, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+          px[2] = demosaic_inner_px<0, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+          px[3] = demosaic_inner_px<1, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        } else {
+          px[0] = demosaic_inner_px<1, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+          px[1] = demosaic_inner_px<0, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+          px[2] = demosaic_inner_px<1, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+          px[3] = demosaic_inner_px<0, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        }
+      } else {
+        if (xo == 0) {
+          px[0] = demosaic_inner_px<2, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+          px[1] = demosaic_inner_px<3, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+          px[2] = demosaic_inner_px<2, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+          px[3] = demosaic_inner_px<3, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        } else {
+          px[0] = demosaic_inner_px<3, ZA>(pw[0], pw[1], pw[2], cw[0], cw[1], cw[2], nw[0], nw[1], nw[2]);
+          px[1] = demosaic_inner_px<2, ZA>(pw[1], pw[2], pw[3], cw[1], cw[2], cw[3], nw[1], nw[2], nw[3]);
+          px[2] = demosaic_inner_px<3, ZA>(pw[2], pw[3], pw[4], cw[2], cw[3], cw[4], nw[2], nw[3], nw[4]);
+          px[3] = demosaic_inner_px<2, ZA>(pw[3], pw[4], pw[5], cw[3], cw[4], cw[5], nw[3], nw[4], nw[5]);
+        }
+      }
+      // frame-edge pixels: taps outside the image are skipped, not mirrored (demosaic.rs:103-104)
+      const bool edge_lane = (r == 0) || (r == Hm1) || col_edge;
+      if (__builtin_amdgcn_ballot_w64(edge_lane) != 0) {
+        if (edge_lane) {
+          #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t c = col0 + j;
+            if (c < a.W && (r == 0 || r == Hm1 || c == 0 || c == Wm1)) {
+              const float t[9] = {pw[j], pw[j + 1], pw[j + 2], cw[j], cw[j + 1], cw[j + 2], nw[j], nw[j + 1], nw[j + 2]};
+              uint32_t m = 0x1FFu;
+              if (r == 0) m &= ~0x007u;
+              if (r == Hm1) m &= ~0x1C0u;
+              if (c == 0) m &= ~0x049u;
+              if (c == Wm1) m &= ~0x124u;
+              if (ROT) {
+                float to[9];
+                const uint32_t mo = ori_window_dyn(a.ori, pw, cw, nw, j, to, m);
+                const int role = a.roles[2 * (int)(r & 1u) + (int)((j + xo) & 1u)];
+                px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), to, mo) : demosaic_edge_dispatch(to, mo, role >> 1, role & 1);
+              } else
+              px[j] = GEN ? demosaic_gen_literal_px(__float_as_uint(rowcells[cxo[j] + 27]), t, m) : demosaic_edge_dispatch(t, m, pr, (int)((j + xo) & 1u));
+            }
           }
         }
       }
-    }
-    if (DEMO) {
-      bool fNN;
-      const RowWin NN = finish_row(raw_next, fNN);       // row r+2 (clamped past the frame: those rows are masked as edges)
-      __builtin_amdgcn_sched_barrier(0);
-      if (FULL) {
-        uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
-        RgbeStage::stage(stg, lane, px);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        RgbeStage::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + pc0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      } else if (lane_on) {
-        RgbeStage::store_direct(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, px);
+      if (DEMO) {
+        bool fNN;
+        const RowWin NN = finish_row(raw_next, fNN);       // row r+2 (clamped past the frame: those rows are masked as edges)
+        __builtin_amdgcn_sched_barrier(0);
+        if (FULL) {
+          uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
+          RgbeStage::stage(stg, lane, px);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          RgbeStage::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else if (lane_on) {
+          RgbeStage::store_direct(frame_dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, px);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        raw_next = issue_row(min(r + 3, Hm1));
+        P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
+        if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
+        continue;
       }
+      PixOut o[4];
+#if IPK_ABLATE >= 5
+      for (int j = 0; j < 4; ++j) px[j] = make_float4(cw[j + 1], pw[j + 1], nw[j + 1], 0.0f);
+#endif
+#if IPK_ABLATE >= 4
+      for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
+#else
+      bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
+      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
+      if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
+          if (bad) o[j] = e;
+        }
+      }
+#endif
+      bool fNN;
+      const RowWin NN = finish_row(raw_next, fNN);         // row r+2: the wait for its loads sits before this row's stores
+      __builtin_amdgcn_sched_barrier(0);
+#if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
+      if (OUT == 0 && FULL) {
+        float *rowp = reinterpret_cast<float *>(frame_dst) + ((size_t)(r - a.out_r0) * a.W + pc0) * 3;
+        f4u q0{o[0].r, o[0].g, o[0].b, o[1].r}, q1{o[1].g, o[1].b, o[2].r, o[2].g}, q2{o[2].b, o[3].r, o[3].g, o[3].b};
+        reinterpret_cast<f4u *>(rowp)[lane] = q0; reinterpret_cast<f4u *>(rowp)[64 + lane] = q1; reinterpret_cast<f4u *>(rowp)[128 + lane] = q2;
+      }
+#elif IPK_ABLATE == 7    // timing only: no stores
+      if (o[0].r == 123.456f) reinterpret_cast<float *>(frame_dst)[lane] = o[1].g + o[2].b + o[3].r;
+#else
+      if (FULL) {
+        // Lane-blocked -> lane-interleaved through the wave's LDS staging buffer, then three stores per lane whose
+        // addresses are contiguous across the wave (whole cache lines per instruction; a 48-byte lane stride would
+        // touch every line of the 3 KB span with each of its stores).
+        uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
+        // The compiler reasons about one lane: a lane never reads back what it staged, so without these wave-scope
+        // fences it treats the staging writes as dead stores / reorders them past the reads.  Wavefront-scope fences
+        // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
+        OutStage<OUT>::stage(stg, lane, o);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        OutStage<OUT>::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else {
+        if (lane_on) OutStore<OUT>::store(frame_dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       raw_next = issue_row(min(r + 3, Hm1));
       P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
-      continue;
     }
-    PixOut o[4];
-#if IPK_ABLATE >= 5
-    for (int j = 0; j < 4; ++j) px[j] = make_float4(cw[j + 1], pw[j + 1], nw[j + 1], 0.0f);
-#endif
-#if IPK_ABLATE >= 4
-    for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
-#else
-    bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
-    if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
-      #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
-        if (bad) o[j] = e;
-      }
-    }
-#endif
-    bool fNN;
-    const RowWin NN = finish_row(raw_next, fNN);         // row r+2: the wait for its loads sits before this row's stores
-    __builtin_amdgcn_sched_barrier(0);
-#if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
-    if (OUT == 0 && FULL) {
-      float *rowp = reinterpret_cast<float *>(a.dst) + ((size_t)(r - a.out_r0) * a.W + pc0) * 3;
-      f4u q0{o[0].r, o[0].g, o[0].b, o[1].r}, q1{o[1].g, o[1].b, o[2].r, o[2].g}, q2{o[2].b, o[3].r, o[3].g, o[3].b};
-      reinterpret_cast<f4u *>(rowp)[lane] = q0; reinterpret_cast<f4u *>(rowp)[64 + lane] = q1; reinterpret_cast<f4u *>(rowp)[128 + lane] = q2;
-    }
-#elif IPK_ABLATE == 7    // timing only: no stores
-    if (o[0].r == 123.456f) reinterpret_cast<float *>(a.dst)[lane] = o[1].g + o[2].b + o[3].r;
-#else
-    if (FULL) {
-      // Lane-blocked -> lane-interleaved through the wave's LDS staging buffer, then three stores per lane whose
-      // addresses are contiguous across the wave (whole cache lines per instruction; a 48-byte lane stride would
-      // touch every line of the 3 KB span with each of its stores).
-      uint32_t *stg = s_stage + (threadIdx.x >> 6) * STG;
-      // The compiler reasons about one lane: a lane never reads back what it staged, so without these wave-scope
-      // fences it treats the staging writes as dead stores / reorders them past the reads.  Wavefront-scope fences
-      // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
-      OutStage<OUT>::stage(stg, lane, o);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      OutStage<OUT>::flush(stg, lane, a.dst, (size_t)(r - a.out_r0) * a.W + pc0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-      if (lane_on) OutStore<OUT>::store(a.dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    raw_next = issue_row(min(r + 3, Hm1));
-    P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
-    if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
+    if (!BATCH) return;                                   // single-frame launch: one task per wave
   }
 }
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
+__global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer_body<SrcT, VEC, OUT, FULL, GEN, PXG, CMN, ROT, false>(a, nullptr); }
+// the persistent batch form; instantiated for the common parameter set only (launch_fused_bayer_batch)
+template <typename SrcT, bool VEC, int OUT, bool PXG>
+__global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, true, false, true>(a, &bp); }
 
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blocks_per_cu);
 
@@ -2288,6 +2308,43 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   fused_task_grid(a, f.num_cus, blocks, 2);
 
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
+  if (f.batch_n > 0) {
+    // the persistent batch kernel exists for the common parameter set without per-pixel guards (launch_fused_t's first choices for real sensors)
+    const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
+                        std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
+    const bool batchable = common && a.ori == 0 && !a.gen_cells && a.px_guard == 0 && f.batch_n > 1;
+    for (int i0 = 0; i0 < f.batch_n; i0 += kBatchMax) {
+      const int n = std::min(kBatchMax, f.batch_n - i0);
+      if (batchable && n > 1) {
+        BatchPtrs bp;
+        for (int i = 0; i < n; ++i) { bp.src[i] = f.batch_src[i0 + i]; bp.dst[i] = f.batch_dst[i0 + i]; }
+        for (int i = n; i < kBatchMax; ++i) { bp.src[i] = nullptr; bp.dst[i] = nullptr; }
+        a.n_frames = (uint32_t)n;
+        const unsigned grid = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);            // one resident block per CU
+        // Row segments for a persistent launch: long tasks (24 .. 128 rows, the longest that fill the grid) whose
+        // total over the batch fills whole rounds of the grid's waves as exactly as possible (tasks are dealt round-robin, not stolen).
+        {
+          const uint32_t nrows = a.out_r1 - a.out_r0, waves = grid * 16u;
+          uint32_t best = a.n_segs; double best_eff = 0.0;
+          for (uint32_t segs = std::max(1u, nrows / 128u); segs <= std::max(1u, nrows / 24u); ++segs) {
+            const uint64_t total = (uint64_t)n * a.n_strips * segs;
+            const double eff = (double)total / (double)(((total + waves - 1) / waves) * waves);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = segs; }
+          }
+          if (best_eff > 0.0) a.n_segs = best;
+        }
+#define IPK_BATCH_LAUNCH(T, V, O) hipLaunchKernelGGL((k_fused_bayer_batch<T, V, O, false>), dim3(grid), dim3(1024), 0, s, a, bp)
+        if (!f.src_is_u16) { if (f.out_type == 0) IPK_BATCH_LAUNCH(float, true, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(float, true, 1); else IPK_BATCH_LAUNCH(float, true, 2); }
+        else { if (f.out_type == 0) IPK_BATCH_LAUNCH(uint16_t, false, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(uint16_t, false, 1); else IPK_BATCH_LAUNCH(uint16_t, false, 2); }
+#undef IPK_BATCH_LAUNCH
+      } else {
+        FusedLaunch one = f;
+        one.batch_n = 0;
+        for (int i = 0; i < n; ++i) { one.src = f.batch_src[i0 + i]; one.dst = f.batch_dst[i0 + i]; const int rc = launch_fused_bayer(one, s); if (rc) return rc; }
+      }
+    }
+    return 0;
+  }
   if (!f.src_is_u16) {
     if (f.out_type == 0) launch_fused_t<float, true, 0>(a, blocks, s);
     else if (f.out_type == 1) launch_fused_t<float, true, 1>(a, blocks, s);

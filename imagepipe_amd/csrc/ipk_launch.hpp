@@ -75,6 +75,9 @@ struct FusedLaunch {
   int num_cus;
   int ori;                       // 0, or the ipk_orientation (Rotate90 / Rotate270) in whose rotated space the launch works: src is the permuted mosaic
   int roles[4];                  // ori != 0: demosaic role of the rotated-space pixel with parities (row & 1, col & 1), index 2 * row parity + col parity
+  // launch_fused_bayer only: batch_n > 0 = that many frames of this shape and these parameters (host arrays of device pointers, src already
+  // offset like `src`); one persistent launch per 64 frames where a batch variant of the kernel exists, one launch per frame otherwise
+  int batch_n; const void *const *batch_src; void *const *batch_dst;
 };
 // returns 0, or -2 when f.ori != 0 and the parameters have no rotated-space variant (nothing is launched)
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);

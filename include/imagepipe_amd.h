@@ -272,6 +272,12 @@ typedef struct {
  * Any colour filter without a fourth colour is accepted (the four RGGB phases, X-Trans, 12x12 ...; 16-letter patterns are refused, see ipk_cfa_shift); fails with
  * IPK_ERR_UNSUPPORTED for RGBE-style filters (callers then run the staged ops). */
 IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
+/* n frames of ONE shape and ONE parameter set (a caller looping Pipeline::run over a shoot, src/pipeline.rs:246-249: frames are independent;
+ * BASELINE.json configs[3]): srcs[i] -> dsts[i], host arrays of device pointers, whole frames only.  Where the kernel has a batch variant
+ * (Bayer filter, ordinary levels / multipliers / matrix, a 2- or 3-knot curve, width >= 256) the frames run as ONE persistent launch per 64
+ * -- the lookup tables are staged once per CU instead of once per frame and CU, and no CU idles between frames; otherwise one launch per
+ * frame.  Either way every dsts[i] is bit-identical to ipk_raw_to_srgb(p, srcs[i], dsts[i]). */
+IPK_API int ipk_raw_to_srgb_batch(const ipk_fused_params *p, const void *const *srcs, void *const *dsts, size_t n, void *stream);
 /* ipk_raw_to_srgb followed by OpTransform (src/ops/transform.rs:56-73) for the given rawloader orientation, without a pass over the
  * 3-channel result: the 1-channel mosaic is permuted instead (rotate_buffer's index walk, :102-128) and the kernel works in
  * rotated space, adding the demosaic taps in the reference's order of the ORIGINAL orientation.  Whole frames (no band) of a

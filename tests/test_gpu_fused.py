@@ -855,3 +855,39 @@ def test_fused_extreme_aspect_ratios(ipa, orc, cfa, shape, is_float):
     got = pipe.run()
     assert pipe.last_used_fused and (got.width, got.height) == (w, h)
     assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa)), "extreme shape %s %dx%d" % (cfa[:4], w, h))
+
+
+@pytest.mark.parametrize("is_float,out_type,n,shape", [(True, "f32", 5, (96, 512)), (False, "u8", 3, (70, 300)), (False, "u16", 2, (64, 256)), (True, "f32", 1, (40, 260)),
+                                                       (False, "f32", 70, (24, 256)), (True, "u8", 67, (30, 258))])
+def test_batch_launch_equals_single_launches(ipa, is_float, out_type, n, shape):
+    """ipk_raw_to_srgb_batch (one persistent launch per 64 frames) against ipk_raw_to_srgb frame by frame, bit for bit; n = 70 spans two launches"""
+    import torch
+    h, w = shape
+    ot = {"f32": ipa.OUT_F32, "u8": ipa.OUT_U8, "u16": ipa.OUT_U16}[out_type]
+    plan = ipa.FusedPlan(width=w, height=h, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa="GRBG", wb_coeffs=util.WB,
+                         cam_to_xyz_normalized=util.cam_matrix(), out_type=ot, linear=(out_type == "u16"))
+    srcs = []
+    for i in range(n):
+        raw = util.noise_u16(util.SEED + 4000 + i, h, w)
+        srcs.append(torch.from_numpy(raw.astype(np.float32).ravel()).cuda() if is_float else ipa.upload_u16(raw).reshape(-1))
+    want = [plan.run(s, plan.new_output()).clone() for s in srcs]
+    outs = [torch.zeros_like(x) for x in want]
+    ipa.FusedBatchPlan(plan, srcs, outs).run()
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(outs[i].view(torch.uint8), want[i].view(torch.uint8)), "frame %d of %d" % (i, n)
+
+
+def test_batch_launch_falls_back_frame_by_frame(ipa, orc):
+    """a filter / parameter set without a batch variant of the kernel (X-Trans; no base curve): the same entry point, one launch per frame"""
+    import torch
+    h, w = 60, 270
+    for kw in (dict(cfa=XT), dict(cfa="RGGB", points=())):
+        plan = ipa.FusedPlan(width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix(), **kw)
+        srcs = [ipa.upload_u16(util.noise_u16(util.SEED + 4100 + i, h, w)).reshape(-1) for i in range(3)]
+        want = [plan.run(s, plan.new_output()).clone() for s in srcs]
+        outs = [torch.zeros_like(x) for x in want]
+        ipa.FusedBatchPlan(plan, srcs, outs).run()
+        torch.cuda.synchronize()
+        for a, b in zip(outs, want):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
