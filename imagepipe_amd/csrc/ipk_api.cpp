@@ -347,6 +347,7 @@ void ipk_shutdown(void) {
   for (auto &b : g.pool) (void)hipFree(b.p);
   g.pool.clear();
   host_lanes_release();
+  ipk::release_task_counters();
   g.ready = false; g.device = -1; g.num_cus = 0;
 }
 int ipk_is_initialized(void) { return g.ready ? 1 : 0; }
@@ -483,11 +484,13 @@ int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, si
   ipk::Cfa cfa; DevCfa dev;
   int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
   int xoff, yoff;
+  int lrc = 0;
   if (cfa.bayer_phase(xoff, yoff))       // the four RGGB phases: row-walking kernel (coalesced loads, register window, staged stores)
-    ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, nullptr, 0, 0, dst4, g.num_cus, S(stream));
+    lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, nullptr, 0, 0, dst4, g.num_cus, S(stream));
   else if (dev.gen_cells)                // any other three-colour filter (X-Trans ...): same kernel, generic-CFA mode
-    ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, 0, 0, dev.gen_cells, dev.gen_pw, dev.gen_ph, dst4, g.num_cus, S(stream));
+    lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, 0, 0, dev.gen_cells, dev.gen_pw, dev.gen_ph, dst4, g.num_cus, S(stream));
   else ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
+  if (lrc) return fail(IPK_ERR_NOMEM, "no task queue for this stream");
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
@@ -850,7 +853,9 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.out_type = p->out_type;
   f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
   f.num_cus = g.num_cus;
-  if (ipk::launch_fused_bayer(f, S(stream)) != 0) return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for these parameters");
+  { const int lrc = ipk::launch_fused_bayer(f, S(stream));
+    if (lrc == -3) return fail(IPK_ERR_NOMEM, "no task queue for this stream");
+    if (lrc != 0) return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for these parameters"); }
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }

@@ -9,6 +9,9 @@
 #include <cstring>
 #include <cmath>
 #include <type_traits>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "ipk_device.hpp"
 #include "ipk_launch.hpp"
 
@@ -1191,6 +1194,8 @@ struct FusedArgs {
   uint32_t row_off;           // image row held by slab row 0
   uint32_t out_r0, out_r1;    // output rows [out_r0, out_r1)
   uint32_t n_frames;          // batch launches (k_fused_bayer_batch): frames behind the BatchPtrs argument
+  uint32_t *task_ctr;         // this launch's task queue: tasks n_waves + *task_ctr, ... are still to be drawn (zero when the launch starts)
+  uint32_t *task_ctr_other;   // the stream's other queue, which this launch zeroes for the stream's next launch (task_counters_for)
   float min0, range0;         // blacklevels[0], whitelevels[0]-blacklevels[0]
   float inv_range0;           // RN(1/range0) for the 4-instruction division
   int exact_norm;             // 1: normalise with true divisions (host could not validate the fast form for range0)
@@ -1199,7 +1204,7 @@ struct FusedArgs {
   ToLabParams tolab;
   Mat9 rgbm;                  // XYZ_D65_33
   int has_curve, linear;
-  uint32_t n_strips, n_segs;  // task grid
+  uint32_t n_strips, n_segs;  // task grid: strips x row segments
   uint32_t lc_base, lc_rem;   // lane-columns per strip: base (+1 for the first lc_rem strips)
   const float *lab_table;
   const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
@@ -1875,15 +1880,31 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // run of tasks -- block b -> run b % 8, position b / 8 -- so that vertically adjacent row segments share an L2 left the HBM fetch
   // at 453 -> 452 MB per launch: the two halo rows a segment shares with its neighbour are read ~0.1 ms apart and do not survive in
   // a 4 MB L2 that streams 1.6 GB.  Time unchanged on uniform data, +4 % on a frame whose saturated region then lands on one XCD.)
-  // One task = one strip x row segment of one frame.  A single-frame launch gives every wave exactly one task.  A BATCH launch (the frames of
-  // ipk_raw_to_srgb_batch, same shape and parameters, pointers in the second kernel argument) is persistent: 16 waves per CU walk the tasks of
-  // all frames with stride = the number of waves, so a block fills its LDS tables once for the whole batch and no CU idles between frames.
+  // One task = one strip x row segment of one frame.  The launch is PERSISTENT -- one 1024-thread block per CU, sixteen waves -- and a wave DRAWS
+  // its next task from a device counter when it is done with the last one (lane 0's atomic, broadcast).  Round 2 gave every wave exactly one task
+  // and oversubscribed the CUs two blocks deep: a CU then waited for the slowest of a block's sixteen waves before it could take the next block (the
+  // LDS holds one), and every block staged the lookup tables again -- 13 % of the 100 MP frame's time (0.587 -> 0.510 ms).  A BATCH launch (the frames
+  // of ipk_raw_to_srgb_batch, same shape and parameters, pointers in the second kernel argument) queues the tasks of all its frames the same way.
+  // The counter is the launch stream's own (launches of one stream never overlap); a stream has two, used alternately, and a launch zeroes the one
+  // its successor will use.
   const uint32_t per_frame = a.n_strips * a.n_segs;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t n_tasks = BATCH ? per_frame * a.n_frames : per_frame;
-  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gt < n_tasks; gt += n_waves) {   // whole waves enter and leave together
+  // Every wave starts with the task of its own index; further tasks are drawn with one atomic each.  Atomics on one address cost ~6 ns apiece
+  // device-wide (8 XCDs): a first draw by all 4096 waves at once would add 25 us to a launch -- hence the static first round; the 4096 failing
+  // draws at the end are spread over the last tasks' run time.  (A coherent load in front of the atomic, to see an empty queue without touching
+  // it, made every draw cost ~40 ns instead: 0.81 ms for the 100 MP frame.)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.task_ctr_other = 0u;
+  auto draw = [&]() -> uint32_t {
+    uint32_t t = 0xFFFFFFFFu;
+    if ((threadIdx.x & 63u) == 0) {
+      t = n_waves + atomicAdd(a.task_ctr, 1u);
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  };
+  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gt < n_tasks; gt = n_tasks > n_waves ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
     const uint32_t frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
-    const uint32_t task = BATCH ? gt - frame * per_frame : gt;
+    const uint32_t task = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt - frame * per_frame)) : gt;
     const void *const frame_src = BATCH ? bp->src[frame] : a.src;
     void *const frame_dst = BATCH ? bp->dst[frame] : a.dst;
     const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
@@ -1914,7 +1935,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     const uint32_t nrows = a.out_r1 - a.out_r0;
     const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
     const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
-    if (r0 >= r1) { if (BATCH) continue; return; }
+    if (r0 >= r1) continue;
 
     // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl); every other lane
     // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
@@ -2167,7 +2188,6 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
     }
-    if (!BATCH) return;                                   // single-frame launch: one task per wave
   }
 }
 template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
@@ -2176,13 +2196,15 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer
 template <typename SrcT, bool VEC, int OUT, bool PXG>
 __global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, true, false, true>(a, &bp); }
 
-static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blocks_per_cu);
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1);
+struct FusedArgs;
+static bool task_counters_for(hipStream_t s, FusedArgs &a);
 
 // Staged demosaic::full for an RGGB-phase Bayer mosaic (OUT == 3 of the row-walking kernel).  Same band arguments as the
 // generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
 // gen_cells != null: generic-CFA mode (pattern gen_pw x gen_ph, no fourth colour) instead of the RGGB phase (xoff, yoff).
-void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
-                           int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s) {
+int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
+                          int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
   a.src = src; a.dst = dst4; a.W = (uint32_t)width; a.H = (uint32_t)img_height; a.owidth = width;
@@ -2190,7 +2212,8 @@ void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, si
   a.xoff = xoff; a.yoff = yoff; a.range0 = 1.0f; a.inv_range0 = 1.0f;
   a.gen_cells = gen_cells; a.gen_pw = (uint32_t)gen_pw; a.gen_ph = (uint32_t)gen_ph;
   unsigned blocks;
-  fused_task_grid(a, num_cus, blocks, 1);
+  fused_task_grid(a, num_cus, blocks);
+  if (!task_counters_for(s, a)) return -3;
   if (gen_cells) {
     if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, true>), dim3(blocks), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, true>), dim3(blocks), dim3(1024), 0, s, a);
@@ -2198,6 +2221,7 @@ void launch_demosaic_bayer(const float *src, size_t width, size_t img_height, si
     if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, false>), dim3(blocks), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, false>), dim3(blocks), dim3(1024), 0, s, a);
   }
+  return 0;
 }
 
 template <typename SrcT, bool VEC, int OUT>
@@ -2241,35 +2265,66 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 }
 
 // task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
-static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, int blocks_per_cu) {
-#ifdef IPK_DEV_KNOBS
-  static const int dev_tpb = getenv("IPK_DEV_TPB") ? atoi(getenv("IPK_DEV_TPB")) : 1024;
-  static const int dev_bpc = getenv("IPK_DEV_BPC") ? atoi(getenv("IPK_DEV_BPC")) : 1;
-  const uint32_t waves_per_block = dev_tpb / 64; blocks_per_cu = dev_bpc;
-#else
+// The task queues of a stream: two counters used by its launches alternately -- a launch draws from one and zeroes the other for its successor
+// (launches on one stream run in order, so neither is ever shared).  Every stream handle gets its own pair, never freed individually (8 bytes per
+// stream the process has ever launched on, from one 16 KB block); release_task_counters() returns the block at ipk_shutdown.
+namespace {
+std::mutex g_ctr_mu;
+uint32_t *g_ctr_block = nullptr;
+struct StreamCtr { hipStream_t stream; uint32_t slot, parity; };
+std::vector<StreamCtr> g_ctr_of;
+constexpr uint32_t kCtrSlots = 2048;
+}
+static bool task_counters_for(hipStream_t s, FusedArgs &a) {
+  std::lock_guard<std::mutex> lk(g_ctr_mu);
+  if (!g_ctr_block) {
+    if (hipMalloc(reinterpret_cast<void **>(&g_ctr_block), kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMemset(g_ctr_block, 0, kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(g_ctr_block); g_ctr_block = nullptr; return false; }
+  }
+  StreamCtr *e = nullptr;
+  for (auto &c : g_ctr_of) if (c.stream == s) { e = &c; break; }
+  if (!e) {
+    if (g_ctr_of.size() >= kCtrSlots) return false;           // a process with more than 2048 live streams: the caller reports it
+    g_ctr_of.push_back({s, (uint32_t)g_ctr_of.size(), 0u});
+    e = &g_ctr_of.back();
+  }
+  a.task_ctr = g_ctr_block + 2 * e->slot + e->parity;
+  a.task_ctr_other = g_ctr_block + 2 * e->slot + (e->parity ^ 1u);
+  e->parity ^= 1u;
+  return true;
+}
+void release_task_counters() {
+  std::lock_guard<std::mutex> lk(g_ctr_mu);
+  if (g_ctr_block) (void)hipFree(g_ctr_block);
+  g_ctr_block = nullptr; g_ctr_of.clear();
+}
+
+// Task grid: strips of <= 64 lane-columns x row segments.  A task costs its rows plus about 2.5 rows' worth of set-up (two halo rows, the three-row
+// priming of the walker), and the queue should hold several tasks per wave for the draws to even anything out:
+//   a wave's even share of the work is at least 40 rows of a strip (frames above ~40 MP, or any batch): segments of ~32 rows, drawn from the queue.
+//     100 MP frame (tools/task_rows_sweep.sh, one box): 24 / 32 / 48 rows 0.531 / 0.535 / 0.584 ms noise, 0.417 / 0.419 / 0.439 photo; 12 / 16 / 20 rows
+//     within 2 % of 32 on another; a tall first task per wave followed by short ones (50-80 % of the rows, then 8-24-row tasks) 0.531-0.551: no better
+//     than uniform; ONE task per wave (nothing to draw) 0.576 / 0.497; round 2's launch (two blocks per CU in turn, one task per wave) 0.587 / 0.472;
+//   smaller frames: one task per wave, at least 8 rows (24 MP: 23 rows each, 0.148 ms either way).
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
   const uint32_t waves_per_block = 16;
+#ifdef IPK_DEV_KNOBS
+  static const uint32_t uni = getenv("IPK_DEV_TASK_ROWS") ? (uint32_t)atoi(getenv("IPK_DEV_TASK_ROWS")) : 32u;
+  static const uint32_t share_min = getenv("IPK_DEV_SHARE_MIN") ? (uint32_t)atoi(getenv("IPK_DEV_SHARE_MIN")) : 40u;
+#else
+  const uint32_t uni = 32u, share_min = 40u;
 #endif
-  // blocks_per_cu > 1 oversubscribes the CUs with shorter tasks: only one 1024-thread block is resident per CU, the
-  // rest queue and the hardware hands them out as blocks finish -- which evens out frames whose saturated regions (the
-  // out-of-table cbrtf branch) would otherwise make some waves' tasks much longer than others'.  Measured at 100 MP with
-  // 1 / 2 / 4 tasks per wave: gradient frame 0.600 / 0.594 / 0.584 ms, photo-like frame 0.519 / 0.497 / 0.522 ms, uniform
-  // noise 0.620 / 0.628 / 0.629 ms (shorter tasks pay more halo rows) -- the launcher uses 2.  Tasks keep at least 24 rows.
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;
   a.n_strips = (w4 + 63) / 64;
   a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;   // balanced strips (generic kernel); FULL uses 64-lane strips
   const uint32_t nrows = a.out_r1 - a.out_r0;
-  uint32_t segs = total_waves / a.n_strips;
-  if (segs < 1) segs = 1;
-  if (blocks_per_cu > 1) {
-    const uint32_t most = std::max(segs, nrows / 24u);
-    segs = std::min(segs * (uint32_t)blocks_per_cu, most);
-  }
-  if (segs > nrows) segs = nrows;
-  a.n_segs = segs;
-  const uint32_t tasks = a.n_strips * a.n_segs;
-  blocks = (tasks + waves_per_block - 1) / waves_per_block;
+  const uint64_t share = (uint64_t)nrows * a.n_strips * frames / total_waves;   // rows of one strip a wave gets from an even split
+  if (share >= share_min) a.n_segs = std::max(1u, nrows / uni);
+  else a.n_segs = std::min(nrows, std::min(std::max(1u, (uint32_t)(total_waves / ((uint64_t)a.n_strips * frames))), std::max(1u, nrows / 8u)));
+  const uint64_t tasks = (uint64_t)a.n_strips * a.n_segs * frames;
+  blocks = (unsigned)std::min<uint64_t>(grid, (tasks + waves_per_block - 1) / waves_per_block);
 }
 
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
@@ -2305,17 +2360,15 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   }
 
   unsigned blocks;
-  fused_task_grid(a, f.num_cus, blocks, 2);
+  fused_task_grid(a, f.num_cus, blocks);
 
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
   if (f.batch_n > 0) {
-    // the persistent batch kernel exists for the common parameter set without per-pixel guards (launch_fused_t's first choices for real sensors)
+    // the multi-frame form of the kernel exists for the common parameter set without per-pixel guards (launch_fused_t's first choices for
+    // real sensors); 64 x 512x512 frames: 2.6 us per frame in one launch against 13 us with a launch each
     const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
                         std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
-    // ... and pays where launches matter: measured per frame, persistent vs one launch each -- 64 x 512x512: 2.6 vs 13 us; 64 x 24 MP: 0.151 vs
-    // 0.152 ms; 8 x 100 MP: 0.613 vs 0.589 ms (the hardware hands out single-frame blocks as CUs free up, the persistent waves take their tasks
-    // round-robin) -- so frames above 32 MP keep one launch each
-    const bool batchable = common && a.ori == 0 && !a.gen_cells && a.px_guard == 0 && f.batch_n > 1 && (uint64_t)a.W * a.H <= (32ull << 20);
+    const bool batchable = common && a.ori == 0 && !a.gen_cells && a.px_guard == 0 && f.batch_n > 1;
     for (int i0 = 0; i0 < f.batch_n; i0 += kBatchMax) {
       const int n = std::min(kBatchMax, f.batch_n - i0);
       if (batchable && n > 1) {
@@ -2323,19 +2376,9 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
         for (int i = 0; i < n; ++i) { bp.src[i] = f.batch_src[i0 + i]; bp.dst[i] = f.batch_dst[i0 + i]; }
         for (int i = n; i < kBatchMax; ++i) { bp.src[i] = nullptr; bp.dst[i] = nullptr; }
         a.n_frames = (uint32_t)n;
-        const unsigned grid = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);            // one resident block per CU
-        // Row segments for a persistent launch: long tasks (24 .. 128 rows, the longest that fill the grid) whose
-        // total over the batch fills whole rounds of the grid's waves as exactly as possible (tasks are dealt round-robin, not stolen).
-        {
-          const uint32_t nrows = a.out_r1 - a.out_r0, waves = grid * 16u;
-          uint32_t best = a.n_segs; double best_eff = 0.0;
-          for (uint32_t segs = std::max(1u, nrows / 128u); segs <= std::max(1u, nrows / 24u); ++segs) {
-            const uint64_t total = (uint64_t)n * a.n_strips * segs;
-            const double eff = (double)total / (double)(((total + waves - 1) / waves) * waves);
-            if (eff > best_eff + 1e-9) { best_eff = eff; best = segs; }
-          }
-          if (best_eff > 0.0) a.n_segs = best;
-        }
+        unsigned grid;
+        fused_task_grid(a, f.num_cus, grid, (uint32_t)n);
+        if (!task_counters_for(s, a)) return -3;              // (exactly one call per launch: the stream's two queues alternate)
 #define IPK_BATCH_LAUNCH(T, V, O) hipLaunchKernelGGL((k_fused_bayer_batch<T, V, O, false>), dim3(grid), dim3(1024), 0, s, a, bp)
         if (!f.src_is_u16) { if (f.out_type == 0) IPK_BATCH_LAUNCH(float, true, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(float, true, 1); else IPK_BATCH_LAUNCH(float, true, 2); }
         else { if (f.out_type == 0) IPK_BATCH_LAUNCH(uint16_t, false, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(uint16_t, false, 1); else IPK_BATCH_LAUNCH(uint16_t, false, 2); }
@@ -2348,6 +2391,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     }
     return 0;
   }
+  if (!task_counters_for(s, a)) return -3;
   if (!f.src_is_u16) {
     if (f.out_type == 0) launch_fused_t<float, true, 0>(a, blocks, s);
     else if (f.out_type == 1) launch_fused_t<float, true, 1>(a, blocks, s);
