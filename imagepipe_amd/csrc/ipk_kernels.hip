@@ -2198,7 +2198,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPt
 
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1);
 struct FusedArgs;
-static bool task_counters_for(hipStream_t s, FusedArgs &a);
+static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk);
 
 // Staged demosaic::full for an RGGB-phase Bayer mosaic (OUT == 3 of the row-walking kernel).  Same band arguments as the
 // generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
@@ -2213,7 +2213,8 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
   a.gen_cells = gen_cells; a.gen_pw = (uint32_t)gen_pw; a.gen_ph = (uint32_t)gen_ph;
   unsigned blocks;
   fused_task_grid(a, num_cus, blocks);
-  if (!task_counters_for(s, a)) return -3;
+  std::unique_lock<std::mutex> queue_lock;
+  if (!task_counters_for(s, a, queue_lock)) return -3;
   if (gen_cells) {
     if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, true>), dim3(blocks), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, true>), dim3(blocks), dim3(1024), 0, s, a);
@@ -2275,8 +2276,10 @@ struct StreamCtr { hipStream_t stream; uint32_t slot, parity; };
 std::vector<StreamCtr> g_ctr_of;
 constexpr uint32_t kCtrSlots = 2048;
 }
-static bool task_counters_for(hipStream_t s, FusedArgs &a) {
-  std::lock_guard<std::mutex> lk(g_ctr_mu);
+// `lk` is held by the caller until its kernel launch has been issued: two host threads launching on one stream must enqueue in the order in
+// which they were handed the stream's queues.
+static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk) {
+  lk = std::unique_lock<std::mutex>(g_ctr_mu);
   if (!g_ctr_block) {
     if (hipMalloc(reinterpret_cast<void **>(&g_ctr_block), kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) return false;
     if (hipMemset(g_ctr_block, 0, kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(g_ctr_block); g_ctr_block = nullptr; return false; }
@@ -2378,7 +2381,8 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
         a.n_frames = (uint32_t)n;
         unsigned grid;
         fused_task_grid(a, f.num_cus, grid, (uint32_t)n);
-        if (!task_counters_for(s, a)) return -3;              // (exactly one call per launch: the stream's two queues alternate)
+        std::unique_lock<std::mutex> queue_lock;              // (exactly one call per launch: the stream's two queues alternate)
+        if (!task_counters_for(s, a, queue_lock)) return -3;
 #define IPK_BATCH_LAUNCH(T, V, O) hipLaunchKernelGGL((k_fused_bayer_batch<T, V, O, false>), dim3(grid), dim3(1024), 0, s, a, bp)
         if (!f.src_is_u16) { if (f.out_type == 0) IPK_BATCH_LAUNCH(float, true, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(float, true, 1); else IPK_BATCH_LAUNCH(float, true, 2); }
         else { if (f.out_type == 0) IPK_BATCH_LAUNCH(uint16_t, false, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(uint16_t, false, 1); else IPK_BATCH_LAUNCH(uint16_t, false, 2); }
@@ -2391,7 +2395,8 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     }
     return 0;
   }
-  if (!task_counters_for(s, a)) return -3;
+  std::unique_lock<std::mutex> queue_lock;
+  if (!task_counters_for(s, a, queue_lock)) return -3;
   if (!f.src_is_u16) {
     if (f.out_type == 0) launch_fused_t<float, true, 0>(a, blocks, s);
     else if (f.out_type == 1) launch_fused_t<float, true, 1>(a, blocks, s);

@@ -891,3 +891,36 @@ def test_batch_launch_falls_back_frame_by_frame(ipa, orc):
         torch.cuda.synchronize()
         for a, b in zip(outs, want):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_task_queues_under_concurrent_launches(ipa):
+    """the persistent kernel draws its tasks from a per-stream queue pair that consecutive launches use alternately: four host threads launch
+    48 MP frames (large enough for drawn tasks) on two shared streams and on the null stream at once; every output must equal the frame's
+    single-threaded result"""
+    import threading
+    import torch
+    h, w = 6000, 8000
+    plan = ipa.FusedPlan(width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
+                         cam_to_xyz_normalized=util.cam_matrix(), out_type=ipa.OUT_U8)
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    srcs = [torch.randint(0, 16384, (h * w,), device="cuda", generator=g, dtype=torch.int32).to(torch.int16) for _ in range(4)]
+    want = [plan.run(s, plan.new_output()).clone() for s in srcs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[plan.new_output() for _ in range(6)] for _ in range(4)]
+    errs = []
+
+    def worker(t):
+        try:
+            for i in range(6):
+                st = 0 if i % 3 == 2 else streams[(t + i) % 2].cuda_stream
+                plan.run(srcs[t], outs[t][i], st)
+        except Exception as e:      # noqa
+            errs.append(repr(e))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [x.start() for x in th]; [x.join() for x in th]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for t in range(4):
+        for i in range(6):
+            assert torch.equal(outs[t][i], want[t]), (t, i)
