@@ -2029,6 +2029,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
     bool fP = false, fC = false, fN = false;
+    // (tried: all four row loads of a task's start issued together, finished in turn -- 100 MP unchanged, 24 MP 0.151 -> 0.162 ms)
     if (r0 > 0) P = finish_row(issue_row(r0 - 1), fP);
     C = finish_row(issue_row(r0), fC);
     uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
