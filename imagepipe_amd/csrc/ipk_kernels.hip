@@ -2285,6 +2285,9 @@ static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std:
     if (hipMalloc(reinterpret_cast<void **>(&g_ctr_block), kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) return false;
     if (hipMemset(g_ctr_block, 0, kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(g_ctr_block); g_ctr_block = nullptr; return false; }
   }
+  // hipStreamPerThread is one handle for a different stream in every host thread: key it by the calling thread
+  static thread_local char per_thread_key;
+  if (s == hipStreamPerThread) s = reinterpret_cast<hipStream_t>(&per_thread_key);
   StreamCtr *e = nullptr;
   for (auto &c : g_ctr_of) if (c.stream == s) { e = &c; break; }
   if (!e) {
