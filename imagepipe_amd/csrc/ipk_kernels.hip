@@ -1892,7 +1892,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   const uint32_t n_tasks = BATCH ? per_frame * a.n_frames : per_frame;
   // Every wave starts with the task of its own index; further tasks are drawn with one atomic each.  Atomics on one address cost ~6 ns apiece
   // device-wide (8 XCDs): a first draw by all 4096 waves at once would add 25 us to a launch -- hence the static first round; the 4096 failing
-  // draws at the end are spread over the last tasks' run time.  (A coherent load in front of the atomic, to see an empty queue without touching
+  // draws at the end are spread over the last tasks' run time.  (Measured later with dummy atomics on the same cache line: one more per draw takes
+  // the 100 MP frame from 0.53 to 0.96 ms, four more to 1.24 -- 11-17 ns apiece once they queue up; the 12 480 draws of that frame keep the
+  // counter's line busy for a quarter of the launch.  Shorter tasks or more counters per launch are not free.)  (A coherent load in front of the atomic, to see an empty queue without touching
   // it, made every draw cost ~40 ns instead: 0.81 ms for the 100 MP frame.)
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.task_ctr_other = 0u;
   auto draw = [&]() -> uint32_t {
