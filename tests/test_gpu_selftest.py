@@ -124,3 +124,21 @@ def test_init_time_libm_check_agrees_with_the_exhaustive_one(L):
     host (glibc 2.35, the routine the device ports) they agree -- the exhaustive tests above say the same for every argument"""
     n = C.c_size_t(123)
     assert L.ipk_host_libm_matches(C.byref(n)) == 1 and n.value == 0
+
+
+def test_shutdown_and_init_again():
+    """ipk_shutdown releases everything the context holds (tables, CFA records, scratch pool, host lanes, the streams' task queues); a second
+    ipk_init in the same process starts clean and computes the same frame.  Runs in its own process: the session fixture keeps its context."""
+    import subprocess, sys, os
+    code = ("import numpy as np, torch, imagepipe_amd as ipa, util; from imagepipe_amd import _lib\n"
+            "def frame():\n"
+            "    raw = util.noise_u16(util.SEED + 9, 6000, 8000)\n"
+            "    plan = ipa.FusedPlan(width=8000, height=6000, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa='RGGB', wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix(), out_type=ipa.OUT_U8)\n"
+            "    o = plan.run(ipa.upload_u16(raw), plan.new_output()); torch.cuda.synchronize(); return o.cpu()\n"
+            "ipa.init(0); a = frame(); a2 = frame()\n"
+            "_lib.load().ipk_shutdown(); _lib.check(_lib.load().ipk_init(0), 'ipk_init')\n"
+            "b = frame(); assert torch.equal(a, b) and torch.equal(a, a2); print('REINIT_OK')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=os.path.join(root, "tests") + os.pathsep + root))
+    assert r.returncode == 0 and "REINIT_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
