@@ -924,3 +924,30 @@ def test_task_queues_under_concurrent_launches(ipa):
     for t in range(4):
         for i in range(6):
             assert torch.equal(outs[t][i], want[t]), (t, i)
+
+
+@pytest.mark.parametrize("cfa,shape", [("GBRG", (100003, 300)), (XT, (90001, 517)), ("RGGB", (70000, 200))])
+def test_drawn_tasks_on_tall_narrow_frames(ipa, orc, cfa, shape):
+    """frames whose waves get 40+ rows each run with tasks DRAWN from the stream's queue (one or three strips, thousands of 32-row segments;
+    the 200-pixel-wide one takes the predicated-tail variant): every sample against the oracle"""
+    h, w = shape
+    raw = util.noise_u16(util.SEED + h, h, w)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa)), "drawn tasks %s %dx%d" % (cfa[:4], w, h))
+
+
+def test_drawn_tasks_in_a_batch_launch(ipa):
+    """64 frames of 2304 x 300 in one persistent launch: 64 x 9 strips x 9 segments queue up behind the first round; each frame against its own launch"""
+    import torch
+    h, w, n = 300, 2304, 64
+    plan = ipa.FusedPlan(width=w, height=h, is_float=True, black0=util.BLACK, white0=util.WHITE, cfa="BGGR", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    srcs = [torch.randint(0, 16384, (h * w,), device="cuda", generator=g, dtype=torch.int32).to(torch.float32) for _ in range(n)]
+    want = [plan.run(s, plan.new_output()).clone() for s in srcs]
+    outs = [torch.zeros_like(x) for x in want]
+    ipa.FusedBatchPlan(plan, srcs, outs).run()
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(outs[i].view(torch.int32), want[i].view(torch.int32)), i
