@@ -1897,7 +1897,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // counter's line busy for a quarter of the launch.  Shorter tasks or more counters per launch are not free.)  (A coherent load in front of the atomic, to see an empty queue without touching
   // it, made every draw cost ~40 ns instead: 0.81 ms for the 100 MP frame.)
   // (Tried: two levels -- chunks of 16 tasks per atomic, dealt to a block's waves through LDS tickets: 16x fewer atomics, but the tasks a block is
-  // sitting on cannot go to another block's idle waves: 100 MP noise 0.526 -> 0.629 ms, photo 0.414 -> 0.463.)
+  // sitting on cannot go to another block's idle waves: 100 MP noise 0.526 -> 0.629 ms, photo 0.414 -> 0.463.  And eight queues, one per XCD on its
+  // own cache line, each holding every eighth task: 0.535 -> 0.554, 64 x 24 MP 7.83 -> 8.36 ms -- one queue for the whole device balances better
+  // than eight uncontended ones.)
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.task_ctr_other = 0u;
   auto draw = [&]() -> uint32_t {
     uint32_t t = 0xFFFFFFFFu;
