@@ -1172,8 +1172,9 @@ void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hip
 //   [+ output8bit/output16bit], one pass: 4 (or 2) bytes in, 12 (or 3/6) bytes out per pixel.
 //
 // Structure (MI355X-first, not a restatement of the reference's row-parallel loops):
-//   * one 1024-thread workgroup resident per CU (4 waves per SIMD: measured optimum); both 13-bit tables live in LDS as
-//     plain floats (64 KB) next to one staging buffer per wave and, in generic-CFA mode, the pattern-cell records;
+//   * one 1024-thread workgroup per CU (4 waves per SIMD: measured optimum), PERSISTENT: it stays for the whole launch; both 13-bit tables
+//     live in LDS (the Lab table as {v, dv} pairs where there is room) next to one staging buffer per wave and, in generic-CFA mode, the
+//     pattern-cell records;
 //   * no barriers after the table load: every WAVE owns a strip of 256 columns (4 consecutive pixels per lane => 16-byte
 //     loads contiguous across the wave) and walks down a segment of rows, keeping a 3-row window of normalised samples
 //     in registers; horizontal neighbours come from the adjacent lane by DPP wave shifts, the two strip-edge columns
@@ -1181,8 +1182,9 @@ void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hip
 //     lane-contiguous 16-byte stores;
 //   * each mosaic sample is therefore read from HBM once (plus 3 halo rows per segment and 2 halo columns per strip) and
 //     normalised once;
-//   * tasks (strip x row segment of >= 24 rows) outnumber the resident waves 4:1 so that the block dispatcher evens out
-//     frames whose saturated regions make some tasks longer;
+//   * tasks = strip x row segment of ~32 rows; a wave takes the task of its own index first and DRAWS further ones from the launch stream's
+//     queue (one atomic each), which evens out frames whose saturated regions make some tasks longer and leaves no wave waiting for the rest
+//     of its block (fused_bayer_body, fused_task_grid);
 //   * parameters that are the same for practically every raw file are template flags (CMN, PXG), because a
 //     runtime-uniform flag is a scalar branch per row.
 // ------------------------------------------------------------------------------------------
@@ -2507,7 +2509,7 @@ int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
 int launch_tolab_fast(const FusedLaunch &f, size_t npix, hipStream_t s) {
   FusedArgs a = chain_args(f);
   const size_t chunks = (npix + 255) / 256;
-  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256) * 2u;                 // two 1024-thread blocks per CU fit (34 KB of LDS each)
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256) * 2u;                 // two 1024-thread blocks per CU fit (66 KB of LDS each)
   const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
   hipLaunchKernelGGL(k_pointwise_chain<true>, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
   return 0;
