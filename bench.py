@@ -2,7 +2,9 @@
 """bench.py -- megapixels/s of the full raw->sRGB pipe on a 100 MP f32 Bayer frame (BASELINE.json's metric).
 
   python bench.py --gpus N --steps K --warmup W [--config c3|c2|c4|c5|c5b] [--batch B --width X --height Y]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1: one rank per GPU.  Either the caller starts the ranks (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+  --master-addr 127.0.0.1 ... bench.py --gpus N ...) or, invoked plainly, bench.py starts them itself the same way (relaunch_as_ranks).
+  A line whose n_gpus differs from --gpus is never printed: fewer visible GPUs than N, or a WORLD_SIZE that is not N, is a non-zero exit.
 
 One step = one pass of the hot path (Pipeline::run: gofloat + demosaic + tolab + basecurve + fromlab + gamma) over one batch of
 synthetic frames, input and output resident in HBM.  Frames are independent (src/pipeline.rs:246-249), so frame i of a batch goes to
@@ -101,6 +103,25 @@ def glibc_version():
         return None
 
 
+def relaunch_as_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher's environment: start the N ranks under torch.distributed.run, one per GPU,
+    and hand their exit code on.  Refuses (exit 2) when the node shows fewer than N GPUs -- IPK_BENCH_SHARE_GPU=1 (development: all ranks
+    on GPU 0 over gloo, the library's host transport) lifts that."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("IPK_BENCH_SHARE_GPU") != "1":
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); refusing to print a line for fewer ranks than asked\n" % (args.gpus, have))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, cwd=os.getcwd()))
+
+
 class Ctx:
     """process-wide plumbing: torch, the process group, barriers and max-over-ranks reductions"""
 
@@ -110,15 +131,22 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus and self.world > 1:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        if self.world != args.gpus:                     # never a line whose n_gpus is not what was asked for
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, self.world))
+            raise SystemExit(2)
         self.dist = None
+        self.share = False
+        self._comm = None
         if self.world > 1:
             import torch.distributed as dist
             # IPK_BENCH_SHARE_GPU=1 (development only): all ranks on one GPU over gloo, to exercise the N > 1 control flow on a 1-GPU box
             share = os.environ.get("IPK_BENCH_SHARE_GPU") == "1"
+            self.share = share
             if share:
                 self.local_rank = 0
+            elif torch.cuda.device_count() < self.world:
+                sys.stderr.write("bench.py: %d ranks but %d visible GPU(s)\n" % (self.world, torch.cuda.device_count()))
+                raise SystemExit(2)
             torch.cuda.set_device(self.local_rank)
             if share:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
@@ -126,6 +154,20 @@ class Ctx:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
         self.red_dev = "cpu" if (self.dist is not None and self.dist.get_backend() == "gloo") else "cuda"
+
+    def comm(self):
+        """the LIBRARY's communicator over the ranks (ipk_comm: RCCL when the ranks have a GPU each, its host transport when they share one)"""
+        if self._comm is None:
+            from imagepipe_amd import parallel as par
+            self._comm = par.Comm()
+        return self._comm
+
+    def comm_info(self):
+        """what the library's transport saw: (rank, ranks, transport) from ipk_comm_info"""
+        from imagepipe_amd import _lib
+        r, n, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().ipk_comm_info(self.comm().handle, ctypes.byref(r), ctypes.byref(n), ctypes.byref(t)), "ipk_comm_info")
+        return {"ranks": n.value, "transport": "rccl" if t.value == 0 else "host"}
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -285,6 +327,8 @@ def main():
     args = parse()
     if args.band_child:
         return band_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return relaunch_as_ranks(args)
     ctx = Ctx(args)
     torch = ctx.torch
     import imagepipe_amd as ipa

@@ -301,6 +301,8 @@ int ipk_init(int device) {
     HIPCHK(hipMalloc(&g.lut_plain[t], ipk::kLutLen * sizeof(float)));
     HIPCHK(hipMemcpy(g.lut_plain[t], g.lut_host[t].data(), ipk::kLutLen * sizeof(float), hipMemcpyHostToDevice));
   }
+  // the row-walking kernels' task-queue heads, one block for all streams (nothing is allocated at launch time, so launches can be captured)
+  if (!ipk::init_task_counters()) return fail(IPK_ERR_HIP, "task queue allocation failed");
   g.device = device;
   g.ready = true;
   // The device's cbrtf reproduces glibc 2.35's routine; the lookup tables above and a reference built on THIS host use this host's libm.
@@ -490,7 +492,7 @@ int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, si
   else if (dev.gen_cells)                // any other three-colour filter (X-Trans ...): same kernel, generic-CFA mode
     lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, 0, 0, dev.gen_cells, dev.gen_pw, dev.gen_ph, dst4, g.num_cus, S(stream));
   else ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
-  if (lrc) return fail(IPK_ERR_NOMEM, "no task queue for this stream");
+  if (lrc) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued)");
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
@@ -854,7 +856,7 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
   f.num_cus = g.num_cus;
   { const int lrc = ipk::launch_fused_bayer(f, S(stream));
-    if (lrc == -3) return fail(IPK_ERR_NOMEM, "no task queue for this stream");
+    if (lrc == -4) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued; the stream's task queue is untouched)");
     if (lrc != 0) return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for these parameters"); }
   HIPCHK(hipGetLastError());
   return IPK_OK;

@@ -94,7 +94,37 @@ __device__ __forceinline__ float cbrtf_glibc_sel(float x) {
 // RESULT with the host libm's cbrtf for EVERY f32 in (1,2) is checked on the device (tests/test_gpu_selftest.py), which is
 // a proof since the domain is enumerable.  (Measured on the way: dropping the Newton step fails for 627 096 inputs; the
 // variants with the residual correction, with two Newton steps, or with the literal polynomial all pass as well.)
+// IPK_OPT_CBRT_ASM: the same steps with (a) the argument's halving folded into the constants -- xm = x/2 is exact, so the polynomial in dx = 2 xm has
+// its coefficients scaled by powers of two, 2 xm is dx itself and the denominator is taken twice (2 den = 4 t2 + dx; the reciprocal, its Newton
+// step and the final products scale by exact powers of two, the last constant becomes 2^(1/3)/... see below) -- one instruction fewer; and (b) the
+// polynomial's two fmas as explicit v_fma_f64: hipcc turns `fma(a, x, CONST)` into a register copy of CONST plus v_fmac_f64 (two-address form),
+// two extra v_mov_b64 per evaluation.  Proven like the form above (tests/test_gpu_selftest.py, every f32 in (1,2)).
+#ifndef IPK_OPT_CBRT_ASM
+#define IPK_OPT_CBRT_ASM 1
+#endif
+__device__ __forceinline__ double fma_f64_vvv(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double fma_f64_svv(double a, double b, double c) {   // a wave-uniform (the one scalar operand VOP3 may read)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ float cbrtf_glibc_1to2(float x) {
+#if IPK_OPT_CBRT_ASM
+  // with dx = (double)x = 2 dxm:  c2 dxm^2 = (c2/4) dx^2, c1 dxm = (c1/2) dx  (exact scalings)
+  const double dx = (double)x;
+  const float u = (float)fma_f64_vvv(fma_f64_svv(-0.191502161678719066 * 0.25, dx, 0.697570460207922770 * 0.5), dx, 0.492659620528969547);
+  const float t2 = u * u * u;
+  const double du = (double)u, dt2 = (double)t2;
+  const double num = du * (dt2 + dx);                      // dt2 + 2 dxm: the exact sum, as the fma form gives it
+  const double den2 = __builtin_fma(4.0, dt2, dx);          // 2 (2 dt2 + dxm), exactly twice the proven form's denominator
+  double r = __builtin_amdgcn_rcp(den2);                    // = r/2 exactly (the reciprocal unit works on the mantissa)
+  r = __builtin_fma(__builtin_fma(-den2, r, 1.0), r, r);
+  return (float)((num * r) * (2.0 * 1.2599210498948731647672));
+#else
   const float xm = x * 0.5f;                             // exact
   const double dxm = (double)xm;
   const float u = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, dxm, 0.697570460207922770), dxm, 0.492659620528969547);
@@ -105,6 +135,7 @@ __device__ __forceinline__ float cbrtf_glibc_1to2(float x) {
   double r = __builtin_amdgcn_rcp(den);
   r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
   return (float)((num * r) * 1.2599210498948731647672);
+#endif
 }
 
 // XYZ_LAB_TRANSFORM.lookup (src/color_conversions.rs:102-114 with the closure of :120-124)

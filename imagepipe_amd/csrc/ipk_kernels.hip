@@ -52,9 +52,28 @@ using namespace ipkd;
 #ifndef IPK_OPT_GAMPAIRS
 #define IPK_OPT_GAMPAIRS 1
 #endif
+//   IPK_OPT_PRIME4     a task's first four row loads issued together (measured: no gain, see fused_bayer_body)
+#ifndef IPK_OPT_PRIME4
+#define IPK_OPT_PRIME4 0
+#endif
+// Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
+//   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
+#ifndef IPK_OPT_SLOTMASK
+#define IPK_OPT_SLOTMASK 1
+#endif
+//   (kept unconditionally: the task position is wave-uniform for the compiler -- readfirstlane -- so the row counter, the row parity and the strip
+//    parity live in scalar registers and the demosaic's role dispatch is scalar branches instead of exec-mask regions: noise 0.529 -> 0.521 ms)
 
 namespace ipk {
 
+#ifdef IPK_DEV_PROBE   // development only (tools/wave_timeline.py): per-wave time stamps of the row-walking kernels, 8 x u64 per wave
+__device__ unsigned long long g_probe[4096 * 8];
+}  // namespace ipk
+extern "C" __attribute__((visibility("default"))) int ipk_dev_probe_read(unsigned long long *out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipk::g_probe), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+namespace ipk {
+#endif
 #if IPK_OPT_LABPAIRS
 typedef LutPair LabTab;
 #else
@@ -1188,6 +1207,7 @@ void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hip
 //   * parameters that are the same for practically every raw file are template flags (CMN, PXG), because a
 //     runtime-uniform flag is a scalar branch per row.
 // ------------------------------------------------------------------------------------------
+constexpr int kQueueStride = 32;    // 32-bit words between a stream's queue counter and its arrival counter: one 128-byte line each
 struct FusedArgs {
   const void *src;            // element (row 0 of the slab, sensor column x) -- see row_off
   void *dst;                  // first output row (image row out_r0)
@@ -1196,8 +1216,9 @@ struct FusedArgs {
   uint32_t row_off;           // image row held by slab row 0
   uint32_t out_r0, out_r1;    // output rows [out_r0, out_r1)
   uint32_t n_frames;          // batch launches (k_fused_bayer_batch): frames behind the BatchPtrs argument
-  uint32_t *task_ctr;         // this launch's task queue: tasks n_waves + *task_ctr, ... are still to be drawn (zero when the launch starts)
-  uint32_t *task_ctr_other;   // the stream's other queue, which this launch zeroes for the stream's next launch (task_counters_for)
+  uint32_t *task_ctr;         // the launch stream's task queue: tasks n_waves + *task_ctr, ... are still to be drawn; kQueueStride words behind it the
+                              // arrival counter of the leaving waves.  Both zero when a launch starts and when it ends.  Null = no queue: one task per
+                              // wave (task_counters_for, fused_task_grid)
   float min0, range0;         // blacklevels[0], whitelevels[0]-blacklevels[0]
   float inv_range0;           // RN(1/range0) for the 4-instruction division
   int exact_norm;             // 1: normalise with true divisions (host could not validate the fast form for range0)
@@ -1552,6 +1573,22 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // progressive waits let the first lerps start while the last reads are still in flight, and a wait that is already satisfied costs little.)
   // (Round 2, again without gain: ONE wave-level test -- the OR of the twelve compare masks -- in front of the per-slot tests: noise 0.591 ->
   // 0.621 ms, photo 0.473 -> 0.480, smooth 0.572 -> 0.595.)
+#if IPK_OPT_SLOTMASK
+  // One slot = one table-stage value of all 64 lanes.  Per slot that stays in the table this costs a compare and a branch; a slot with lanes above
+  // 1 adds one compare, the cube root and one select, and the negative / NaN lanes (their own compare: as a bit pattern they are exactly the
+  // values above +inf's) the linear branch.  (Round 2 derived the third mask from the first two -- hipcc moves such a mask through a VGPR to
+  // branch on it -- and copied each mask into vcc: 36 instructions per entered slot, 27 now; the uniform noise frame enters 8 of 12 per row.)
+  #pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    if (__builtin_amdgcn_ballot_w64(__float_as_uint(v[k]) > 0x3F800000u) != 0) {   // some lane has v > 1, v < 0, -0 or NaN
+      const bool hi = v[k] > 1.0f;
+      if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
+      const bool lo = __float_as_uint(v[k]) > 0x7F800000u;            // negative (or -0), or NaN: out of the table and not above 1
+      if (__builtin_amdgcn_ballot_w64(lo) != 0)
+      { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
+    }
+  }
+#else
   #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
@@ -1567,6 +1604,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
     }
   }
+#endif
 #endif
   f2 rr[2], gg[2], bb[2];
   #pragma unroll
@@ -1887,35 +1925,64 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // and oversubscribed the CUs two blocks deep: a CU then waited for the slowest of a block's sixteen waves before it could take the next block (the
   // LDS holds one), and every block staged the lookup tables again -- 13 % of the 100 MP frame's time (0.587 -> 0.510 ms).  A BATCH launch (the frames
   // of ipk_raw_to_srgb_batch, same shape and parameters, pointers in the second kernel argument) queues the tasks of all its frames the same way.
-  // The counter is the launch stream's own (launches of one stream never overlap); a stream has two, used alternately, and a launch zeroes the one
-  // its successor will use.
+  // The counter is the launch STREAM's (launches of one stream never overlap) and every launch leaves it zero: the last wave to leave -- an arrival
+  // counter next to it -- resets both.  A launch is therefore self-contained: a launch that failed to enqueue, a captured launch replayed from a
+  // graph, a stream used by two host threads all find a zeroed queue (round 2 alternated two counters per stream and relied on every launch running
+  // exactly once, in issue order).  a.task_ctr == null (no queue slot could be had for this stream): one task per wave, nothing drawn.
   const uint32_t per_frame = a.n_strips * a.n_segs;
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const uint32_t n_tasks = BATCH ? per_frame * a.n_frames : per_frame;
   // Every wave starts with the task of its own index; further tasks are drawn with one atomic each.  Atomics on one address cost ~6 ns apiece
   // device-wide (8 XCDs): a first draw by all 4096 waves at once would add 25 us to a launch -- hence the static first round; the 4096 failing
-  // draws at the end are spread over the last tasks' run time.  (Measured later with dummy atomics on the same cache line: one more per draw takes
+  // draws at the end are spread over the last tasks' run time.  (Measured with dummy atomics on the same cache line: one more per draw takes
   // the 100 MP frame from 0.53 to 0.96 ms, four more to 1.24 -- 11-17 ns apiece once they queue up; the 12 480 draws of that frame keep the
-  // counter's line busy for a quarter of the launch.  Shorter tasks or more counters per launch are not free.)  (A coherent load in front of the atomic, to see an empty queue without touching
+  // counter's line busy for a quarter of the launch.)  (A coherent load in front of the atomic, to see an empty queue without touching
   // it, made every draw cost ~40 ns instead: 0.81 ms for the 100 MP frame.)
-  // (Tried: two levels -- chunks of 16 tasks per atomic, dealt to a block's waves through LDS tickets: 16x fewer atomics, but the tasks a block is
-  // sitting on cannot go to another block's idle waves: 100 MP noise 0.526 -> 0.629 ms, photo 0.414 -> 0.463.  And eight queues, one per XCD on its
-  // own cache line, each holding every eighth task: 0.535 -> 0.554, 64 x 24 MP 7.83 -> 8.36 ms -- one queue for the whole device balances better
-  // than eight uncontended ones.)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.task_ctr_other = 0u;
+  // (Tried, round 2: two levels -- chunks of 16 tasks per atomic, dealt to a block's waves through LDS tickets: 16x fewer atomics, but the tasks a block
+  // is sitting on cannot go to another block's idle waves: 100 MP noise 0.526 -> 0.629 ms, photo 0.414 -> 0.463.  And eight queues, one per XCD on its
+  // own cache line, each holding every eighth task: 0.535 -> 0.554, 64 x 24 MP 7.83 -> 8.36 ms.)
+  // (Round 3, tools/wave_timeline.py -- per-wave time stamps: the waves of a 100 MP launch are resident for 87 % (noise) / 82 % (photo-like) of its
+  // span; the sixteen waves of a CU share its VALU unevenly -- the same 32 rows take one wave 113 us and another 347 -- and the last tenth of the
+  // launch runs on 15 % / 4 % of the waves; a task costs 1.3 us of draw and 4.5 us of priming.  What that tail is worth was then measured by
+  // removing it: bands that get shorter towards the end of the frame (32 -> 16 -> 8 -> 4 rows, a wave's even share of what is left), eight queue
+  // heads with stealing and an LDS mark for heads found dry, the draw issued one row (or one task) ahead, the first four row loads of a task in
+  // flight together.  Residency rose to 94 %, and nothing got faster: 0.515 -> 0.522-0.530 ms on noise, 0.412 -> 0.419-0.430 photo-like, 24 MP
+  // 0.140 -> 0.150, 64 x 24 MP 7.5 -> 7.8 ms (same box, tools/gss_sweep.sh, profiles/r03_band_sweep.txt).  The kernel is bound by VALU issue: the
+  // waves that remain in the tail simply run faster, so the tail wastes about 5 %, and twice the tasks cost that much in draws and priming.
+  // Units of 4 rows numbered strip after strip (chunks of vertically adjacent units) were worse still: a block's sixteen waves then read sixteen 1 KB
+  // pieces 1.4 MB apart instead of 16 KB of one row, rows ran 6-10 % slower.  Kept from all of it: the self-resetting queue.)
+#ifdef IPK_DEV_PROBE
+  unsigned long long pb_t0 = __builtin_readcyclecounter(), pb_draw = 0, pb_tasks = 0, pb_atomics = 0, pb_rows = 0, pb_prime = 0;
+  const unsigned long long pb_w0 = wall_clock64();
+#endif
   auto draw = [&]() -> uint32_t {
     uint32_t t = 0xFFFFFFFFu;
+#ifdef IPK_DEV_PROBE
+    const unsigned long long d0 = __builtin_readcyclecounter();
+    pb_atomics += 1;
+#endif
     if ((threadIdx.x & 63u) == 0) {
       t = n_waves + atomicAdd(a.task_ctr, 1u);
     }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+#ifdef IPK_DEV_PROBE
+    pb_draw += __builtin_readcyclecounter() - d0;
+#endif
+    return t;
   };
-  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gt < n_tasks; gt = n_tasks > n_waves ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
+  const bool queued = a.task_ctr != nullptr && n_tasks > n_waves;
+  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gt < n_tasks; gt = queued ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
     const uint32_t frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
-    const uint32_t task = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt - frame * per_frame)) : gt;
+    // the task index is wave-uniform, and the compiler is told so: row counter, row parity and strip parity then live in scalar registers and the
+    // demosaic's role dispatch is scalar branches instead of exec-mask regions (noise 0.529 -> 0.521 ms)
+    const uint32_t task = (uint32_t)__builtin_amdgcn_readfirstlane((int)(BATCH ? gt - frame * per_frame : gt));
+    const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
+    // rows: this segment's output rows [r0, r1)
+    const uint32_t nrows = a.out_r1 - a.out_r0;
+    const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
+    const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
     const void *const frame_src = BATCH ? bp->src[frame] : a.src;
     void *const frame_dst = BATCH ? bp->dst[frame] : a.dst;
-    const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
 
     // columns: this strip's lane-columns [lc0, lc0+nl), 4 pixels each.  FULL: every strip is 64 lanes wide and the
     // last one is shifted left to stay inside the frame; the columns it shares with its neighbour are computed by
@@ -1939,11 +2006,11 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // for all 65 536 values
     // (a compile-time false for the Bayer variants, so that they carry no trace of it)
     const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
-    // rows: this segment's output rows [r0, r1)
-    const uint32_t nrows = a.out_r1 - a.out_r0;
-    const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
-    const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
     if (r0 >= r1) continue;
+#ifdef IPK_DEV_PROBE
+    pb_tasks += 1; pb_rows += r1 - r0;
+    const unsigned long long pb_p0 = __builtin_readcyclecounter();
+#endif
 
     // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl); every other lane
     // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
@@ -2037,9 +2104,20 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
     bool fP = false, fC = false, fN = false;
-    // (tried: all four row loads of a task's start issued together, finished in turn -- 100 MP unchanged, 24 MP 0.151 -> 0.162 ms)
+    // A chunk starts with the loads of its first four rows in flight together and awaits them in turn: one memory round trip instead of three
+    // (4.7 us per chunk, tools/wave_timeline.py).  The row above the frame's first row does not exist: row 0 is loaded in its place, for a
+    // window every pixel of which takes the edge path.
+#if IPK_OPT_PRIME4
+    RawRowT raw_next;
+    {
+      const RawRowT rp = issue_row(r0 > 0 ? r0 - 1 : 0u), rc = issue_row(r0), rn = issue_row(min(r0 + 1, Hm1));
+      raw_next = issue_row(min(r0 + 2, Hm1));
+      P = finish_row(rp, fP); C = finish_row(rc, fC); N = finish_row(rn, fN);
+    }
+#else
     if (r0 > 0) P = finish_row(issue_row(r0 - 1), fP);
     C = finish_row(issue_row(r0), fC);
+#endif
     uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
     // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
     // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
@@ -2050,8 +2128,13 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // out of order, so a wait for loads with younger stores in flight becomes vmcnt(0) and exposes the full store latency
     // every iteration (it was 24 % of the wave's time); here the only stores older than the awaited loads are a whole
     // iteration old.
+#if !IPK_OPT_PRIME4
     N = finish_row(issue_row(min(r0 + 1, Hm1)), fN);
     RawRowT raw_next = issue_row(min(r0 + 2, Hm1));
+#endif
+#ifdef IPK_DEV_PROBE
+    pb_prime += __builtin_readcyclecounter() - pb_p0;
+#endif
     // (the ~20 register moves that rotate the row window per iteration would vanish in a 3x unrolled loop; the compiler refuses
     // `#pragma unroll 3` here -- wave-level ballots and barriers in the body -- and a hand-unrolled body triples the code for ~1 %)
     for (uint32_t r = r0; r < r1; ++r) {
@@ -2198,6 +2281,24 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
     }
   }
+  // the last wave to leave zeroes the queue for the stream's next launch (every other wave's draws have returned before it arrived here)
+  if (queued && (threadIdx.x & 63u) == 0) {
+    uint32_t *const arrived = a.task_ctr + kQueueStride;
+    if (atomicAdd(arrived, 1u) == n_waves - 1u) {
+      __hip_atomic_store(a.task_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#ifdef IPK_DEV_PROBE
+  if ((threadIdx.x & 63u) == 0) {
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w < 4096u) {
+      unsigned long long *q = g_probe + 8 * w;
+      q[0] = pb_t0; q[1] = __builtin_readcyclecounter(); q[2] = pb_draw | (pb_atomics << 48); q[3] = pb_tasks; q[4] = pb_prime; q[5] = pb_rows;
+      q[6] = pb_w0; q[7] = wall_clock64();
+    }
+  }
+#endif
 }
 template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer_body<SrcT, VEC, OUT, FULL, GEN, PXG, CMN, ROT, false>(a, nullptr); }
@@ -2206,8 +2307,9 @@ template <typename SrcT, bool VEC, int OUT, bool PXG>
 __global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, true, false, true>(a, &bp); }
 
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1);
-struct FusedArgs;
 static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk);
+// after hipLaunchKernelGGL: an enqueue error becomes the launcher's return value (-4); nothing is left to undo, the heads were not touched
+static int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -4; }
 
 // Staged demosaic::full for an RGGB-phase Bayer mosaic (OUT == 3 of the row-walking kernel).  Same band arguments as the
 // generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
@@ -2221,10 +2323,10 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
   a.xoff = xoff; a.yoff = yoff; a.range0 = 1.0f; a.inv_range0 = 1.0f;
   a.gen_cells = gen_cells; a.gen_pw = (uint32_t)gen_pw; a.gen_ph = (uint32_t)gen_ph;
   unsigned blocks;
+  std::unique_lock<std::mutex> queue_lock;
+  (void)task_counters_for(s, a, queue_lock);
   // the demosaic-only Bayer variant is memory-bound and small (58 VGPRs, 67 KB of LDS): two persistent blocks per CU, 8 waves per SIMD in flight
   fused_task_grid(a, gen_cells ? num_cus : 2 * (num_cus > 0 ? num_cus : 256), blocks);
-  std::unique_lock<std::mutex> queue_lock;
-  if (!task_counters_for(s, a, queue_lock)) return -3;
   if (gen_cells) {
     if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, true>), dim3(blocks), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, true>), dim3(blocks), dim3(1024), 0, s, a);
@@ -2232,7 +2334,7 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
     if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, false>), dim3(blocks), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<float, true, 3, false, false>), dim3(blocks), dim3(1024), 0, s, a);
   }
-  return 0;
+  return launch_status();
 }
 
 template <typename SrcT, bool VEC, int OUT>
@@ -2275,38 +2377,57 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
   else hipLaunchKernelGGL((k_fused_bayer<SrcT, VEC, OUT, false, false>), dim3(grid), dim3(tpb), 0, s, a);
 }
 
-// task grid: strips of <= 64 lane-columns, row segments so that tasks ~= waves of the grid
-// The task queues of a stream: two counters used by its launches alternately -- a launch draws from one and zeroes the other for its successor
-// (launches on one stream run in order, so neither is ever shared).  Every stream handle gets its own pair, never freed individually (8 bytes per
-// stream the process has ever launched on, from one 16 KB block); release_task_counters() returns the block at ipk_shutdown.
+// The task queue of a stream (fused_bayer_body): a counter and an arrival counter, zero between launches -- a launch leaves them as it found
+// them, so nothing is reset from the host and a launch that never ran (an error at enqueue, a graph that is never replayed) costs nothing.  Every
+// stream handle gets its own slot from one device block allocated at ipk_init (nothing is allocated at launch time, which stream capture forbids);
+// hipStreamPerThread is a different stream in every host thread and is keyed by the calling thread.  When the table is full the least recently used
+// slot whose stream has drained is reused; when there is none the launch runs the static schedule (task_ctr = null) -- the queue is an optimisation
+// and never fails a call.
 namespace {
 std::mutex g_ctr_mu;
 uint32_t *g_ctr_block = nullptr;
-struct StreamCtr { hipStream_t stream; uint32_t slot, parity; };
+struct StreamCtr { hipStream_t key; hipStream_t stream; uint32_t slot; uint64_t last_use; };
 std::vector<StreamCtr> g_ctr_of;
-constexpr uint32_t kCtrSlots = 2048;
+uint64_t g_ctr_clock = 0;
+constexpr uint32_t kCtrSlots = 1024;
+constexpr uint32_t kCtrSlotWords = 2 * kQueueStride;
 }
-// `lk` is held by the caller until its kernel launch has been issued: two host threads launching on one stream must enqueue in the order in
-// which they were handed the stream's queues.
+bool init_task_counters() {
+  std::lock_guard<std::mutex> lk(g_ctr_mu);
+  if (g_ctr_block) return true;
+  if (hipMalloc(reinterpret_cast<void **>(&g_ctr_block), (size_t)kCtrSlots * kCtrSlotWords * sizeof(uint32_t)) != hipSuccess) { g_ctr_block = nullptr; return false; }
+  if (hipMemset(g_ctr_block, 0, (size_t)kCtrSlots * kCtrSlotWords * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(g_ctr_block); g_ctr_block = nullptr; return false; }
+  return true;
+}
+// `lk` is held by the caller until its kernel launch has been issued: two host threads launching on one stream must enqueue one after the other.
+// Returns false (a.task_ctr = null: static schedule) when no slot can be had.
 static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk) {
+  a.task_ctr = nullptr;
   lk = std::unique_lock<std::mutex>(g_ctr_mu);
-  if (!g_ctr_block) {
-    if (hipMalloc(reinterpret_cast<void **>(&g_ctr_block), kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) return false;
-    if (hipMemset(g_ctr_block, 0, kCtrSlots * 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(g_ctr_block); g_ctr_block = nullptr; return false; }
-  }
-  // hipStreamPerThread is one handle for a different stream in every host thread: key it by the calling thread
+  if (!g_ctr_block) return false;
   static thread_local char per_thread_key;
-  if (s == hipStreamPerThread) s = reinterpret_cast<hipStream_t>(&per_thread_key);
+  const hipStream_t key = (s == hipStreamPerThread) ? reinterpret_cast<hipStream_t>(&per_thread_key) : s;
   StreamCtr *e = nullptr;
-  for (auto &c : g_ctr_of) if (c.stream == s) { e = &c; break; }
+  for (auto &c : g_ctr_of) if (c.key == key) { e = &c; break; }
   if (!e) {
-    if (g_ctr_of.size() >= kCtrSlots) return false;           // a process with more than 2048 live streams: the caller reports it
-    g_ctr_of.push_back({s, (uint32_t)g_ctr_of.size(), 0u});
-    e = &g_ctr_of.back();
+    if (g_ctr_of.size() < kCtrSlots) {
+      g_ctr_of.push_back({key, s, (uint32_t)g_ctr_of.size(), 0});
+      e = &g_ctr_of.back();
+    } else {
+      // reuse the least recently used slot whose stream has nothing in flight (a destroyed stream's handle answers with an error: also free)
+      StreamCtr *lru = nullptr;
+      for (auto &c : g_ctr_of) if (!lru || c.last_use < lru->last_use) lru = &c;
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (!lru || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+      const hipError_t q = (lru->key == lru->stream) ? hipStreamQuery(lru->stream) : hipErrorNotReady;   // per-thread streams: not queryable from here
+      (void)hipGetLastError();
+      if (q == hipErrorNotReady) return false;
+      lru->key = key; lru->stream = s;
+      e = lru;
+    }
   }
-  a.task_ctr = g_ctr_block + 2 * e->slot + e->parity;
-  a.task_ctr_other = g_ctr_block + 2 * e->slot + (e->parity ^ 1u);
-  e->parity ^= 1u;
+  e->last_use = ++g_ctr_clock;
+  a.task_ctr = g_ctr_block + (size_t)e->slot * kCtrSlotWords;
   return true;
 }
 void release_task_counters() {
@@ -2321,7 +2442,7 @@ void release_task_counters() {
 //     100 MP frame (tools/task_rows_sweep.sh, one box): 24 / 32 / 48 rows 0.531 / 0.535 / 0.584 ms noise, 0.417 / 0.419 / 0.439 photo; 12 / 16 / 20 rows
 //     within 2 % of 32 on another; a tall first task per wave followed by short ones (50-80 % of the rows, then 8-24-row tasks) 0.531-0.551: no better
 //     than uniform; ONE task per wave (nothing to draw) 0.576 / 0.497; round 2's launch (two blocks per CU in turn, one task per wave) 0.587 / 0.472;
-//   smaller frames: one task per wave, at least 8 rows (24 MP: 23 rows each, 0.148 ms either way).
+//   smaller frames, or no queue for this stream (task_ctr == null): one task per wave, at least 8 rows (24 MP: 23 rows each, 0.148 ms either way).
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
   const uint32_t waves_per_block = 16;
 #ifdef IPK_DEV_KNOBS
@@ -2337,7 +2458,7 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_
   a.lc_base = w4 / a.n_strips; a.lc_rem = w4 % a.n_strips;   // balanced strips (generic kernel); FULL uses 64-lane strips
   const uint32_t nrows = a.out_r1 - a.out_r0;
   const uint64_t share = (uint64_t)nrows * a.n_strips * frames / total_waves;   // rows of one strip a wave gets from an even split
-  if (share >= share_min) a.n_segs = std::max(1u, nrows / uni);
+  if (share >= share_min && a.task_ctr != nullptr) a.n_segs = std::max(1u, nrows / uni);
   else a.n_segs = std::min(nrows, std::min(std::max(1u, (uint32_t)(total_waves / ((uint64_t)a.n_strips * frames))), std::max(1u, nrows / 8u)));
   const uint64_t tasks = (uint64_t)a.n_strips * a.n_segs * frames;
   blocks = (unsigned)std::min<uint64_t>(grid, (tasks + waves_per_block - 1) / waves_per_block);
@@ -2375,9 +2496,6 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     if (!common || f.ori < 1 || f.ori > 7) return -2;
   }
 
-  unsigned blocks;
-  fused_task_grid(a, f.num_cus, blocks);
-
   const bool vec = f.src_is_u16 ? f.src_aligned4 : true;
   if (f.batch_n > 0) {
     // the multi-frame form of the kernel exists for the common parameter set without per-pixel guards (launch_fused_t's first choices for
@@ -2393,13 +2511,14 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
         for (int i = n; i < kBatchMax; ++i) { bp.src[i] = nullptr; bp.dst[i] = nullptr; }
         a.n_frames = (uint32_t)n;
         unsigned grid;
+        std::unique_lock<std::mutex> queue_lock;
+        (void)task_counters_for(s, a, queue_lock);
         fused_task_grid(a, f.num_cus, grid, (uint32_t)n);
-        std::unique_lock<std::mutex> queue_lock;              // (exactly one call per launch: the stream's two queues alternate)
-        if (!task_counters_for(s, a, queue_lock)) return -3;
 #define IPK_BATCH_LAUNCH(T, V, O) hipLaunchKernelGGL((k_fused_bayer_batch<T, V, O, false>), dim3(grid), dim3(1024), 0, s, a, bp)
         if (!f.src_is_u16) { if (f.out_type == 0) IPK_BATCH_LAUNCH(float, true, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(float, true, 1); else IPK_BATCH_LAUNCH(float, true, 2); }
         else { if (f.out_type == 0) IPK_BATCH_LAUNCH(uint16_t, false, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(uint16_t, false, 1); else IPK_BATCH_LAUNCH(uint16_t, false, 2); }
 #undef IPK_BATCH_LAUNCH
+        if (const int rc = launch_status()) return rc;
       } else {
         FusedLaunch one = f;
         one.batch_n = 0;
@@ -2409,7 +2528,9 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     return 0;
   }
   std::unique_lock<std::mutex> queue_lock;
-  if (!task_counters_for(s, a, queue_lock)) return -3;
+  (void)task_counters_for(s, a, queue_lock);
+  unsigned blocks;
+  fused_task_grid(a, f.num_cus, blocks);
   if (!f.src_is_u16) {
     if (f.out_type == 0) launch_fused_t<float, true, 0>(a, blocks, s);
     else if (f.out_type == 1) launch_fused_t<float, true, 1>(a, blocks, s);
@@ -2423,7 +2544,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     else if (f.out_type == 1) launch_fused_t<uint16_t, false, 1>(a, blocks, s);
     else launch_fused_t<uint16_t, false, 2>(a, blocks, s);
   }
-  return 0;
+  return launch_status();
 }
 
 

@@ -26,10 +26,11 @@ void launch_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size
 void launch_demosaic_full(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
                           const uint32_t *lookups_dev, float *dst4, hipStream_t s);
 
-// returns 0, or -3 when the stream's task queue could not be set up (out of device memory; more than 2048 streams)
+// returns 0, or -4 when the launch could not be enqueued (hipGetLastError after the launch)
 int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
                           int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s);
-void release_task_counters();   // the per-stream task queues of the row-walking kernels (ipk_shutdown)
+bool init_task_counters();      // the per-stream task-queue heads of the row-walking kernels: one device block (ipk_init)
+void release_task_counters();   // (ipk_shutdown)
 
 template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
@@ -81,7 +82,7 @@ struct FusedLaunch {
   // offset like `src`); one persistent launch per 64 frames where a batch variant of the kernel exists, one launch per frame otherwise
   int batch_n; const void *const *batch_src; void *const *batch_dst;
 };
-// returns 0, -2 when f.ori != 0 and the parameters have no rotated-space variant, -3 when the stream's task queue could not be set up (nothing is launched)
+// returns 0, -2 when f.ori != 0 and the parameters have no rotated-space variant (nothing is launched), -4 when a launch could not be enqueued
 int launch_fused_bayer(const FusedLaunch &f, hipStream_t s);
 // rotate_buffer's permutation on a 1-channel image through an arbitrary source pitch / window (steps in source elements)
 template <typename T>
