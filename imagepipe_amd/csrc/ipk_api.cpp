@@ -980,6 +980,15 @@ int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits) {
   ipk::launch_selftest_clamp(dev, nullptr); HIPCHK(hipGetLastError());
   return selftest_collect(dev, n_bad, first_bad_bits);
 }
+int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  if (!n_bad || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "bad selftest arguments");
+  ipk::Spline sp; int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
+  void *dev; rc = selftest_alloc(&dev); if (rc) return rc;
+  if (ipk::launch_selftest_spline3(sp, dev, nullptr) != 0) { (void)hipFree(dev); return fail(IPK_ERR_UNSUPPORTED, "the kernels keep the select form for this curve"); }
+  HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
 int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_bad_bits) {
   REQUIRE_INIT();
   void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;

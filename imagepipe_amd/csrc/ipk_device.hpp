@@ -342,6 +342,24 @@ __device__ __forceinline__ float spline_interpolate_3(const SplineDev &s, const 
   r = (val >= x2) ? s.py[2] : r;                       // val >= end
   return r;
 }
+// The same decisions with two of the three selects turned into arithmetic (round 3; 5 instructions per pixel fewer):
+//   val <= x0 or NaN -> y0:  the argument is raised to x0 first (v_max_f32 returns the number when the other operand is NaN); segment 0 at a
+//     difference of exactly 0 gives y0 + c1*0 + c2*0*0 + c3*0*0*0 = y0 -- every product is a zero, and adding zeros to y0 returns y0 bit for bit
+//     unless y0 is -0.0 (which would come back as +0.0);
+//   val == x1 -> y1:  the knot itself goes to segment 1 (`>=` instead of `>`), whose difference is then exactly 0: y1 by the same argument;
+//   val >= x2 -> y2 stays a select (segment 1 at x2 is only approximately y2).
+// Needs finite coefficients (0 * inf is NaN) and knot ordinates that are not -0.0: spline3_arith_ok(), checked by the host, which otherwise
+// keeps the form above.  Equality with the literal search on EVERY f32 argument is checked on the device for the curves the tests use
+// (ipk_selftest_spline3, tests/test_gpu_selftest.py).
+__device__ __forceinline__ float spline_interpolate_3a(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
+  const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
+  const float v1 = fmaxf(val, x0);
+  const bool up = v1 >= x1;
+  const float *rec = lds_knots + kKnotSegRec + (up ? 8 : 0);
+  const float4 q = *reinterpret_cast<const float4 *>(rec);
+  const float r = spline_poly(q.y, q.z, q.w, rec[4], v1 - q.x);
+  return (val >= x2) ? s.py[2] : r;
+}
 __device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
   const int np = s.npoints;
   if (np == 3) {

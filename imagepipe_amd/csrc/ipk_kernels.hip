@@ -56,6 +56,20 @@ using namespace ipkd;
 #ifndef IPK_OPT_PRIME4
 #define IPK_OPT_PRIME4 0
 #endif
+//   IPK_OPT_SPLINE3A   the common-parameter variants' 3-knot base curve with its lower clamp and knot hit as arithmetic (spline_interpolate_3a); the
+//                      host admits a curve to those variants only when spline3_arith_ok() holds
+#ifndef IPK_OPT_SPLINE3A
+#define IPK_OPT_SPLINE3A 1
+#endif
+//   IPK_OPT_UNROLL3    the row loop of the common-parameter Bayer variants as three copies of its body with the three-row window in rotating roles
+//                      (no 18 register copies per row, three times the code): noise 0.544 -> 0.550 ms, photo 0.435 -> 0.445 -- off
+#ifndef IPK_OPT_UNROLL3
+#define IPK_OPT_UNROLL3 0
+#endif
+//   IPK_OPT_FAIRPRIO   launches without a queue (one task per wave): issue priority that falls as a wave advances through its task (see row_step)
+#ifndef IPK_OPT_FAIRPRIO
+#define IPK_OPT_FAIRPRIO 1
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -1025,6 +1039,15 @@ static ToLabParams make_tolab(const float *mul4, const float *cm12) {
   for (int i = 0; i < 12; ++i) p.cm[i] = cm12[i];
   return p;
 }
+// spline_interpolate_3a's precondition (ipk_device.hpp): finite coefficients, knot ordinates that are not -0.0
+static bool spline3_arith_ok(const SplineDev &d) {
+  if (!IPK_OPT_SPLINE3A) return true;
+  for (int i = 0; i < 3; ++i) {
+    if (!std::isfinite(d.px[i]) || !std::isfinite(d.py[i]) || (d.py[i] == 0.0f && std::signbit(d.py[i]))) return false;
+    if (i < 2 && !(std::isfinite(d.c1[i]) && std::isfinite(d.c2[i]) && std::isfinite(d.c3[i]))) return false;
+  }
+  return true;
+}
 static SplineDev make_spline(const SplineHost &h) {
   SplineDev d;
   d.npoints = h.npoints; d.nseg = h.nseg;
@@ -1621,7 +1644,8 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       continue;
     }
     if (has_curve && IPK_ABLATE < 3) {
-      if (curve3) L = F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
+      if (curve3) L = IPK_OPT_SPLINE3A ? F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y))
+                                       : F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
       else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
     }
     const f2 cl = L * S2(100.0f);
@@ -2137,7 +2161,24 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
 #endif
     // (the ~20 register moves that rotate the row window per iteration would vanish in a 3x unrolled loop; the compiler refuses
     // `#pragma unroll 3` here -- wave-level ballots and barriers in the body -- and a hand-unrolled body triples the code for ~1 %)
-    for (uint32_t r = r0; r < r1; ++r) {
+    // One row: demosaic + point-wise stages + store of row r from the window (P, C, N) = rows r-1, r, r+1; then row r+2 is finished INTO P's
+    // registers (P is dead by then) and row r+3 issued.  The caller passes the three windows in rotating roles -- (P, C, N), (C, N, P), (N, P, C) --
+    // so the window never moves between registers (IPK_OPT_UNROLL3; the rolling form copies 18 registers per row).
+    auto row_step = [&](RowWin &P, RowWin &C, RowWin &N, bool &fP, bool &fC, bool &fN, const uint32_t r) {
+#if IPK_OPT_FAIRPRIO
+      // The four waves of a SIMD are served oldest first: left alone, the same 23 rows take one wave 83 us and another 164 (24 MP frame, one task per
+      // wave, tools/wave_timeline.py) and the launch ends on a quarter of its waves.  Where nothing is drawn from a queue a wave's issue priority
+      // therefore falls as it advances through its task, row by row in a cycle of four: whichever of a SIMD's waves is a row behind outranks the
+      // others until it has caught up (lifetimes 121-165 us, 24 MP frame 0.141 -> 0.133 ms).  With a queue the unevenness is harmless -- the fast
+      // waves simply draw more tasks -- and waves in step with each other wait for their table reads and stores at the same time: 100 MP frame
+      // 0.519 -> 0.542 ms with the priorities on, so they stay off there.
+      if (!queued) switch ((r - r0) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+      }
+#endif
       const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
       const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
       const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
@@ -2226,9 +2267,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         }
         __builtin_amdgcn_sched_barrier(0);
         raw_next = issue_row(min(r + 3, Hm1));
-        P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
+        P = NN; fP = fNN;
         if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
-        continue;
+        return;
       }
       PixOut o[4];
 #if IPK_ABLATE >= 5
@@ -2277,8 +2318,21 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
 #endif
       __builtin_amdgcn_sched_barrier(0);
       raw_next = issue_row(min(r + 3, Hm1));
-      P = C; C = N; N = NN; fP = fC; fC = fN; fN = fNN;
+      P = NN; fP = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
+    };
+#if IPK_OPT_UNROLL3
+    if (!GEN && !ROT && CMN) {                             // the headline variants only: three copies of the row body
+      for (uint32_t r = r0;;) {
+        row_step(P, C, N, fP, fC, fN, r); if (++r >= r1) break;
+        row_step(C, N, P, fC, fN, fP, r); if (++r >= r1) break;
+        row_step(N, P, C, fN, fP, fC, r); if (++r >= r1) break;
+      }
+    } else
+#endif
+    for (uint32_t r = r0; r < r1; ++r) {
+      row_step(P, C, N, fP, fC, fN, r);
+      { const RowWin t = P; P = C; C = N; N = t; const bool ft = fP; fP = fC; fC = fN; fN = ft; }   // back to rolling order
     }
   }
   // the last wave to leave zeroes the queue for the stream's next launch (every other wave's draws have returned before it arrived here)
@@ -2344,7 +2398,7 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 #else
   const unsigned tpb = 1024;
 #endif
-  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
+  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && spline3_arith_ok(a.spline) && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
                       std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
   if (a.ori != 0) {                                      // rotated space: the common parameter set only (launch_fused_bayer checked)
     if (a.gen_cells) { hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, true, true, true, true>), dim3(grid), dim3(tpb), 0, s, a); return; }
@@ -2491,7 +2545,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   if (f.ori != 0) {
     // rotated space exists for the common parameter set (the CMN variants) only;
     // anything else: the caller permutes the output instead
-    const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
+    const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && spline3_arith_ok(a.spline) && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
                         std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
     if (!common || f.ori < 1 || f.ori > 7) return -2;
   }
@@ -2500,7 +2554,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   if (f.batch_n > 0) {
     // the multi-frame form of the kernel exists for the common parameter set without per-pixel guards (launch_fused_t's first choices for
     // real sensors); 64 x 512x512 frames: 2.6 us per frame in one launch against 13 us with a launch each
-    const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
+    const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && spline3_arith_ok(a.spline) && !a.exact_norm && (a.linear != 0) == (f.out_type == 2) && a.W >= 256u &&
                         std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
     const bool batchable = common && a.ori == 0 && !a.gen_cells && a.px_guard == 0 && f.batch_n > 1;
     for (int i0 = 0; i0 < f.batch_n; i0 += kBatchMax) {
@@ -2775,6 +2829,21 @@ __global__ void k_selftest_clamp(SelftestOut *out) {
 }
 // output8bit: (v * 256).max(0).min(255) as u8 versus v_cvt_pk_u8_f32 of the product (variant 0), of its floor (variant 1), and
 // versus the saturating v_cvt_u32_f32 + unsigned min (variant 2), every bit pattern
+// every f32 argument through the arithmetic 3-knot form against the literal search (curves.rs:126-157)
+__global__ void k_selftest_spline3(SplineDev sp, SelftestOut *out) {
+  __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
+  if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, sp, (int)threadIdx.x);
+  __syncthreads();
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float v = __uint_as_float((unsigned)i);
+    const float want = spline_interpolate_lds(s_knots, sp.npoints, sp.nseg, v), got = spline_interpolate_3a(sp, s_knots, v);
+    const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);
+    if (!same) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
 __global__ void k_selftest_quant8(SelftestOut *out, int variant) {
   unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
   const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -2803,6 +2872,17 @@ int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bit
   const float rc_lo = (float)(1.0 / (double)c - (double)rc);
   hipLaunchKernelGGL(k_selftest_cdiv, dim3(256 * 8), dim3(256), 0, s, c, rc, rc_lo, variant, lo_bits, hi_bits, include_special,
                      reinterpret_cast<SelftestOut *>(out_dev));
+  return 0;
+}
+// returns -2 when the curve is not one the arithmetic form is used for (not 2 or 3 knots, or spline3_arith_ok fails)
+int launch_selftest_spline3(const SplineHost &h, void *out_dev, hipStream_t s) {
+  SplineDev d = make_spline(h);
+  if (d.npoints == 2) {                                   // padded like launch_fused_bayer does
+    d.npoints = 3; d.nseg = 2; d.px[2] = d.px[1]; d.py[2] = d.py[1];
+    d.c1[1] = d.c1[0]; d.c2[1] = d.c2[0]; d.c3[1] = d.c3[0]; d.c1[2] = d.c1[1];
+  }
+  if (d.npoints != 3 || !spline3_arith_ok(d)) return -2;
+  hipLaunchKernelGGL(k_selftest_spline3, dim3(256 * 8), dim3(256), 0, s, d, reinterpret_cast<SelftestOut *>(out_dev));
   return 0;
 }
 int launch_selftest_fract(void *out_dev, hipStream_t s) { hipLaunchKernelGGL(k_selftest_fract, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev)); return 0; }

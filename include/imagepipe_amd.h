@@ -503,6 +503,10 @@ IPK_API int ipk_selftest_cdiv(float c, int variant, float lo, float hi, int incl
 IPK_API int ipk_selftest_lut_weight(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* v.max(0.0).min(1.0) (src/ops/gamma.rs:22) versus v_med3_f32(v,0,1) for every f32 */
 IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
+/* SplineFunc::interpolate (src/ops/curves.rs:126-157) on every f32 against the form the fused kernels use for a base curve of 2 or 3 knots (lower
+ * clamp and exact knot hit as arithmetic, ipk_device.hpp spline_interpolate_3a); the curve is given like ipk_basecurve's.  IPK_ERR_UNSUPPORTED when
+ * the kernels would not use that form for this curve (more knots, a knot ordinate of -0.0, non-finite coefficients). */
+IPK_API int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint64_t *n_bad, uint32_t *first_bad_bits);
 /* output8bit (src/color_conversions.rs:323-326) on every f32 against a cheaper form: variant 0 v_cvt_pk_u8_f32(v*256), 1 the same of
  * floor(v*256), 2 min(saturating v_cvt_u32_f32(v*256), 255) -- the form the kernels use must report 0 mismatches */
 IPK_API int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_bad_bits);

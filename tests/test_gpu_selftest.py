@@ -109,6 +109,25 @@ def test_device_cbrtf_fast_form_every_f32_in_1_to_2(L, orc):
 
 
 
+@pytest.mark.parametrize("exposure,points", [(0.0, [(0.5, 0.6)]), (0.0, []), (0.7, []), (-1.3, [(0.5, 0.6)]), (0.0, [(0.25, 0.1)]), (0.0, [(0.7, 0.95)]),
+                                             (0.4, [(0.1, 0.3)]), (0.0, [(0.5, 0.5)]), (0.0, [(0.999, 0.001)])])
+def test_base_curve_arithmetic_form_equals_the_literal_search_on_every_f32(L, exposure, points):
+    """SplineFunc::interpolate (curves.rs:126-157: end clamps, binary search, exact knot hit) against the fused kernels' form for curves of 2 or 3
+    knots, which folds the lower clamp and the knot hit into the polynomial (ipk_device.hpp spline_interpolate_3a): all 2^32 arguments"""
+    if not points and abs(exposure) < 0.001:
+        pytest.skip("no curve at all: OpBaseCurve returns its input (curves.rs:34-36)")
+    flat = (C.c_float * max(2, 2 * len(points)))(*[c for p in points for c in p])
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_spline3(C.c_float(exposure), flat, len(points), C.byref(n), C.byref(first)) == 0
+    assert n.value == 0, (n.value, hex(first.value))
+
+
+def test_base_curve_arithmetic_form_is_refused_for_a_negative_zero_ordinate(L):
+    flat = (C.c_float * 2)(0.5, -0.0)
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_spline3(C.c_float(0.0), flat, 1, C.byref(n), C.byref(first)) == -5       # IPK_ERR_UNSUPPORTED: the kernels keep the select form
+
+
 def test_output8bit_packed_form_is_exact_on_every_f32(L):
     """output8bit = (v*256).max(0).min(255) as u8 (color_conversions.rs:323-326) against v_cvt_pk_u8_f32 of floor(v*256), the form the
     kernels pack their 8-bit output with, and against the saturating v_cvt_u32_f32 + unsigned min: all 2^32 inputs.  (Without the floor the

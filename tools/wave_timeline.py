@@ -27,12 +27,16 @@ rc = L.ipk_dev_probe_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b
 atomics = (buf.reshape(4096, 8)[:, 2] >> np.uint64(48)).astype(np.float64)
 buf.reshape(4096, 8)[:, 2] &= np.uint64((1 << 48) - 1)
 q = buf.reshape(4096, 8).astype(np.float64)
+live = q[:, 3] > 0                     # waves that ran at least one task
+atomics = atomics[live]; q = q[live]
+n_live = int(live.sum())
 w0, w1 = q[:, 6], q[:, 7]
 t_begin, t_end = w0.min(), w1.max()
 span_us = (t_end - t_begin) / 100.0
 life = (w1 - w0) / 100.0
 cyc = q[:, 1] - q[:, 0]
 print("%s %dx%d: event %.1f us; first wave start -> last wave end %.1f us" % (kind, W, H, e0.elapsed_time(e1) * 1e3, span_us))
+print("  lifetime us percentiles 0/10/50/90/100: %.1f %.1f %.1f %.1f %.1f" % tuple(np.percentile(life, [0, 10, 50, 90, 100])))
 print("  wave start offsets us: min %.1f median %.1f max %.1f" % ((w0 - t_begin).min() / 100, np.median(w0 - t_begin) / 100, (w0 - t_begin).max() / 100))
 print("  wave end before launch end us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % tuple(np.percentile((t_end - w1) / 100, [0, 10, 50, 90, 100])))
 print("  wave lifetime us: mean %.1f (%.3f of span); shader clock during life %.2f GHz" % (life.mean(), life.mean() / span_us, (cyc / (life * 1e3)).mean()))
@@ -44,6 +48,6 @@ print("  task priming (4 row loads, 3 awaited) per wave us: mean %.2f = %.2f per
 ends = np.sort((w1 - t_begin) / 100.0)
 for f in (0.5, 0.75, 0.9, 0.95):
     t = span_us * f
-    print("  at %.0f %% of the span (%.0f us): %d of 4096 waves still resident" % (f * 100, t, int((ends > t).sum())))
+    print("  at %.0f %% of the span (%.0f us): %d of %d waves still resident" % (f * 100, t, int((ends > t).sum()), n_live))
 per_row = life / np.maximum(q[:, 5] + 2.5 * q[:, 3], 1)
 print("  us per row-equivalent (rows + 2.5 per task): mean %.3f" % per_row.mean())
