@@ -137,6 +137,7 @@ class Ctx:
         self.dist = None
         self.share = False
         self._comm = None
+        self.failed = []
         if self.world > 1:
             import torch.distributed as dist
             # IPK_BENCH_SHARE_GPU=1 (development only): all ranks on one GPU over gloo, to exercise the N > 1 control flow on a 1-GPU box
@@ -154,6 +155,11 @@ class Ctx:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
         self.red_dev = "cpu" if (self.dist is not None and self.dist.get_backend() == "gloo") else "cuda"
+
+    def fail(self, leg, msg):
+        """a secondary measurement that failed: loud (stderr, "failed_legs" of the line) but never silent and never fatal to the headline"""
+        self.failed.append(leg)
+        sys.stderr.write("bench.py: rank %d: leg %s FAILED: %s\n" % (self.rank, leg, msg))
 
     def comm(self):
         """the LIBRARY's communicator over the ranks (ipk_comm: RCCL when the ranks have a GPU each, its host transport when they share one)"""
@@ -240,6 +246,7 @@ class FusedBatch:
             del ints
             self.dsts.append(torch.empty(H * W * 3, dtype=out_dt, device="cuda"))
         self.cm = util.cam_matrix()
+        self.black, self.white, self.wb = util.BLACK, util.WHITE, util.WB
         self.plan = ipa.FusedPlan(width=W, height=H, is_float=self.is_float, black0=util.BLACK, white0=util.WHITE, cfa=cfa, wb_coeffs=util.WB,
                                   cam_to_xyz_normalized=self.cm, out_type=self.out_type)
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -288,21 +295,32 @@ def oracle_check(ctx, util, wl, rows=None):
 
 
 def copy_ceiling(ctx, nbytes):
-    """device-to-device copy of `nbytes` (read + write counted): the practical HBM ceiling next to the 8 TB/s spec peak"""
+    """device-to-device copy of `nbytes` (read + write counted) with the library's own 16-bytes-per-lane copy kernel (ipk_copy_probe): the
+    practical HBM ceiling next to the 8 TB/s spec peak (MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy); torch's copy_ beside it"""
     torch = ctx.torch
+    import imagepipe_amd as ipa
+    L = ipa.lib()
     a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").fill_(1.0)
     b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        b.copy_(a)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return 2.0 * nbytes / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+
+    def probe():
+        rc = L.ipk_copy_probe(a.data_ptr(), b.data_ptr(), nbytes, st)
+        assert rc == 0, rc
+    own, tch = run(probe), run(lambda: b.copy_(a))
     del a, b
-    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+    return own, tch
 
 
 def valu_model(kernel_ms):
@@ -378,6 +396,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+        "value_basis": "all frames' pixels / wall time of the K timed steps (barrier + synchronize on both sides, max over ranks), i.e. the MEAN step; "
+                       "the median step is roofline.kernel_ms_median, the run without clock pre-warm config.cold_ms",
+        "value_from_median_step": round(B * (H * W) / 1e6 / (median_ms * 1e-3), 1),
         "dtype": "f32", "data": "synthetic (%s, 14-bit %s sensor values, torch Philox seed 0x%X+frame)" % (args.data, cfa if len(cfa) == 4 else "X-Trans", util.SEED + 2),
         "config": {"workload": "%dx%d (%.0f MP) synthetic %s %s mosaic -> fused gofloat+demosaic+tolab+basecurve+fromlab+gamma -> %s RGB, %s"
                                % (W, H, H * W / 1e6, cfa if len(cfa) == 4 else "X-Trans", args.src, args.out,
@@ -414,7 +435,10 @@ def main():
             result["roofline_valu"] = vm
 
     if extras:
-        result["roofline"]["copy_ceiling_GBps"] = round(copy_ceiling(ctx, (12 if dev_small else 1200) * 1000 * 1000), 1)     # every rank (keeps the ranks in step)
+        own, tch = copy_ceiling(ctx, (12 if dev_small else 1200) * 1000 * 1000)     # every rank (keeps the ranks in step)
+        result["roofline"]["copy_ceiling_GBps"] = round(max(own, tch), 1)
+        result["roofline"]["copy_ceiling_detail"] = {"ipk_copy_probe_GBps": round(own, 1), "torch_copy_GBps": round(tch, 1),
+                                                     "guide_float4_copy_GBps": 6290.0, "bytes": (12 if dev_small else 1200) * 1000 * 1000}
         result["roofline"]["frac_of_copy_ceiling"] = round(achieved / result["roofline"]["copy_ceiling_GBps"], 4)
         other = {}
         for kind in ("smooth", "photo"):
@@ -446,6 +470,16 @@ def main():
     # ---- CPU baseline: the oracle's reference-shaped pipeline (unfused, one task per row) on this host ----
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(util, args.data, args.cpu_seconds)
+    if world > 1:
+        try:
+            result["config"]["ipk_comm"] = ctx.comm_info()      # what the library's own transport saw (ipk_comm_info): rank count and transport
+            if result["config"]["ipk_comm"]["ranks"] != world:
+                ctx.fail("ipk_comm", "the library's communicator has %d ranks, the job %d" % (result["config"]["ipk_comm"]["ranks"], world))
+        except Exception as e:
+            result["config"]["ipk_comm"] = {"ok": False, "error": repr(e)}
+            ctx.fail("ipk_comm", repr(e))
+    result["failed_legs"] = ctx.failed
+    assert result["n_gpus"] == args.gpus, (result["n_gpus"], args.gpus)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if ctx.dist is not None:
@@ -454,14 +488,32 @@ def main():
 
 
 def gather_leg(ctx, wl, steps):
-    """compute + all-gather of every frame's result to every rank (SURVEY.md 8e prices the f32 gather above the compute; both
-    figures are reported).  torch.distributed (RCCL) all_gather_into_tensor, one collective per round of N frames."""
+    """compute + all-gather of every frame's result to every rank (SURVEY.md 8e prices the f32 gather above the compute; all figures are
+    reported).  Three transports of the same bytes, one collective per round of N frames, each enqueued behind its frame's kernel:
+      torch_f32  torch.distributed all_gather_into_tensor (RCCL)
+      ipk_f32    the library's own entry point, ipk_band_gather over its RCCL communicator: the round's N frames are the N bands of one buffer,
+                 every rank's kernel writes its frame in place, ncclAllGather in place (ipk_comm.cpp)
+      ipk_u8     the same with the 8-bit output (output_8bit): a quarter of the bytes
+    A leg that fails carries "ok": false and its error, and the failure is repeated on stderr and in the line's "failed_legs"."""
     torch, dist = ctx.torch, ctx.dist
-    try:
-        rounds = (wl.B + ctx.world - 1) // ctx.world
-        if rounds * ctx.world != wl.B:
-            return {"error": "batch not a multiple of the rank count"}
-        per = wl.H * wl.W * 3
+    import imagepipe_amd as ipa
+    from imagepipe_amd import parallel as par
+    out = {}
+    rounds = (wl.B + ctx.world - 1) // ctx.world
+    if rounds * ctx.world != wl.B:
+        return {"ok": False, "error": "batch not a multiple of the rank count"}
+    per = wl.H * wl.W * 3
+    mp_per_step = wl.B * wl.H * wl.W / 1e6
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+            out[name]["ok"] = True
+        except Exception as e:
+            out[name] = {"ok": False, "error": repr(e)}
+            ctx.fail("with_gather." + name, repr(e))
+
+    def torch_f32():
         big = [torch.empty(ctx.world * per, dtype=wl.dsts[0].dtype, device="cuda") for _ in range(rounds)]
 
         def step():
@@ -469,12 +521,44 @@ def gather_leg(ctx, wl, steps):
                 wl.plan.run(s, d, wl.stream)
                 dist.all_gather_into_tensor(big[j], d)          # enqueued behind frame j's kernel; frame j+1's launch follows on the same stream
         elapsed, _, _ = timed(ctx, step, steps, 1, 0.0)
-        mp = steps * wl.B * wl.H * wl.W / 1e6
-        return {"value": round(mp / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+        return {"value": round(steps * mp_per_step / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "gathered_bytes_per_rank_per_step": per * wl.dsts[0].element_size() * wl.B,
-                "collective": "all_gather_into_tensor (RCCL) of the f32 results, one per round of N frames"}
-    except Exception as e:
-        return {"error": repr(e)}
+                "collective": "torch.distributed all_gather_into_tensor of the results, one per round of N frames"}
+
+    def ipk(out_type, dtype, label):
+        comm = ctx.comm()
+        bands = [par.Band(k, k * wl.H, wl.H, k * wl.H, wl.H) for k in range(ctx.world)]     # round buffer = N frames stacked: rank k's frame is band k
+        plan = wl.plan if out_type == wl.out_type else ipa.FusedPlan(width=wl.W, height=wl.H, is_float=wl.is_float, black0=wl.black, white0=wl.white, cfa="RGGB",
+                                                                     wb_coeffs=wl.wb, cam_to_xyz_normalized=wl.cm, out_type=out_type)
+        big = [torch.empty((ctx.world * wl.H, wl.W * 3), dtype=dtype, device="cuda") for _ in range(rounds)]
+        mine = [b[ctx.rank * wl.H:(ctx.rank + 1) * wl.H].reshape(-1) for b in big]
+
+        def step():
+            for j, s in enumerate(wl.srcs):
+                plan.run(s, mine[j], wl.stream)                 # the frame lands in its band of the round's buffer
+                comm.gather(big[j], bands, root=-1, stream=wl.stream)
+        elapsed, _, _ = timed(ctx, step, steps, 1, 0.0)
+        # every rank now holds every frame of the last round: rank r's band must equal what rank r computed (checked through a checksum exchange)
+        sums = [float(big[-1][k * wl.H:(k + 1) * wl.H].to(torch.float64).sum()) for k in range(ctx.world)]
+        allsums = [None] * ctx.world
+        dist.all_gather_object(allsums, sums)
+        same = all(a == allsums[0] for a in allsums)
+        if not same:
+            raise RuntimeError("gathered frames differ between ranks")
+        return {"value": round(steps * mp_per_step / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "gathered_bytes_per_rank_per_step": per * big[0].element_size() * wl.B, "every_rank_holds_the_same_frames": same,
+                "collective": "ipk_band_gather (%s transport), in place, %s" % (ctx.comm_info()["transport"], label)}
+
+    leg("torch_f32", torch_f32)
+    if wl.out_type == ipa.OUT_F32:
+        leg("ipk_f32", lambda: ipk(ipa.OUT_F32, torch.float32, "f32 results"))
+    leg("ipk_u8", lambda: ipk(ipa.OUT_U8, torch.uint8, "8-bit results (output_8bit)"))
+    # headline of the object: the library's own f32 gather when it ran, torch's otherwise
+    best = out.get("ipk_f32") if out.get("ipk_f32", {}).get("ok") else out.get("torch_f32")
+    if best and best.get("ok"):
+        out["value"], out["unit"], out["ms_per_step"] = best["value"], "MP/s", best["ms_per_step"]
+    out["ok"] = all(v.get("ok") for v in out.values() if isinstance(v, dict))
+    return out
 
 
 def batch_mode(ctx, ipa, util, W, H, B, src_kind, out_kind, data, steps, warmup, gather):
@@ -482,14 +566,41 @@ def batch_mode(ctx, ipa, util, W, H, B, src_kind, out_kind, data, steps, warmup,
     elapsed, mean_ms, median_ms = timed(ctx, wl.step, steps, warmup, 0.0)
     mp = steps * B * H * W / 1e6
     kernel_ms = mean_ms / wl.launches_per_step
+    parity = None
+    if ctx.rank == 0 and out_kind == "f32" and wl.mine:
+        parity = batch_oracle_check(ctx, util, wl)            # untimed: the first and the last frame of the rank, as the timed launch left them
     out = {"config": "BASELINE.json configs[3]: %d x %dx%d RGGB %s frames per step, frame i on rank i mod N, no data-path collective" % (B, W, H, src_kind),
            "value": round(mp / elapsed, 1), "unit": "MP/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "scaling": "strong",
            "frames_on_rank0": len(wl.mine), "kernel_ms": round(kernel_ms, 4),
            "launch": "ipk_raw_to_srgb_batch: one persistent launch per 64 frames of a rank (kernel_ms = time per frame)" if wl.batch is not None else "one launch per frame",
            "frac": round(wl.alg_bytes_per_launch() / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if parity:
+        out["parity_check"] = parity
     if gather:
         out["with_gather"] = gather_leg(ctx, wl, steps=2)
     return out
+
+
+def batch_oracle_check(ctx, util, wl):
+    """the rank's first and last frame exactly as wl.step() -- the timed path: ipk_raw_to_srgb_batch when the rank has several frames -- left them,
+    every sample against the CPU oracle"""
+    import numpy as np
+    import oracle
+    torch = ctx.torch
+    for d in wl.dsts:
+        d.zero_()
+    wl.step(); torch.cuda.synchronize()
+    idx = sorted({0, len(wl.srcs) - 1})
+    for i in idx:
+        part = wl.srcs[i].cpu().numpy().reshape(wl.H, wl.W)
+        desc = oracle.make_pipeline(part if wl.is_float else part.view(np.uint16), cfa="RGGB", source_kind=1 if wl.is_float else 0,
+                                    blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=wl.cm)
+        want = torch.from_numpy(oracle.pipeline_run(desc).reshape(-1))
+        got = wl.dsts[i].cpu()
+        if not torch.equal(got.view(torch.int32), want.view(torch.int32)):
+            util.assert_bits_equal(got.numpy().reshape(wl.H, wl.W, 3), want.numpy().reshape(wl.H, wl.W, 3), "bench batch parity check, frame %d" % wl.mine[i])
+    return "frames %s of rank 0 (%s) bit-identical to the CPU oracle, every sample" % (
+        [wl.mine[i] for i in idx], "one ipk_raw_to_srgb_batch launch per 64 frames" if wl.batch is not None else "one launch per frame")
 
 
 def band_leg(ctx, ipa, util, wl, args):
@@ -604,11 +715,24 @@ def band_children(ctx, args, W, H):
         for line in out.splitlines():
             if line.startswith("BAND_CHILD "):
                 res = json.loads(line[len("BAND_CHILD "):])
-        if res is None:
-            res = {"error": "rank %d child rc=%s: %s" % (ctx.rank, rc, (err or out)[-400:])}
-        return res
+        if res is None and ctx.rank != 0 and rc == 0:
+            res = {"ok": True}                                  # only rank 0's child prints the figures
+        elif res is None:
+            res = {"ok": False, "error": "rank %d child rc=%s: %s" % (ctx.rank, rc, (err or out)[-400:])}
+        else:
+            res["ok"] = rc == 0 and (ctx.rank != 0 or bool(res.get("gathered_frame_bit_identical_to_one_launch")))
+            if not res["ok"]:
+                res["error"] = "child rc=%s, gathered frame identical to one launch: %s" % (rc, res.get("gathered_frame_bit_identical_to_one_launch"))
     except Exception as e:
-        return {"error": repr(e)}
+        res = {"ok": False, "error": repr(e)}
+    if not res["ok"]:
+        ctx.fail("band_mode", res["error"])
+    # every rank's child must have come through, not just rank 0's (all ranks reach this reduction, whatever happened above)
+    if ctx.max_over_ranks([0.0 if res["ok"] else 1.0])[0] != 0.0 and res["ok"]:
+        res["ok"] = False
+        res["error"] = "another rank's child failed"
+        ctx.fail("band_mode", res["error"])
+    return res
 
 
 def cpu_baseline(util, data, seconds):

@@ -980,6 +980,12 @@ int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits) {
   ipk::launch_selftest_clamp(dev, nullptr); HIPCHK(hipGetLastError());
   return selftest_collect(dev, n_bad, first_bad_bits);
 }
+int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst || (bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(IPK_ERR_INVALID, "ipk_copy_probe wants 16-byte aligned buffers and a multiple of 16 bytes");
+  ipk::launch_copy_probe(src, dst, bytes, g.num_cus, S(stream)); HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
 int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint64_t *n_bad, uint32_t *first_bad_bits) {
   REQUIRE_INIT();
   if (!n_bad || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "bad selftest arguments");

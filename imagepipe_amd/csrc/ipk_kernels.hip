@@ -2829,6 +2829,17 @@ __global__ void k_selftest_clamp(SelftestOut *out) {
 }
 // output8bit: (v * 256).max(0).min(255) as u8 versus v_cvt_pk_u8_f32 of the product (variant 0), of its floor (variant 1), and
 // versus the saturating v_cvt_u32_f32 + unsigned min (variant 2), every bit pattern
+// The practical HBM ceiling the roofline figures are compared with: a plain copy, 16 bytes per lane, every lane of every CU streaming
+// (bench.py's copy_ceiling; MI355X_MICROARCH.md measures 6.29 TB/s for such a copy against the 8 TB/s spec peak).
+__global__ __launch_bounds__(256) void k_copy_probe(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+void launch_copy_probe(const void *src, void *dst, size_t bytes, int num_cus, hipStream_t s) {
+  const size_t n16 = bytes / 16;
+  const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)(num_cus > 0 ? num_cus : 256) * 32);
+  hipLaunchKernelGGL(k_copy_probe, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), n16);
+}
 // every f32 argument through the arithmetic 3-knot form against the literal search (curves.rs:126-157)
 __global__ void k_selftest_spline3(SplineDev sp, SelftestOut *out) {
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];

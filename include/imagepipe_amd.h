@@ -503,6 +503,9 @@ IPK_API int ipk_selftest_cdiv(float c, int variant, float lo, float hi, int incl
 IPK_API int ipk_selftest_lut_weight(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* v.max(0.0).min(1.0) (src/ops/gamma.rs:22) versus v_med3_f32(v,0,1) for every f32 */
 IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
+/* Measurement aid, no counterpart in the reference: a plain device-to-device copy, 16 bytes per lane, as the practical HBM ceiling next to which
+ * bench.py reports the kernels' achieved bandwidth (SURVEY.md 8d asks for the measured copy / triad ceiling beside the 8 TB/s spec peak). */
+IPK_API int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream);
 /* SplineFunc::interpolate (src/ops/curves.rs:126-157) on every f32 against the form the fused kernels use for a base curve of 2 or 3 knots (lower
  * clamp and exact knot hit as arithmetic, ipk_device.hpp spline_interpolate_3a); the curve is given like ipk_basecurve's.  IPK_ERR_UNSUPPORTED when
  * the kernels would not use that form for this curve (more knots, a knot ordinate of -0.0, non-finite coefficients). */

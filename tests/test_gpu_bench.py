@@ -42,6 +42,27 @@ def test_bench_two_ranks_control_flow():
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["scaling"] == "weak" and d["value"] > 0
 
 
+def test_bench_gpus_n_invoked_plainly_starts_n_ranks_or_refuses():
+    """`python bench.py --gpus 2` WITHOUT a launcher: on this one-GPU box it must refuse (non-zero exit, no JSON line) rather than print a line for
+    one rank; with the development hook that lets ranks share the GPU it starts the two ranks itself (torch.distributed.run) and the line says so --
+    n_gpus 2, and the rank count the library's own communicator saw (ipk_comm_info)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "IPK_BENCH_SHARE_GPU")}
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "2048", "--height", "1024", "--no-cpu-baseline", "--prewarm-ms", "0"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stdout[-500:])
+        assert "refusing" in r.stderr
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(env, IPK_BENCH_SHARE_GPU="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["config"]["ipk_comm"]["ranks"] == 2
+    # a WORLD_SIZE that is not --gpus is refused as well
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.parametrize("nproc", [1, 2])
 def test_bench_default_control_flow_with_extras(nproc):
     """the DEFAULT command's whole control flow -- parity check, cold-clock leg, copy ceiling, the other data kinds, the 64-frame batch
@@ -57,12 +78,19 @@ def test_bench_default_control_flow_with_extras(nproc):
     assert d["n_gpus"] == nproc and d["scaling"] == "weak" and d["config"]["frames_per_step"] == nproc
     assert "cold_ms" in d["config"] and "copy_ceiling_GBps" in d["roofline"] and set(d["other_data"]) == {"smooth", "photo"}
     b = d["batch_64x24MP"]
-    assert b["value"] > 0 and b["scaling"] == "strong"
+    assert b["value"] > 0 and b["scaling"] == "strong" and "bit-identical" in b["parity_check"]       # the batch launch itself against the oracle
+    assert "ipk_copy_probe_GBps" in d["roofline"]["copy_ceiling_detail"] and d["value_from_median_step"] > 0
     if nproc > 1:
-        assert "value" in b["with_gather"] or "error" in b["with_gather"]
+        g = b["with_gather"]
+        # the library's own gather (host transport here: the ranks share the GPU) must have moved the frames, f32 and 8-bit
+        assert g["ipk_f32"]["ok"] and g["ipk_u8"]["ok"] and g["ipk_f32"]["every_rank_holds_the_same_frames"], g
+        assert g["ipk_u8"]["gathered_bytes_per_rank_per_step"] * 4 == g["ipk_f32"]["gathered_bytes_per_rank_per_step"]
         # the banded single-frame leg runs in child processes on the RCCL transport: with two ranks on ONE GPU RCCL refuses the communicator,
-        # and the leg must report that instead of costing the line
-        assert "band_mode" in d and ("value" in d["band_mode"] or "error" in d["band_mode"]), d.get("band_mode")
+        # and the leg must say so loudly (ok false, named in failed_legs) instead of costing the line or passing silently
+        assert d["band_mode"]["ok"] is False and "band_mode" in d["failed_legs"], d.get("band_mode")
+        assert d["config"]["ipk_comm"] == {"ranks": 2, "transport": "host"}
+    else:
+        assert d["failed_legs"] == []
     assert "bit-identical" in d["parity_check"] and "cpu_baseline" in d
 
 
@@ -90,7 +118,7 @@ def test_bench_batch_two_ranks():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 6 and d["scaling"] == "strong" and d["value"] > 0
-    assert "value" in d["with_gather"] or "error" in d["with_gather"]          # gloo may refuse device tensors; RCCL is the driver's path
+    assert d["with_gather"]["ipk_f32"]["ok"] and d["with_gather"]["ipk_u8"]["ok"]        # the library's gather; torch's over gloo may refuse device tensors
 
 
 @pytest.mark.parametrize("cfa,H,W,nproc", [("RGGB", 150, 600, 2), ("GBRG", 301, 258, 3), ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 180, 300, 4)])
