@@ -119,6 +119,14 @@ int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
 // takes a block another stream used last: it gets a new one, so after a few runs every stream of a multi-stream caller owns the blocks it
 // cycles through.  Only when memory runs out is the device drained, after which every idle block may go anywhere.  No stream handle is
 // ever touched except the caller's current one (a previous one may have been destroyed).
+// hipStreamPerThread is ONE handle that names a different stream in every host thread: the pool's "same stream" test keys it by the calling
+// thread (as the task queues do), so two threads on their per-thread streams never hand each other a block without an ordering between them.
+// (A handle value that HIP reuses for a new stream after hipStreamDestroy while the old stream's work is still in flight cannot be told apart:
+// callers synchronise a stream before destroying it -- INTEGRATION.md.)
+static hipStream_t pool_key(hipStream_t s) {
+  static thread_local char per_thread_key;
+  return s == hipStreamPerThread ? reinterpret_cast<hipStream_t>(&per_thread_key) : s;
+}
 static int pool_pick(size_t bytes, hipStream_t stream) {
   int best = -1;
   for (size_t i = 0; i < g.pool.size(); ++i) {
@@ -128,6 +136,7 @@ static int pool_pick(size_t bytes, hipStream_t stream) {
   return best;
 }
 int pool_get(size_t bytes, void **out, hipStream_t stream) {
+  stream = pool_key(stream);
   std::lock_guard<std::mutex> lk(g.mu);
   int best = pool_pick(bytes, stream);
   if (best < 0) {
@@ -164,6 +173,7 @@ int pool_get(size_t bytes, void **out, hipStream_t stream) {
 }
 void pool_put(void *p, hipStream_t stream) {
   if (!p) return;
+  stream = pool_key(stream);
   std::lock_guard<std::mutex> lk(g.mu);
   for (auto &b : g.pool) if (b.p == p) { b.last = stream; b.busy = false; return; }
 }
@@ -551,6 +561,16 @@ int ipk_raw_scaled_demosaic_band(const void *src, int src_type, size_t owidth, s
     return fail(IPK_ERR_INVALID, "bad raw_scaled_demosaic_band arguments");
   if (band->out_rows == 0) return IPK_OK;
   if (band->out_row0 + band->out_rows > nheight || band->src_row0 + band->src_rows > height) return fail(IPK_ERR_INVALID, "band outside the frame");
+  if (nheight < 2) return fail(IPK_ERR_INVALID, "a banded scaled demosaic needs at least two output rows");
+  {
+    // the slab must hold every source row the band's windows read (scaling.rs:84-94; the same f32 expressions as ipk_band_plan_scaled): a slab
+    // that does not -- a hand-built band, a plan made for another output height -- would make the kernel read outside it
+    const float skip = ((float)((int64_t)height - 1) - 0.0f) / ((float)(nheight - 1));
+    const size_t from = std::min(height - 1, ipk::f32_to_usize(std::floor(0.0f + skip * (float)band->out_row0)));
+    const size_t to = std::min(height - 1, ipk::f32_to_usize(std::floor(0.0f + skip * (float)(band->out_row0 + band->out_rows))));
+    if (band->src_row0 > from || band->src_row0 + band->src_rows <= to)
+      return fail(IPK_ERR_INVALID, "band slab rows [%zu,%zu) do not cover the window rows [%zu,%zu]", band->src_row0, band->src_row0 + band->src_rows, from, to);
+  }
   ipk::Cfa cfa; DevCfa dev; int rc = get_cfa(cfa_pat, cfa, dev); if (rc) return rc;
   const int norm_fast = validate_cdiv_for_range(black0, white0 - black0, src_type == IPK_SRC_U16) ? 1 : 0;
   if (src_type == IPK_SRC_U16) ipk::launch_raw_scaled_demosaic<uint16_t>(static_cast<const uint16_t *>(src), owidth, x, 0, width, height, black0, white0, norm_fast, cfa.three_colour() ? 0 : 1, nwidth, nheight, dev.cfa48, (int)cfa.width, (int)cfa.height, dst4, S(stream), band->src_row0, band->out_row0, band->out_rows);
@@ -1129,10 +1149,15 @@ int ipk_timing_begin(void) {
   return IPK_OK;
 }
 int ipk_timing_end(ipk_stage_time *out, int max_stages, int *n_stages) {
-  if (!n_stages || (max_stages > 0 && !out)) return fail(IPK_ERR_INVALID, "null argument");
+  // the session ends whatever the arguments are: a bad call must not leave the thread armed with its events alive
   g_timing.active = false;
-  int n = 0, rc = IPK_OK;
   auto &mk = g_timing.marks;
+  if (!n_stages || (max_stages > 0 && !out)) {
+    for (auto &m : mk) (void)hipEventDestroy(m.second);
+    mk.clear();
+    return fail(IPK_ERR_INVALID, "null argument");
+  }
+  int n = 0, rc = IPK_OK;
   if (!mk.empty() && hipEventSynchronize(mk.back().second) != hipSuccess) rc = fail(IPK_ERR_HIP, "hipEventSynchronize failed");
   for (size_t i = 1; i < mk.size() && rc == IPK_OK; ++i) {
     if (mk[i].first == "(start)") continue;                       // a second pipeline call inside one session starts a new sequence

@@ -352,10 +352,22 @@ int ipk_comm_wait(ipk_comm *c, void *stream) {
   if (!c) return internal_fail(IPK_ERR_INVALID, "null communicator");
   if (!c->pending) return IPK_OK;
   HIPCHK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->ev_out, 0));
+  c->pending = false;                   // `stream` is now ordered behind every gather begun so far; a later begin sets it again
   return IPK_OK;
 }
 
 // ---- self-check of a transport ----------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+struct DevBuf {                          // a device allocation that is returned on every path out of the self-check
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+}
+extern "C" {
 int ipk_comm_selftest(ipk_comm *c) {
   int rc = ipk::internal_require_init(); if (rc) return rc;
   if (!c) return internal_fail(IPK_ERR_INVALID, "null communicator");
@@ -367,8 +379,9 @@ int ipk_comm_selftest(ipk_comm *c) {
     const int to = (me + 1) % n, from = (me - 1 + n) % n;
     std::vector<uint8_t> hs(row), hr(row, 0);
     for (size_t i = 0; i < row; ++i) hs[i] = (uint8_t)(me * 31 + i % 200);
-    void *ds = nullptr, *dr = nullptr, *dg = nullptr;
-    HIPCHK(hipMalloc(&ds, row)); HIPCHK(hipMalloc(&dr, row)); HIPCHK(hipMalloc(&dg, 1024 * (size_t)n));
+    DevBuf bs, br, bg;
+    HIPCHK(hipMalloc(&bs.p, row)); HIPCHK(hipMalloc(&br.p, row)); HIPCHK(hipMalloc(&bg.p, 1024 * (size_t)n));
+    void *const ds = bs.p, *const dr = br.p, *const dg = bg.p;
     HIPCHK(hipMemcpy(ds, hs.data(), row, hipMemcpyHostToDevice));
     NCCLCHK(g_rccl.GroupStart());
     NCCLCHK(g_rccl.Send(ds, row, ncclUint8, to, c->nccl, nullptr));
@@ -379,7 +392,6 @@ int ipk_comm_selftest(ipk_comm *c) {
     HIPCHK(hipMemcpy(hr.data(), dr, row, hipMemcpyDeviceToHost));
     std::vector<uint8_t> hg(1024 * (size_t)n);
     HIPCHK(hipMemcpy(hg.data(), dg, hg.size(), hipMemcpyDeviceToHost));
-    (void)hipFree(ds); (void)hipFree(dr); (void)hipFree(dg);
     for (size_t i = 0; i < row; ++i) if (hr[i] != (uint8_t)(from * 31 + i % 200)) return internal_fail(IPK_ERR_HIP, "comm selftest: RCCL ring step delivered wrong bytes");
     for (int k = 0; k < n; ++k) for (size_t i = 0; i < 1024; ++i)
       if (hg[(size_t)k * 1024 + i] != (uint8_t)(k * 31 + i % 200)) return internal_fail(IPK_ERR_HIP, "comm selftest: ncclAllGather delivered wrong bytes");
@@ -396,8 +408,9 @@ int ipk_comm_selftest(ipk_comm *c) {
       for (size_t i = 0; i < bands[(size_t)k].out_rows * row; ++i) want[bands[(size_t)k].out_row0 * row + i] = (uint8_t)(17 * k + 3 + (i * 7 + ragged) % 251);
     const ipk_band &b = bands[(size_t)me];
     std::memcpy(host.data() + b.out_row0 * row, want.data() + b.out_row0 * row, b.out_rows * row);
-    void *dev = nullptr;
-    HIPCHK(hipMalloc(&dev, total));
+    DevBuf bdev;
+    HIPCHK(hipMalloc(&bdev.p, total));
+    void *const dev = bdev.p;
     HIPCHK(hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice));
     rc = ipk_band_gather(c, dev, row, bands.data(), -1, nullptr);
     if (!rc) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(host.data(), dev, total, hipMemcpyDeviceToHost)); }
@@ -406,16 +419,15 @@ int ipk_comm_selftest(ipk_comm *c) {
     if (!rc) {
       std::vector<uint8_t> slab(b.src_rows * row, 0xDD);
       std::memcpy(slab.data() + (b.out_row0 - b.src_row0) * row, want.data() + b.out_row0 * row, b.out_rows * row);
-      void *ds = nullptr;
-      HIPCHK(hipMalloc(&ds, slab.size()));
+      DevBuf bslab;
+      HIPCHK(hipMalloc(&bslab.p, slab.size()));
+      void *const ds = bslab.p;
       HIPCHK(hipMemcpy(ds, slab.data(), slab.size(), hipMemcpyHostToDevice));
       rc = ipk_band_exchange_halo(c, ds, row, bands.data(), nullptr);
       if (!rc) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(slab.data(), ds, slab.size(), hipMemcpyDeviceToHost)); }
       if (!rc && std::memcmp(slab.data(), want.data() + b.src_row0 * row, slab.size()) != 0)
         rc = internal_fail(IPK_ERR_HIP, "comm selftest: slab after the halo exchange differs (ragged=%d, rank %d of %d)", ragged, me, n);
-      (void)hipFree(ds);
     }
-    (void)hipFree(dev);
     if (rc) return rc;
   }
   return IPK_OK;

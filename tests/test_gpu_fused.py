@@ -951,3 +951,71 @@ def test_drawn_tasks_in_a_batch_launch(ipa):
     torch.cuda.synchronize()
     for i in range(n):
         assert torch.equal(outs[i].view(torch.int32), want[i].view(torch.int32)), i
+
+
+def test_task_queue_survives_a_launch_that_failed_to_enqueue(ipa, orc):
+    """A launch on a stream handle HIP rejects (the stream was destroyed) must come back as IPK_ERR_HIP -- nothing was enqueued -- and leave the
+    library's task queues as they were: the next launches, on a live stream and large enough to draw tasks, equal the oracle.  (Round 2's queues
+    alternated two counters per stream and a launch that never ran left the next-but-one frame incomplete.)  Runs in a child process: a HIP build
+    that faults on a destroyed handle instead of rejecting it must not take the test session with it."""
+    code = r'''
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, "tests")
+import imagepipe_amd as ipa, oracle, util
+ipa.init(0)
+hip = C.CDLL("libamdhip64.so")
+st = C.c_void_p()
+assert hip.hipStreamCreate(C.byref(st)) == 0
+dead = st.value
+assert hip.hipStreamSynchronize(st) == 0 and hip.hipStreamDestroy(st) == 0
+H, W = 5000, 9000                                   # 45 MP: above the queue's threshold, tasks are drawn
+raw = util.noise_u16(util.SEED + 5, H, W)
+cm = util.cam_matrix()
+plan = ipa.FusedPlan(width=W, height=H, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
+src = ipa.upload_u16(raw)
+out = plan.new_output()
+try:
+    plan.run(src, out, dead)
+    print("NOTE: the destroyed stream was accepted")
+except ipa._lib.IpkError as e:
+    assert e.code == -3, e.code                     # IPK_ERR_HIP
+    print("rejected:", e)
+want = oracle.pipeline_run(oracle.make_pipeline(raw, cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB,
+                                                cam_to_xyz_normalized=cm))
+live = torch.cuda.current_stream().cuda_stream
+for i in range(3):
+    out.zero_()
+    plan.run(src, out, live); torch.cuda.synchronize()
+    util.assert_bits_equal(out.cpu().numpy().reshape(H, W, 3), want, "launch %d after the failed one" % i)
+print("QUEUE_OK")
+'''
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "QUEUE_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_fused_launch_captured_in_a_graph_replays_correctly(ipa, orc):
+    """The fused launch (tasks drawn from the stream's queue) captured into a HIP graph and replayed: every replay finds the queue as the last
+    one left it -- zeroed by its last wave -- so each replay produces the whole frame (round 2's queues broke on the second replay), and a direct
+    launch afterwards is still right.  Nothing is allocated at launch time (capture forbids it)."""
+    import torch
+    H, W = 5000, 9000
+    raw = util.noise_u16(util.SEED + 6, H, W)
+    cm = util.cam_matrix()
+    plan = ipa.FusedPlan(width=W, height=H, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
+    src = ipa.upload_u16(raw)
+    out = plan.new_output()
+    plan.run(src, out); torch.cuda.synchronize()          # warm: the stream's queue slot exists
+    want = torch.from_numpy(orc.pipeline_run(orc.make_pipeline(raw, cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                                                                wb_coeffs=util.WB, cam_to_xyz_normalized=cm)).reshape(-1))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.run(src, out, torch.cuda.current_stream().cuda_stream)
+    for i in range(3):
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(out.cpu().view(torch.int32), want.view(torch.int32)), "replay %d" % i
+    out.zero_()
+    plan.run(src, out); torch.cuda.synchronize()
+    assert torch.equal(out.cpu().view(torch.int32), want.view(torch.int32)), "direct launch after the replays"
