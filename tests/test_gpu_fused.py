@@ -441,6 +441,61 @@ def test_config4_batch_of_64_frames_full_size(ipa, orc):
         del st, pipe
 
 
+def test_config4_batch_launch_full_size_vs_oracle(ipa, orc):
+    """BASELINE.json configs[3] through the path bench.py TIMES: ipk_raw_to_srgb_batch, 64 x 6000x4000 RGGB f32 frames as ONE persistent launch
+    (k_fused_bayer_batch: the queue holds the tasks of all 64 frames).  Six frames spread over the batch -- the first, the last, one next to a
+    frame boundary of the task list -- against the oracle, every sample; every frame against the same frame through a launch of its own; and
+    the same once more with the 8-bit output (the first and the last frame against the oracle's output_8bit)."""
+    import torch
+    H, W, B = 4000, 6000, 64
+    kw = dict(width=W, height=H, is_float=True, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    plan = ipa.FusedPlan(**kw)
+    g = torch.Generator(device="cuda")
+    srcs = []
+    for i in range(B):
+        g.manual_seed(util.SEED + 7000 + i)
+        srcs.append(torch.randint(0, 16384, (H * W,), generator=g, device="cuda", dtype=torch.int32).to(torch.float32))
+    outs = [plan.new_output() for _ in range(B)]
+    batch = ipa.FusedBatchPlan(plan, srcs, outs)
+    batch.run(); torch.cuda.synchronize()
+    for i in (0, 1, 17, 32, 62, 63):
+        raw = srcs[i].cpu().numpy().reshape(H, W)
+        want = torch.from_numpy(orc.pipeline_run(_oracle_desc(orc, raw, "RGGB")).reshape(-1))
+        if not torch.equal(outs[i].cpu().view(torch.int32), want.view(torch.int32)):
+            assert_bits_equal(outs[i].cpu().numpy().reshape(H, W, 3), want.numpy().reshape(H, W, 3), "batch-launch frame %d" % i)
+    alone = plan.new_output()
+    for i in range(B):
+        plan.run(srcs[i], alone); torch.cuda.synchronize()
+        assert torch.equal(alone.view(torch.int32), outs[i].view(torch.int32)), i
+    del outs, alone, batch
+    torch.cuda.empty_cache()
+    plan8 = ipa.FusedPlan(out_type=ipa.OUT_U8, **kw)
+    outs8 = [plan8.new_output() for _ in range(B)]
+    ipa.FusedBatchPlan(plan8, srcs, outs8).run(); torch.cuda.synchronize()
+    one8 = plan8.new_output()
+    for i in range(B):
+        plan8.run(srcs[i], one8); torch.cuda.synchronize()
+        assert torch.equal(one8, outs8[i]), i
+    for i in (0, 63):
+        raw = srcs[i].cpu().numpy().reshape(H, W)
+        assert np.array_equal(outs8[i].cpu().numpy().reshape(H, W, 3), orc.pipeline_output_8bit(_oracle_desc(orc, raw, "RGGB"))), i
+
+
+def test_config5_full_size_f32_mosaic_vs_oracle(ipa, orc):
+    """BASELINE.json configs[4] as BASELINE.md words it -- an f32 mosaic (RawImageData::Float) -- at its real size: 8640x5760 X-Trans, maxwidth 2160
+    -> 2160x1440 through k_raw_scaled_demosaic_w8m<float> and the point-wise chain, the whole output against the oracle.  The samples are 14-bit
+    values plus a fraction, so that the float path is not fed integers only."""
+    H, W = 5760, 8640
+    xt = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+    raw = (util.noise_u16(util.SEED + 41, H, W).astype(np.float32) + util.uniform_f32(util.SEED + 42, H * W).reshape(H, W)).astype(np.float32)
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, xt, is_float=True))
+    pipe.globals.settings.maxwidth = 2160
+    got = pipe.run()
+    assert (got.width, got.height) == (2160, 1440) and not pipe.last_used_fused
+    want = orc.pipeline_run(_oracle_desc(orc, raw, xt, maxwidth=2160))
+    assert_bits_equal(got.numpy(), want, "config 5 full size, f32 mosaic")
+
+
 def test_config5_full_size_vs_oracle(ipa, orc):
     """BASELINE.json configs[4] at its real size: 8640x5760 X-Trans mosaic, maxwidth 2160 -> 2160x1440 through the one-pass
     gofloat+scaled-demosaic kernel and the point-wise chain; the whole output against the oracle (the oracle needs a few seconds)"""

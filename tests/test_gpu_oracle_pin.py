@@ -45,3 +45,13 @@ def test_host_libm_identity_is_recorded():
     v = libc.gnu_get_libc_version().decode()
     assert v and v[0].isdigit()
     print("glibc", v)
+
+
+def test_product_wb_helpers_vs_oracle_on_this_host(orc):
+    """SURVEY 8(f) rank 4 -- ipk_temp_to_xyz / ipk_xyz_to_temp / ipk_tolab_set_temp / ipk_tolab_get_temp -- are host-only maths of the PRODUCT library;
+    their parity test (tests/test_cabi_host.py) is CPU-marked and runs in the build container.  The GPU box's host computes them with its own libm
+    (exp, pow in the Planck spectrum), so the same comparison with the oracle runs here as well and shows up in the driver's GPU record."""
+    import test_cabi_host as H
+    from imagepipe_amd import _lib
+    H.test_wb_temperature_helpers_vs_oracle.__wrapped__(_lib.load(), orc) if hasattr(H.test_wb_temperature_helpers_vs_oracle, "__wrapped__") \
+        else H.test_wb_temperature_helpers_vs_oracle(_lib.load(), orc)
