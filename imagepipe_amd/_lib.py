@@ -28,7 +28,7 @@ class FusedParams(C.Structure):
         ("src_type", C.c_int), ("owidth", _sz),
         ("x", _sz), ("y", _sz), ("width", _sz), ("height", _sz),
         ("black0", C.c_float), ("white0", C.c_float),
-        ("cfa", C.c_char * 160),
+        ("cfa", C.c_char * 160), ("cfa_width", C.c_int), ("cfa_height", C.c_int),
         ("wb_coeffs", C.c_float * 4), ("cam_to_xyz_normalized", C.c_float * 12),
         ("exposure", C.c_float), ("npoints", C.c_int), ("points", C.c_float * 128),
         ("linear", C.c_int), ("out_type", C.c_int),
@@ -40,7 +40,7 @@ class PipelineDesc(C.Structure):
     """ipk_pipeline_desc"""
     _fields_ = [
         ("src_type", C.c_int), ("width", _sz), ("height", _sz),
-        ("cpp", C.c_int), ("is_cfa", C.c_int), ("cfa", C.c_char * 160),
+        ("cpp", C.c_int), ("is_cfa", C.c_int), ("cfa", C.c_char * 160), ("cfa_width", C.c_int), ("cfa_height", C.c_int),
         ("crop_top", _sz), ("crop_right", _sz), ("crop_bottom", _sz), ("crop_left", _sz),
         ("blacklevels", C.c_float * 4), ("whitelevels", C.c_float * 4),
         ("rotatecrop", C.c_float * 5),

@@ -82,11 +82,37 @@ hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 bool dims_ok(size_t w, size_t h) { return w >= 1 && h >= 1 && w < (1ull << 31) && h < (1ull << 31); }
 
-// 16-letter patterns are refused, not guessed: rawloader's tile shape for them is unverified (ipk_host.hpp Cfa::parse)
+// 16-letter patterns without a stated shape are refused, not guessed: rawloader's tile shape for them is unverified (ipk_host.hpp Cfa::parse)
 int cfa_fail(const char *pat) {
   if (ipk::Cfa::unpinned_length(pat))
-    return fail(IPK_ERR_UNSUPPORTED, "16-letter CFA pattern \"%s\": tile shape (8x2 or 2x8) unverified against rawloader, refused", pat);
+    return fail(IPK_ERR_UNSUPPORTED, "16-letter CFA pattern \"%s\": state the tile's shape (\"8x2:...\" / \"2x8:...\", or cfa_width / cfa_height); it is not guessed", pat);
   return fail(IPK_ERR_INVALID, "invalid CFA pattern \"%s\"", pat ? pat : "(null)");
+}
+// A descriptor's pattern with the shape its cfa_width / cfa_height fields state folded into the string (the notation every other entry point
+// takes); the fields are zeroed.  False: the fields contradict a prefix already in the string, or do not fit the buffer.
+#define IPK_FOLD_CFA(T, d) \
+  T d##_folded; \
+  if ((d) && ((d)->cfa_width != 0 || (d)->cfa_height != 0)) { \
+    d##_folded = *(d); \
+    if (!fold_cfa_shape(d##_folded)) return fail(IPK_ERR_INVALID, "cfa_width / cfa_height do not fit the pattern string"); \
+    (d) = &d##_folded; \
+  }
+template <typename Desc>
+static bool fold_cfa_shape(Desc &d) {
+  if (d.cfa_width == 0 && d.cfa_height == 0) return true;
+  if (d.cfa_width < 1 || d.cfa_height < 1 || d.cfa_width > 48 || d.cfa_height > 48) return false;
+  d.cfa[sizeof(d.cfa) - 1] = 0;
+  int w = 0, h = 0; const char *letters = d.cfa;
+  if (!ipk::Cfa::split_dims(d.cfa, w, h, letters)) return false;
+  if (w != 0 && (w != d.cfa_width || h != d.cfa_height)) return false;
+  if (w == 0) {
+    char buf[sizeof(d.cfa) + 16];
+    const int n = std::snprintf(buf, sizeof(buf), "%dx%d:%s", d.cfa_width, d.cfa_height, letters);
+    if (n < 0 || (size_t)n >= sizeof(d.cfa)) return false;
+    std::memcpy(d.cfa, buf, (size_t)n + 1);
+  }
+  d.cfa_width = 0; d.cfa_height = 0;
+  return true;
 }
 
 // device-side tables for one CFA pattern string (uploaded once, cached)
@@ -762,6 +788,7 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
                       size_t nbatch = 0, const void *const *srcs = nullptr, void *const *dsts = nullptr) {
   REQUIRE_INIT();
   if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  IPK_FOLD_CFA(ipk_fused_params, p)
   if (p->src_type != IPK_SRC_U16 && p->src_type != IPK_SRC_F32) return fail(IPK_ERR_INVALID, "fused path takes u16 or f32 CFA data");
   if (!dims_ok(p->width, p->height) || p->owidth < p->x + p->width) return fail(IPK_ERR_INVALID, "bad geometry");
   if (p->out_type < 0 || p->out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
@@ -1074,6 +1101,7 @@ static int pipeline_sizes_impl(const ipk_pipeline_desc *d, size_t *demosaic_w, s
   return IPK_OK;
 }
 int ipk_pipeline_sizes(const ipk_pipeline_desc *d, size_t *demosaic_w, size_t *demosaic_h, size_t *final_w, size_t *final_h) {
+  IPK_FOLD_CFA(ipk_pipeline_desc, d)
   return pipeline_sizes_impl(d, demosaic_w, demosaic_h, final_w, final_h, nullptr);
 }
 
@@ -1176,6 +1204,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   REQUIRE_INIT();
   if (!d || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
   if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  IPK_FOLD_CFA(ipk_pipeline_desc, d)
   if (ipk_pipeline_takes_fastpath(d, out_type) == 1) {
     if (used_fused) *used_fused = 0;
     if (d->width < 1 || d->height < 1) return fail(IPK_ERR_INVALID, "empty source");
@@ -1492,6 +1521,7 @@ ipk::BufHash key_of(const uint8_t *k) { ipk::BufHash b; std::memcpy(b.data(), k,
 
 int ipk_pipeline_hashes(const ipk_pipeline_desc *d, int out_type, uint64_t source_id, uint8_t *out256) {
   if (!out256) return fail(IPK_ERR_INVALID, "null output");
+  IPK_FOLD_CFA(ipk_pipeline_desc, d)
   Negotiated n; int rc = negotiate(d, out_type, n); if (rc) return rc;
   if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
   ipk::BufHash hs[8]; hash_chain(d, n, source_id, hs);
@@ -1545,6 +1575,7 @@ int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_
                             int *ops_run, int *used_fused, void *stream) {
   REQUIRE_INIT();
   if (!d || !src || !dst || !cache) return fail(IPK_ERR_INVALID, "null argument");
+  IPK_FOLD_CFA(ipk_pipeline_desc, d)
   if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
   if (ipk_pipeline_takes_fastpath(d, out_type) == 1) {                    // returns before the cache is consulted (pipeline.rs:381-402)
     if (ops_run) *ops_run = 0;
@@ -1767,6 +1798,7 @@ void host_lanes_release() { std::lock_guard<std::mutex> lk(g_lanes.mu); g_lanes.
 int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type, int *used_fused) {
   REQUIRE_INIT();
   if (!d || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
+  IPK_FOLD_CFA(ipk_pipeline_desc, d)
   for (size_t i = 0; i < n; ++i) if (!srcs[i] || !dsts[i]) return fail(IPK_ERR_INVALID, "null frame pointer at index %zu", i);
   size_t dw, dh, fw, fh;
   HOST_TRY(ipk_pipeline_sizes(d, &dw, &dh, &fw, &fh));

@@ -91,25 +91,48 @@ struct Cfa {
   uint8_t pattern[48][48] = {};
   bool valid() const { return width > 0; }
   int color_at(size_t row, size_t col) const { return pattern[(row + 48) % 48][(col + 48) % 48]; }
-  // CFA::new(patname)
-  static bool unpinned_length(const char *pat) { return pat && std::strlen(pat) == 16; }
+  // CFA::new(patname).  Pattern strings: the letters R G B E (M = G, Y = E) of one tile, row-major.  The tile's shape is
+  //   inferred for 4 (2 x 2), 36 (6 x 6) and 144 (12 x 12) letters, or
+  //   stated by the caller as a prefix "WxH:" -- "2x8:RGBE..." -- which is the only way to pass 16 letters: rawloader 0.37 is absent from
+  //   /root/reference, its tile shape for that length could not be verified (imagepipe's `8 => 2.0` minscale arm, demosaic.rs:36-37, says 8 wide;
+  //   dcraw's filter tables are 2 wide x 8 high), and the caller has the answer in hand (its CFA object's width and height, demosaic.rs:33).
+  // W and H must divide 48 (the reference tiles every pattern into 48 x 48, demosaic.rs:77-90 / color_at's `% 48`).
+  static bool split_dims(const char *pat, int &w, int &h, const char *&letters) {
+    w = h = 0; letters = pat;
+    const char *colon = pat ? std::strchr(pat, ':') : nullptr;
+    if (!colon) return true;
+    int v[2] = {0, 0}, k = 0, digits = 0;
+    for (const char *q = pat; q < colon; ++q) {
+      if (*q >= '0' && *q <= '9') { v[k] = v[k] * 10 + (*q - '0'); if (++digits > 2) return false; }
+      else if (*q == 'x' && k == 0 && digits > 0) { k = 1; digits = 0; }
+      else return false;
+    }
+    if (k != 1 || digits == 0) return false;
+    w = v[0]; h = v[1]; letters = colon + 1;
+    return w >= 1 && h >= 1 && w <= 48 && h <= 48 && 48 % w == 0 && 48 % h == 0;
+  }
+  static bool unpinned_length(const char *pat) { return pat && !std::strchr(pat, ':') && std::strlen(pat) == 16; }
   static bool parse(const char *pat, Cfa &out) {
-    const size_t len = pat ? std::strlen(pat) : 0;
     out = Cfa();
-    switch (len) {
-      case 0: return true;
-      case 4: out.width = 2; out.height = 2; break;
-      case 36: out.width = 6; out.height = 6; break;
-      // 16 letters: rawloader 0.37 is absent from /root/reference and its tile shape for this length is unverified (8 wide x 2
-      // high as imagepipe's `8 => 2.0` minscale arm suggests, or dcraw's 2 wide x 8 high); no reference test constructs one.
-      // Rejected (IPK_ERR_UNSUPPORTED at the API) rather than guessed -- DESIGN.md section 7.
-      case 16: return false;
-      case 144: out.width = 12; out.height = 12; break;
-      default: return false;
+    int w = 0, h = 0; const char *letters = pat;
+    if (pat && !split_dims(pat, w, h, letters)) return false;
+    const size_t len = letters ? std::strlen(letters) : 0;
+    if (w == 0) {
+      switch (len) {
+        case 0: return true;
+        case 4: out.width = 2; out.height = 2; break;
+        case 36: out.width = 6; out.height = 6; break;
+        case 16: return false;          // shape not stated: refused (IPK_ERR_UNSUPPORTED at the API) rather than guessed
+        case 144: out.width = 12; out.height = 12; break;
+        default: return false;
+      }
+    } else {
+      if ((size_t)w * (size_t)h != len) return false;
+      out.width = w; out.height = h;
     }
     for (size_t i = 0; i < len; ++i) {
       uint8_t v;
-      switch (pat[i]) {
+      switch (letters[i]) {
         case 'R': v = 0; break; case 'G': v = 1; break; case 'B': v = 2; break; case 'E': v = 3; break;
         case 'M': v = 1; break; case 'Y': v = 3; break;
         default: return false;
@@ -120,10 +143,13 @@ struct Cfa {
       for (int c = 0; c < 48; ++c) out.pattern[r][c] = out.pattern[r % out.height][c % out.width];
     return true;
   }
+  // whether a plain string of width*height letters would be read back with this shape
+  bool shape_is_inferred() const { return width == height && (width == 2 || width == 6 || width == 12); }
   // CFA::shift(x, y) as used by cropped_cfa()
   std::string shifted_name(int x, int y) const {
     static const char names[4] = {'R', 'G', 'B', 'E'};
     std::string s;
+    if (!shape_is_inferred()) s = std::to_string(width) + "x" + std::to_string(height) + ":";
     for (int r = 0; r < height; ++r)
       for (int c = 0; c < width; ++c) s.push_back(names[color_at(size_t(r + y), size_t(c + x))]);
     return s;

@@ -122,9 +122,13 @@ IPK_API int ipk_spline_new(const float *pts, int npts, float *px, float *py, flo
  * crop_bottom, crop_left, rotation */
 IPK_API int ipk_rotatecrop_calc_size(const float *params5, float input_ratio, size_t width, size_t height,
                                      int reverse, size_t *nwidth, size_t *nheight);
-/* rawloader CFA::shift as used by RawImage::cropped_cfa() (call site src/ops/demosaic.rs:13).  Pattern strings: 4 (2x2), 36 (6x6) or 144
- * (12x12) letters R G B E (M = G, Y = E), row-major.  16-letter patterns return IPK_ERR_UNSUPPORTED here and everywhere else: rawloader's
- * tile shape for them (8x2 or 2x8) cannot be verified without its source. */
+/* rawloader CFA::shift as used by RawImage::cropped_cfa() (call site src/ops/demosaic.rs:13).
+ * Pattern strings, here and in every entry point that takes one: the letters R G B E (M = G, Y = E) of one tile, row-major.  The tile's shape
+ * is inferred from 4 (2x2), 36 (6x6) or 144 (12x12) letters, or STATED by the caller in front of them as "WxH:" (W columns, H rows, both
+ * dividing 48 -- the reference tiles every pattern into 48x48): "2x8:RGBGRGBG..." -- the caller's CFA object knows its width and height
+ * (src/ops/demosaic.rs:33).  16 letters WITHOUT a stated shape return IPK_ERR_UNSUPPORTED: rawloader's shape for them (8 wide x 2 high as
+ * imagepipe's minscale arm suggests, or dcraw's 2 x 8) cannot be verified without its source, and a wrong guess would pass every test.
+ * The shifted pattern comes back in the same notation (with the prefix unless the shape is one the letter count implies). */
 IPK_API int ipk_cfa_shift(const char *pattern, int x, int y, char *out /* >= strlen+1 */);
 /* Orientation::to_flips / from_flips (call sites src/ops/transform.rs:58-66,106);
  * flips3 = transpose, flip_x, flip_y */
@@ -253,7 +257,9 @@ typedef struct {
   size_t owidth;                   /* RawImage.width: row pitch of src in elements */
   size_t x, y, width, height;      /* OpGoFloat::size_image result */
   float black0, white0;            /* blacklevels[0], whitelevels[0] (gofloat.rs:126) */
-  char cfa[160];                   /* cropped CFA pattern (OpDemosaic.cfa) */
+  char cfa[160];                   /* cropped CFA pattern (OpDemosaic.cfa): letters, or "WxH:letters" (see ipk_cfa_shift) */
+  int cfa_width, cfa_height;       /* the tile's shape as the caller's CFA object has it (cfa.width / cfa.height, src/ops/demosaic.rs:33); 0, 0 = take
+                                      it from the string (a "WxH:" prefix, or the letter count 4 / 36 / 144).  16 letters need one of the two. */
   float wb_coeffs[4];              /* OpToLab.wb_coeffs (normalised again inside, colorspaces.rs:100) */
   float cam_to_xyz_normalized[12]; /* OpToLab.cam_to_xyz_normalized, [[f32;4];3] row-major */
   float exposure;                  /* OpBaseCurve.exposure */
@@ -269,7 +275,7 @@ typedef struct {
 
 /* src: device pointer to the sensor data (element (0,0) of the uncropped frame, or of the band's
  * first source row); dst: device pointer to width*rows*3 elements of out_type.
- * Any colour filter without a fourth colour is accepted (the four RGGB phases, X-Trans, 12x12 ...; 16-letter patterns are refused, see ipk_cfa_shift); fails with
+ * Any colour filter without a fourth colour is accepted (the four RGGB phases, X-Trans, 12x12, 16 letters with a stated shape ...; pattern strings: see ipk_cfa_shift); fails with
  * IPK_ERR_UNSUPPORTED for RGBE-style filters (callers then run the staged ops). */
 IPK_API int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream);
 /* n frames of ONE shape and ONE parameter set (a caller looping Pipeline::run over a shoot, src/pipeline.rs:246-249: frames are independent;
@@ -316,7 +322,8 @@ typedef struct {
   size_t width, height;            /* RawImage.width/height or raster dims */
   int cpp;                         /* RawImage.cpp (1 or 3); ignored for RGB8/RGB16 */
   int is_cfa;                      /* OpGoFloat.is_cfa */
-  char cfa[160];                   /* OpDemosaic.cfa = cropped_cfa() ("" for Other) */
+  char cfa[160];                   /* OpDemosaic.cfa = cropped_cfa() ("" for Other): letters, or "WxH:letters" */
+  int cfa_width, cfa_height;       /* as in ipk_fused_params: the tile's shape from the caller's CFA object, 0, 0 = from the string */
   size_t crop_top, crop_right, crop_bottom, crop_left;   /* OpGoFloat crops */
   float blacklevels[4], whitelevels[4];
   float rotatecrop[5];             /* OpRotateCrop: crop_top, crop_right, crop_bottom, crop_left, rotation */

@@ -294,23 +294,41 @@ ORC_API void orc_lab_to_rgb(const float *m9, const float *in3, float *out3, size
 /* ------------------------------------------------------------------------------------ */
 typedef struct { int width, height; int pattern[48][48]; } orc_cfa;
 
-/* CFA::new(patname): 4->2x2, 36->6x6, 16->8 wide x 2 high (demosaic.rs:36-37 "8x2 pattern"),
- * 144->12x12; row-major letters; tiled to 48x48.  Returns 0 or -1 on an invalid string. */
+/* CFA::new(patname): row-major letters of one tile, tiled to 48x48.  4 -> 2x2, 36 -> 6x6, 144 -> 12x12; any other shape -- 16 letters
+ * in particular, whose shape in rawloader (8 wide x 2 high per demosaic.rs:36-37, or dcraw's 2 x 8) cannot be verified here -- only with
+ * the caller's statement of it as a prefix "WxH:" (W, H dividing 48), the same contract as the product's.  Returns 0 or -1. */
 static int cfa_new(const char *pat, orc_cfa *c) {
-  size_t len = strlen(pat);
   memset(c, 0, sizeof(*c));
-  switch (len) {
-    case 0: c->width = 0; c->height = 0; return 0;
-    case 4: c->width = 2; c->height = 2; break;
-    case 36: c->width = 6; c->height = 6; break;
-    /* 16 letters: tile shape (8x2 or dcraw's 2x8) cannot be verified here -- rawloader is absent; refused like the product */
-    case 16: return -1;
-    case 144: c->width = 12; c->height = 12; break;
-    default: return -1;
+  int w = 0, h = 0;
+  const char *letters = pat, *colon = strchr(pat, ':');
+  if (colon) {
+    int v[2] = {0, 0}, k = 0, digits = 0;
+    for (const char *q = pat; q < colon; q++) {
+      if (*q >= '0' && *q <= '9') { v[k] = v[k] * 10 + (*q - '0'); if (++digits > 2) return -1; }
+      else if (*q == 'x' && k == 0 && digits > 0) { k = 1; digits = 0; }
+      else return -1;
+    }
+    if (k != 1 || digits == 0) return -1;
+    w = v[0]; h = v[1]; letters = colon + 1;
+    if (w < 1 || h < 1 || w > 48 || h > 48 || 48 % w || 48 % h) return -1;
+  }
+  size_t len = strlen(letters);
+  if (w == 0) {
+    switch (len) {
+      case 0: c->width = 0; c->height = 0; return 0;
+      case 4: c->width = 2; c->height = 2; break;
+      case 36: c->width = 6; c->height = 6; break;
+      case 16: return -1;                       /* shape not stated: refused like the product */
+      case 144: c->width = 12; c->height = 12; break;
+      default: return -1;
+    }
+  } else {
+    if ((size_t)w * (size_t)h != len) return -1;
+    c->width = w; c->height = h;
   }
   for (size_t i = 0; i < len; i++) {
     int v;
-    switch (pat[i]) {
+    switch (letters[i]) {
       case 'R': v = 0; break; case 'G': v = 1; break; case 'B': v = 2; break; case 'E': v = 3; break;
       case 'M': v = 1; break; case 'Y': v = 3; break;
       default: return -1;
@@ -331,6 +349,7 @@ ORC_API int orc_cfa_shift(const char *pat, int x, int y, char *out) {
   orc_cfa c; if (cfa_new(pat, &c)) return -1;
   static const char names[4] = {'R', 'G', 'B', 'E'};
   int n = 0;
+  if (!(c.width == c.height && (c.width == 2 || c.width == 6 || c.width == 12))) n = sprintf(out, "%dx%d:", c.width, c.height);
   for (int row = 0; row < c.height; row++)
     for (int col = 0; col < c.width; col++)
       out[n++] = names[cfa_color_at(&c, (size_t)(row + y), (size_t)(col + x))];

@@ -118,11 +118,18 @@ def test_cfa_shift_and_orientation(L, orc):
                 assert out.value.decode() == orc.cfa_shift(pat, x, y)
     assert orc.cfa_shift("RGGB", 1, 0) == "GRBG" and orc.cfa_shift("RGGB", 0, 1) == "GBRG" and orc.cfa_shift("RGGB", 1, 1) == "BGGR"
     assert L.ipk_cfa_shift(b"RGXB", 0, 0, out) == -2
-    # 16 letters: the tile shape (8x2 or 2x8) is unverified against rawloader -- refused by product and oracle alike
+    # 16 letters: the tile shape (8x2 or 2x8) is unverified against rawloader -- refused by product and oracle alike unless the caller states it
     assert L.ipk_cfa_shift(b"RGGBGRBGGBRGBGGR", 0, 0, out) == -5            # IPK_ERR_UNSUPPORTED
     assert b"16-letter" in L.ipk_last_error()
     with pytest.raises(Exception):
         orc.cfa_shift("RGGBGRBGGBRGBGGR", 0, 0)
+    for pat in ["2x8:RGBGRBGGGBGRGRBG", "8x2:RGBGRBGGGBGRGRBG", "4x4:RGBGRBGGGBGRGRBG", "2x2:RGGB", "6x6:" + xt, "2x4:RGGBRGBG", "16x1:RGBGRBGGGBGRGRBG"]:
+        for x in range(9):
+            for y in range(9):
+                assert L.ipk_cfa_shift(pat.encode(), x, y, out) == 0, pat
+                assert out.value.decode() == orc.cfa_shift(pat, x, y)
+    for bad in [b"5x2:RGBGRGBGRG", b"2x8:RGGB", b"x8:RGGBGRBGGBRGBGGR", b"2x:RGGB", b"2x8RGGB", b"0x4:", b"2x8:RGBGRBGGGBGRGRBX"]:
+        assert L.ipk_cfa_shift(bad, 0, 0, out) == -2, bad
     f = (C.c_int * 3)()
     for o in range(9):
         L.ipk_orientation_to_flips(o, f)

@@ -209,8 +209,12 @@ def test_fused_generic_cfa_vs_oracle(ipa, orc, cfa, shape, is_float):
     assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(hh, ww, 3), orc.pipeline_output_16bit(_oracle_desc(orc, src, cfa, crops=crops)))
 
 
-def test_sixteen_letter_cfa_is_refused(ipa, orc):
-    """rawloader's tile shape for a 16-letter pattern (8x2 or 2x8) cannot be verified here: product and oracle refuse it"""
+L16 = "RGBGRBGGGBGRGRBG"                                    # sixteen letters without symmetry: 2 wide x 8 high and 8 wide x 2 high are different filters
+
+
+def test_sixteen_letter_cfa_without_a_stated_shape_is_refused(ipa, orc):
+    """rawloader's tile shape for a 16-letter pattern (8x2 or 2x8) cannot be verified here: without the caller's statement of it, product and
+    oracle refuse the string instead of guessing"""
     raw = util.noise_u16(util.SEED + 81, 32, 300)
     with pytest.raises(ipa.IpkError) as e:                              # OpDemosaic::new's cropped_cfa() is the first to parse it
         ipa.Pipeline.new_from_source(_raw(ipa, raw, W16)).run()
@@ -221,6 +225,47 @@ def test_sixteen_letter_cfa_is_refused(ipa, orc):
     assert e.value.code == -5
     with pytest.raises(Exception):
         orc.pipeline_run(_oracle_desc(orc, raw, W16))
+
+
+@pytest.mark.parametrize("shape_prefix", ["2x8:", "8x2:", "4x4:"])
+@pytest.mark.parametrize("is_float", [False, True])
+def test_sixteen_letter_cfa_with_the_callers_shape(ipa, orc, shape_prefix, is_float):
+    """The same sixteen letters read 2 wide x 8 high (dcraw's layout), 8 wide x 2 high (what imagepipe's `8 => 2.0` minscale arm describes,
+    demosaic.rs:36-37) and 4 x 4, the shape stated by the caller: the fused kernel (generic-CFA mode, pattern 2x8 / 8x2 / 4x4), the staged ops, a
+    cropped frame (cropped_cfa() keeps the shape) and a downscaled one (scaled_demosaic; minscale from cfa.width) against the oracle -- whose own
+    known answers for the two readings are hand-derived in tests/test_oracle_second_restatement.py -- and the three readings differ from each other."""
+    import torch
+    cfa = shape_prefix + L16
+    H, W = 70, 530
+    src = util.noise_u16(util.SEED + 83, H, W)
+    raw = src.astype(np.float32) if is_float else src
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa, is_float=is_float))
+    got = pipe.run()
+    assert pipe.last_used_fused
+    want = orc.pipeline_run(_oracle_desc(orc, raw, cfa))
+    assert_bits_equal(got.numpy(), want, "fused, " + cfa)
+    pipe.allow_fused = False
+    assert_bits_equal(pipe.run().numpy(), want, "staged, " + cfa)
+    others = [orc.pipeline_run(_oracle_desc(orc, raw, p + L16)) for p in ("2x8:", "8x2:", "4x4:") if p != shape_prefix]
+    assert all(not np.array_equal(want, o) for o in others)
+    # the shape through the descriptor's fields instead of the string (what a Rust caller copies from its CFA object)
+    w_, h_ = (int(v) for v in shape_prefix[:-1].split("x"))
+    plan = ipa.FusedPlan(width=W, height=H, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa=L16, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    plan.params.cfa_width, plan.params.cfa_height = w_, h_
+    dev = torch.from_numpy(np.ascontiguousarray(raw).ravel()).cuda() if is_float else ipa.upload_u16(raw)
+    out = plan.run(dev, plan.new_output()); torch.cuda.synchronize()
+    assert_bits_equal(out.cpu().numpy().reshape(H, W, 3), want, "cfa_width / cfa_height fields, " + cfa)
+    plan.params.cfa_width, plan.params.cfa_height = h_ + 1, w_
+    with pytest.raises(ipa.IpkError):
+        plan.run(dev, plan.new_output())
+    # crops shift the pattern (cropped_cfa) and keep its stated shape
+    crops = (3, 2, 1, 5)
+    pc = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa, is_float=is_float, crops=crops))
+    assert_bits_equal(pc.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa, crops=crops)), "cropped, " + cfa)
+    # a size limit: OpDemosaic's scaled branch, entered at scale >= minscale(cfa.width) -- 2.0 for widths 2 and 8 and, by the default arm, 4
+    ps = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa, is_float=is_float))
+    ps.globals.settings.maxwidth = 130
+    assert_bits_equal(ps.run().numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa, maxwidth=130)), "scaled, " + cfa)
 
 
 def test_fused_generic_cfa_specials_take_the_literal_form(ipa, orc):

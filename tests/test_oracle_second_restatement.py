@@ -14,9 +14,16 @@ XTRANS = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
 
 
 def _color_at(pat):
-    side = {4: 2, 36: 6, 144: 12}[len(pat)]
-    tile = [["RGBE".index(c) for c in pat[r * side:(r + 1) * side]] for r in range(side)]
-    return lambda row, col: tile[row % side][col % side]
+    """rawloader's CFA as the reference uses it (demosaic.rs:80,86; scaling.rs:110): letters row-major over a width x height tile; the shape is
+    implied by 4 / 36 / 144 letters or stated as "WxH:" in front of them (the only way to pass 16 letters)"""
+    if ":" in pat:
+        dims, pat = pat.split(":")
+        wide, high = (int(v) for v in dims.split("x"))
+        assert wide * high == len(pat)
+    else:
+        wide = high = {4: 2, 36: 6, 144: 12}[len(pat)]
+    tile = [["RGBE".index(c) for c in pat[r * wide:(r + 1) * wide]] for r in range(high)]
+    return lambda row, col: tile[row % high][col % wide]
 
 
 def _full(pat, buf):
@@ -108,14 +115,19 @@ def test_gofloat_run_raw_hand_values(orc):
     assert g2.shape == (10, 10) and g2[0, 0] == np.float32(raw[1, 3]) / np.float32(4095.0) and g2[9, 9] == np.float32(raw[10, 12]) / np.float32(4095.0)
 
 
-@pytest.mark.parametrize("pat,h,w", [("RGGB", 11, 13), ("GBRG", 10, 12), ("RGBE", 10, 11), (XTRANS, 13, 14)])
+L16 = "RGBGRBGGGBGRGRBG"                        # sixteen letters, no symmetry: read 2 wide x 8 high and 8 wide x 2 high they are different filters
+
+
+@pytest.mark.parametrize("pat,h,w", [("RGGB", 11, 13), ("GBRG", 10, 12), ("RGBE", 10, 11), (XTRANS, 13, 14), ("2x8:" + L16, 19, 13), ("8x2:" + L16, 11, 21),
+                                     ("4x4:" + L16, 10, 10)])
 def test_demosaic_full_against_a_second_restatement(orc, pat, h, w):
     buf = util.uniform_f32(util.SEED + 900 + h, h * w, -0.05, 1.0).reshape(h, w)
     buf[2, 3] = np.float32(-0.0); buf[5, 5] = 0.0
     util.assert_bits_equal(orc.demosaic_full(pat, buf), _full(pat, buf), "demosaic::full %s" % pat[:4])
 
 
-@pytest.mark.parametrize("pat,h,w,nh,nw", [("RGGB", 24, 30, 6, 7), (XTRANS, 36, 30, 9, 7), ("GRBG", 20, 22, 10, 11)])
+@pytest.mark.parametrize("pat,h,w,nh,nw", [("RGGB", 24, 30, 6, 7), (XTRANS, 36, 30, 9, 7), ("GRBG", 20, 22, 10, 11), ("2x8:" + L16, 40, 30, 10, 7),
+                                           ("8x2:" + L16, 24, 40, 8, 13)])
 def test_scaled_demosaic_against_a_second_restatement(orc, pat, h, w, nh, nw):
     buf = util.uniform_f32(util.SEED + 950 + h, h * w, -0.05, 1.0).reshape(h, w)
     want = _transform_buffer(buf.ravel(), w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, 4, pat).reshape(nh, nw, 4)
@@ -409,3 +421,45 @@ def test_white_balance_helpers_against_a_second_restatement(orc):
         t, ti = _xyz_to_temp(acc)
         got = orc.tolab_get_temp(cam_to_xyz, np.array(wbv, np.float32))
         assert (np.float32(got[0]), np.float32(got[1])) == (t, ti), (wbv, got, t, ti)
+
+
+def test_sixteen_letter_patterns_known_answers(orc):
+    """Hand-derived known answers for a 16-letter filter under both shapes a caller may state (rawloader's own shape for 16 letters cannot be
+    checked here, so the caller states it: "2x8:" / "8x2:").  Letters L16 = R G B G R B G G G B G R G R B G.
+      2 wide x 8 high: tile rows  RG / BG / RB / GG / GB / GR / GR / BG        8 wide x 2 high: tile rows  RGBGRBGG / GBGRGRBG
+    (1) colour of a pixel: (row 2, col 1) is B in the first reading (third tile row "RB"), G in the second (row 2 = tile row 0, col 1);
+        (row 1, col 5) is G ("BG", col 5 % 2 = 1) against R ("GBGRGRBG"[5]).
+    (2) demosaic::full of a mosaic whose every sample is 10 x (colour index + 1) -- 10 on R, 20 on G, 30 on B sites: a colour that has a tap in
+        a pixel's 3x3 neighbourhood comes out as exactly its constant (mean of equal values), a colour without one stays 0.0 (demosaic.rs:110-114).
+        At (row 3, col 0) -- a G site in both readings -- the 2x8 neighbourhood is  R B / G G / G B  (cols 0..1 and the wrapped col -1 = col 1 of
+        the tile): R, G, B all present -> (10, 20, 30, 0).  In the 8x2 reading row 3 is tile row 1 and the neighbourhood of col 0 -- cols 7, 0, 1 of
+        the tile rows 0, 1, 0 -- is  G R G / G G B / G R G: also all three.  At (row 4, col 3): 2x8 reads rows 3..5 = GG / GB / GR, cols 2..4 ->
+        G G G / G B G / G R G -> own colour B = 30, G = 20, R = 10.  8x2 reads tile rows 1, 0, 1 at cols 2, 3, 4 -> G R G / B G R / G R G: the
+        centre is G (own value 20), R present (10), B present (30).
+    (3) a single bright sample: the filters disagree about which channel it lands in -- a 1000 at (row 2, col 1) is B (2x8) or G (8x2)."""
+    two, eight = "2x8:" + L16, "8x2:" + L16
+    (w2, pat2), (w8, pat8) = orc.cfa_pattern(two), orc.cfa_pattern(eight)
+    assert (w2, w8) == (2, 8)                                         # cfa.width, which picks OpDemosaic's minscale arm (demosaic.rs:33-39)
+    assert pat2[2, 1] == 2 and pat8[2, 1] == 1 and pat2[1, 5] == 1 and pat8[1, 5] == 0
+    assert [int(v) for v in pat2[:8, :2].ravel()] == ["RGBE".index(c) for c in L16] and [int(v) for v in pat8[:2, :8].ravel()] == ["RGBE".index(c) for c in L16]
+    h, w = 16, 16
+    for name, pat in ((two, pat2), (eight, pat8)):
+        mosaic = (10.0 * (pat[:h, :w] + 1)).astype(np.float32)
+        out = orc.demosaic_full(name, mosaic)
+        for (r, c) in ((3, 0), (4, 3), (8, 8), (5, 9)):
+            window = pat[r - 1:r + 2, max(c - 1, 0):c + 2]
+            want = [10.0 * (k + 1) if (window == k).any() else 0.0 for k in range(3)] + [0.0]
+            assert out[r, c].tolist() == want, (name, r, c, out[r, c], want)
+    assert orc.demosaic_full(two, (10.0 * (pat2[:h, :w] + 1)).astype(np.float32))[3, 0].tolist() == [10.0, 20.0, 30.0, 0.0]
+    assert orc.demosaic_full(eight, (10.0 * (pat8[:h, :w] + 1)).astype(np.float32))[4, 3].tolist() == [10.0, 20.0, 30.0, 0.0]
+    spike = np.zeros((h, w), np.float32); spike[2, 1] = 1000.0
+    o2, o8 = orc.demosaic_full(two, spike), orc.demosaic_full(eight, spike)
+    assert o2[2, 1].tolist() == [0.0, 0.0, 1000.0, 0.0] and o8[2, 1].tolist() == [0.0, 1000.0, 0.0, 0.0]
+    # cropped_cfa(): shifting keeps the stated shape in the string; a square 4x4 reading needs the prefix too (16 letters are never guessed)
+    assert orc.cfa_shift(two, 0, 0) == two and orc.cfa_shift(eight, 0, 0) == eight and orc.cfa_shift("2x2:RGGB", 1, 0) == "GRBG"
+    assert orc.cfa_shift(two, 1, 0) == "2x8:" + "".join(L16[2 * r + (c + 1) % 2] for r in range(8) for c in range(2))
+    assert orc.cfa_shift(eight, 0, 1) == "8x2:" + L16[8:] + L16[:8]
+    with pytest.raises(Exception):
+        orc.cfa_shift(L16, 0, 0)
+    with pytest.raises(Exception):
+        orc.cfa_shift("5x2:RGBGRGBGRG", 0, 0)                          # 5 does not divide 48
