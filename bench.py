@@ -323,20 +323,30 @@ def copy_ceiling(ctx, nbytes):
     return own, tch
 
 
-def valu_model(kernel_ms):
-    """The VALU-issue model of the fused kernel: dynamic instruction counts per launch by issue class
-    (rocprofv3 PMC + the class split of the hot loop's disassembly) x the measured issue cost per class (tools/ubench2.hip),
-    spread over the chip's SIMDs -- everything taken from the tracked file profiles/r*_valu_model.json."""
+def valu_model(kernel_ms, data):
+    """The VALU-issue account of the fused kernel from the tracked file profiles/r*_valu_model.json (tools/evidence_r03.sh):
+    dynamic instruction counts per launch by class (rocprofv3 PMC), priced two ways with tools/ubench2.hip's figures -- `interleaved`: at the cost
+    of one instruction of a loop with the kernel's kind of mix, where half-rate instructions hide behind full-rate ones (the issue time if the
+    kernel interleaved as well); `additive`: every class at the cost of a loop of nothing else (an upper bound) -- plus the model-free wave-cycle
+    ratio and the stall split.  frac = interleaved issue time / this run's kernel time."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_model.json")))
     if not files:
         return None
     try:
         m = json.load(open(files[-1]))
-        pred = m["predicted_ms"]
-        return {"bound": "valu-issue", "insts_per_launch": m["insts_per_launch"], "ns_per_wave_inst": m["ns_per_wave_inst"], "simds": m["simds"],
-                "predicted_ms": pred, "measured_ms": round(kernel_ms, 4), "frac": round(pred / kernel_ms, 4),
-                "note": "predicted = sum(class count x class issue ns) / SIMDs: the time the VALU needs just to issue the kernel's instructions; "
-                        "frac = predicted / measured (1.0 = VALU-issue-bound)", "source": os.path.relpath(files[-1], ROOT)}
+        if data not in m:                                     # round-2 layout: one model, additive pricing only
+            pred = m["predicted_ms"]
+            return {"bound": "valu-issue", "issue_ms": {"additive": pred}, "measured_ms": round(kernel_ms, 4), "frac": round(pred / kernel_ms, 4),
+                    "source": os.path.relpath(files[-1], ROOT)}
+        d = m[data]
+        out = {"bound": "valu-issue", "valu_per_pixel": d.get("valu_per_pixel"), "valu_insts_per_launch": d.get("valu_total_per_launch"),
+               "issue_ms": {"interleaved": d.get("issue_ms_interleaved"), "additive": d.get("issue_ms_additive")}, "measured_ms": round(kernel_ms, 4),
+               "frac": round(d["issue_ms_interleaved"] / kernel_ms, 4), "frac_additive": round(d["issue_ms_additive"] / kernel_ms, 4),
+               "wave_cycles_per_valu": d.get("wave_cycles_per_valu"), "stall_split": d.get("stall_split"),
+               "note": "frac: the time the VALU needs to issue the kernel's instructions if half-rate ones hide behind full-rate ones as in a pure-VALU loop of the "
+                       "same mix, over the measured time; frac_additive prices every class alone (upper bound); wave_cycles_per_valu.ratio is model-free",
+               "source": os.path.relpath(files[-1], ROOT)}
+        return out
     except Exception as e:      # a malformed evidence file must not take the bench line down
         return {"error": repr(e)}
 
@@ -430,7 +440,7 @@ def main():
                     result["roofline"]["traffic_source"] = os.path.relpath(profs[-1], ROOT)
             except Exception:
                 pass
-        vm = valu_model(kernel_ms)
+        vm = valu_model(kernel_ms, args.data)
         if vm:
             result["roofline_valu"] = vm
 

@@ -70,6 +70,10 @@ using namespace ipkd;
 #ifndef IPK_OPT_FAIRPRIO
 #define IPK_OPT_FAIRPRIO 1
 #endif
+//   IPK_OPT_W8M_XCD    config 5's scaled-demosaic kernel launched so that neighbouring output rows run on one XCD (see k_raw_scaled_demosaic_w8m)
+#ifndef IPK_OPT_W8M_XCD
+#define IPK_OPT_W8M_XCD 1
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -365,6 +369,9 @@ struct TransformArgs {
   // output-row band [out_r0, out_r1) of the fused gofloat + scaled_demosaic kernels (multi-GPU sharding of one frame):
   // dst row 0 = output row out_r0; the source slab's first row is folded into src_y (which may wrap: pointer arithmetic mod 2^64)
   uint32_t out_r0, out_r1;
+  // k_raw_scaled_demosaic_w8m: a one-dimensional launch of xcd_gx x xcd_gy blocks (xcd_gy a multiple of 8) laid out so that each XCD works on one
+  // contiguous eighth of the block rows (see the kernel); 0 = the plain two-dimensional grid
+  uint32_t xcd_gx, xcd_gy, xcd_group;
 };
 // (v - center) / skip  (scaling.rs:104-105): cdiv_fast when the host validated the divisor and the dividend is in the proven
 // zone, the IEEE division otherwise (zero or negative skips of degenerate / rotated transforms, absurd centres)
@@ -751,7 +758,25 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
     s_bits[i] = (uint16_t)bits;
   }
   __syncthreads();
-  const uint32_t col_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  // Which block takes which columns and rows.  Output row r reads the source rows floor(skip r) .. floor(skip (r + 1)), so rows r and r + 1 share
+  // one (five rows for every four at scale 4: 1.22x the frame in HBM fetches, profiles/r02_c5_pmc.json).  The hardware deals consecutive block ids
+  // to the eight XCDs in turn, each with its own L2; with a plain gx x gy grid (gx = 9 for a 2160-pixel row) the blocks of neighbouring rows
+  // always land on different XCDs and both fetch the shared row.  Launched one-dimensionally (IPK_OPT_W8M_XCD), block id b belongs to XCD b % 8 and
+  // is the (b / 8)-th block there; runs of `xcd_group` neighbouring block rows go to one XCD, the next run to the next XCD, so that inside a run
+  // the second reader of a shared source row finds it in that XCD's L2.  Measured (50 MP X-Trans -> 2160x1440, FETCH_SIZE x 2 + WRITE_SIZE over
+  // the algorithmic 248.8 MB; kernel time on one box): plain grid 1.22x, 0.0595 ms; runs of 1 / 2 / 4 / 8 / 16 / 74 (an eighth of the frame per XCD)
+  // rows: 1.20x 0.0594 | 1.11x 0.0593 | 1.06x 0.0596 | 1.04x 0.0600 | -- 0.0636 | 1.01x 0.059-0.067 (box to box).  Long runs save traffic the
+  // kernel is not waiting for -- it is bound by VALU issue (46.6 M instructions per launch = 48 us of its 57) -- and cost time on some boxes;
+  // runs of 2 take the traffic to 1.11x at no cost.
+  uint32_t blk_x = blockIdx.x, blk_y = blockIdx.y, rows_step = gridDim.y;
+  if (a.xcd_gx != 0) {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t per_group = a.xcd_group * a.xcd_gx, gi = j / per_group, rem = j - gi * per_group;
+    blk_x = rem % a.xcd_gx;
+    blk_y = (gi * 8u + xcd) * a.xcd_group + rem / a.xcd_gx;
+    rows_step = a.xcd_gy;
+  }
+  const uint32_t col_raw = blk_x * blockDim.x + threadIdx.x;
   const bool lane_in = col_raw < a.nwidth;
   const uint32_t col = min(col_raw, a.nwidth - 1);
   const uint32_t from_x = min(a.width - 1, f32_as_u32_sat(floorf(a.tlx + (a.skip_x_x * (float)col))));
@@ -786,14 +811,14 @@ __global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(
   };
   auto next_of = [&](const Cur &c) -> Cur {
     if (c.y < c.ty) return Cur{c.row, c.y + 1, c.ty, true};
-    const uint32_t nr = c.row + gridDim.y;
+    const uint32_t nr = c.row + rows_step;
     if (nr >= a.out_r1) return Cur{c.row, c.y, c.ty, false};            // past the end: re-reads a valid row, never consumed
     uint32_t f, tt; ywin(nr, f, tt);
     return Cur{nr, f, tt, true};
   };
   auto rowptr = [&](uint32_t y) { return src + (size_t)((uint64_t)y + a.src_y) * a.src_pitch + a.src_x + lx; };
   auto centre = [&](uint32_t r) { return a.tly + (a.skip_y_y * (float)r) + (a.skip_y_y / 2.0f) - 0.5f + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f); };
-  Cur c0; c0.row = a.out_r0 + blockIdx.y; c0.valid = true;
+  Cur c0; c0.row = a.out_r0 + blk_y; c0.valid = true;
   if (c0.row >= a.out_r1) return;
   ywin(c0.row, c0.y, c0.ty);
   typename Row8<T>::Raw cur = Row8<T>::issue(rowptr(c0.y));
@@ -917,6 +942,7 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   a.out_r0 = 0; a.out_r1 = (uint32_t)nheight;
   if (band_out_rows) { a.out_r0 = (uint32_t)band_out_row0; a.out_r1 = (uint32_t)(band_out_row0 + band_out_rows); a.src_y = (uint64_t)0 - (uint64_t)band_src_row0; }
   const size_t out_rows = a.out_r1 - a.out_r0;
+  a.xcd_gx = 0; a.xcd_gy = 0; a.xcd_group = 0;
   a.components = has_fourth_colour ? 4 : 3;               // the w8 kernel skips the fourth bin for three-colour filters (it stays 0.0)
   // windows of at most 8 x 8 samples: floor(skip*(c+1)) - floor(skip*c) + 1 <= ceil(skip) + 1
   if (a.skip_x_x >= 1.0f && a.skip_x_x <= 7.0f && a.skip_y_y >= 1.0f && a.skip_y_y <= 7.0f && width >= 8 &&
@@ -928,10 +954,28 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
     const unsigned total_blocks = 5376u;                                     // 21 blocks per CU = 3 full rounds of the 7 resident ones; measured flat 3584 .. 7168
 #endif
     const unsigned want = std::max(1u, total_blocks / gx);                   // ~16 blocks of 256 threads per CU in total
-    const dim3 grid(gx, (unsigned)std::min<size_t>(out_rows, want), 1);      // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
+    const dim3 grid2(gx, (unsigned)std::min<size_t>(out_rows, want), 1);     // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
+    const dim3 grid = grid2;
 #ifndef IPK_W8_SELECT
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
       const size_t lds = (size_t)pw * ph * kW8CellF4 * 4 * sizeof(float);
+#if IPK_OPT_W8M_XCD
+      dim3 grid = grid2;
+      a.xcd_gx = 0; a.xcd_gy = 0;
+      {
+        uint32_t group = 2;     // block rows per XCD in a run (sweep below)
+#ifdef IPK_DEV_KNOBS
+        if (getenv("IPK_DEV_W8_GROUP")) group = (uint32_t)atoi(getenv("IPK_DEV_W8_GROUP"));
+#endif
+        if (group > 0 && grid2.y >= 8 * group) {
+          a.xcd_gx = grid2.x; a.xcd_group = group; a.xcd_gy = grid2.y / (8 * group) * (8 * group);
+          grid = dim3(a.xcd_gx * a.xcd_gy, 1, 1);
+        }
+      }
+#else
+      const dim3 grid = grid2;
+      a.xcd_gx = 0; a.xcd_gy = 0;
+#endif
       if (a.skip_x_x >= 4.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 5>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       else if (a.skip_x_x >= 2.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 3>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       else hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 2>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-3 evidence collection (run on the GPU box through gpurun): everything DESIGN.md section 5 and the bench line quote, for
+# tools/evidence_r03_summarize.py to turn into tracked files under profiles/.  PMC passes are separate runs with --kernel-trace only.
+TAG=${1:-r03}
+OUT=gpurun_out/evid_$TAG
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf $OUT; mkdir -p $OUT
+B="python bench.py --no-cpu-baseline --no-check --no-extras"
+pmc() { d=$1; shift; ctrs=$1; shift; rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/$d -o p -- "$@" > /dev/null 2>&1; }
+# 1. headline: kernel-trace stats of the default command (pre-warmed clock), then HBM traffic in separate passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > $OUT/bench_stats.log 2>&1
+pmc fetch FETCH_SIZE $B --steps 5 --warmup 1
+pmc write WRITE_SIZE $B --steps 5 --warmup 1
+# 2. instruction classes and the stall split, noise and photo-like data
+for d in noise photo; do
+  pmc cls1_$d "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SALU" $B --steps 3 --warmup 1 --prewarm-ms 0 --data $d
+  pmc cls2_$d "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAVES" $B --steps 3 --warmup 1 --prewarm-ms 0 --data $d
+  pmc stall1_$d "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" $B --steps 3 --warmup 1 --prewarm-ms 0 --data $d
+  pmc stall2_$d "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" $B --steps 3 --warmup 1 --prewarm-ms 0 --data $d
+  pmc stall3_$d "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_SMEM" $B --steps 3 --warmup 1 --prewarm-ms 0 --data $d
+  $B --data $d 2>/dev/null | tail -n 1 > $OUT/bench_$d.json
+done
+# 3. the micro-benchmarks the issue model prices with, and their wave-cycles per instruction
+tools/build/ubench2 > $OUT/ubench2.txt 2>&1
+pmc ubench "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU" tools/build/ubench2
+# 4. configs[3] (the batch kernel), configs[1] (24 MP), configs[4] (scaled X-Trans): kernel-trace stats at the loaded clock + traffic
+for c in c4 c2 c5; do
+  extra=""; [ $c = c4 ] && extra="--steps 5 --warmup 1"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o s -- python bench.py --config $c --no-cpu-baseline --no-check $extra > $OUT/bench_$c.log 2>&1
+  pmc fetch_$c FETCH_SIZE python bench.py --config $c --no-cpu-baseline --no-check --steps 3 --warmup 1 --prewarm-ms 0
+  pmc write_$c WRITE_SIZE python bench.py --config $c --no-cpu-baseline --no-check --steps 3 --warmup 1 --prewarm-ms 0
+done
+# 5. the plain default run, exactly as the driver issues it
+python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+tail -n 1 $OUT/bench_plain.json | cut -c1-400
+ls $OUT | head -60
