@@ -74,6 +74,16 @@ using namespace ipkd;
 #ifndef IPK_OPT_W8M_XCD
 #define IPK_OPT_W8M_XCD 1
 #endif
+//   IPK_OPT_COLD       the wave-uniform tests of the rare paths marked unlikely, so that their code is laid out behind the loop and the common path
+//                      runs through not-taken branches (a taken branch makes the wave refetch its instruction buffer)
+#ifndef IPK_OPT_COLD
+#define IPK_OPT_COLD 1
+#endif
+#if IPK_OPT_COLD
+#define IPK_RARE(x) __builtin_expect(!!(x), 0)
+#else
+#define IPK_RARE(x) (x)
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -1647,7 +1657,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // branch on it -- and copied each mask into vcc: 36 instructions per entered slot, 27 now; the uniform noise frame enters 8 of 12 per row.)
   #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    if (__builtin_amdgcn_ballot_w64(__float_as_uint(v[k]) > 0x3F800000u) != 0) {   // some lane has v > 1, v < 0, -0 or NaN
+    if (IPK_RARE(__builtin_amdgcn_ballot_w64(__float_as_uint(v[k]) > 0x3F800000u) != 0)) {   // some lane has v > 1, v < 0, -0 or NaN
       const bool hi = v[k] > 1.0f;
       if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
       const bool lo = __float_as_uint(v[k]) > 0x7F800000u;            // negative (or -0), or NaN: out of the table and not above 1
@@ -1706,17 +1716,17 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const bool xb0 = gx3.x > kLabE, xb1 = gx3.y > kLabE, zb0 = gz3.x > kLabE, zb1 = gz3.y > kLabE;
     const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
     f2 xq = gx3, yq = gy3, zq = gz3;
-    if (__builtin_amdgcn_ballot_w64(!(xb0 && xb1)) != 0) {
+    if (IPK_RARE(__builtin_amdgcn_ballot_w64(!(xb0 && xb1)) != 0)) {
       const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
       xq = F2(xb0 ? gx3.x : lx.x, xb1 ? gx3.y : lx.y);
     }
-    if (__builtin_amdgcn_ballot_w64(!(yb0 && yb1)) != 0) {
+    if (IPK_RARE(__builtin_amdgcn_ballot_w64(!(yb0 && yb1)) != 0)) {
       const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
       const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
       if (has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
       yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
     }
-    if (__builtin_amdgcn_ballot_w64(!(zb0 && zb1)) != 0) {
+    if (IPK_RARE(__builtin_amdgcn_ballot_w64(!(zb0 && zb1)) != 0)) {
       const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
       zq = F2(zb0 ? gz3.x : lz.x, zb1 ? gz3.y : lz.y);
     }
@@ -2273,7 +2283,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       }
       // frame-edge pixels: taps outside the image are skipped, not mirrored (demosaic.rs:103-104)
       const bool edge_lane = (r == 0) || (r == Hm1) || col_edge;
-      if (__builtin_amdgcn_ballot_w64(edge_lane) != 0) {
+      if (IPK_RARE(__builtin_amdgcn_ballot_w64(edge_lane) != 0)) {
         if (edge_lane) {
           #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -2324,7 +2334,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
 #else
       bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
       if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
-      if (__builtin_amdgcn_ballot_w64(bad) != 0) {          // rare: an input outside the fast form's proven zone
+      if (IPK_RARE(__builtin_amdgcn_ballot_w64(bad) != 0)) {          // rare: an input outside the fast form's proven zone
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);

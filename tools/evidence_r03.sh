@@ -6,7 +6,7 @@ OUT=gpurun_out/evid_$TAG
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $OUT; mkdir -p $OUT
 B="python bench.py --no-cpu-baseline --no-check --no-extras"
-pmc() { d=$1; shift; ctrs=$1; shift; rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/$d -o p -- "$@" > /dev/null 2>&1; }
+pmc() { local sub=$1; shift; local ctrs=$1; shift; rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/$sub -o p -- "$@" > /dev/null 2>&1; }
 # 1. headline: kernel-trace stats of the default command (pre-warmed clock), then HBM traffic in separate passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B > $OUT/bench_stats.log 2>&1
 pmc fetch FETCH_SIZE $B --steps 5 --warmup 1
