@@ -2887,7 +2887,12 @@ __global__ void k_selftest_clamp(SelftestOut *out) {
 // (bench.py's copy_ceiling; MI355X_MICROARCH.md measures 6.29 TB/s for such a copy against the 8 TB/s spec peak).
 __global__ __launch_bounds__(256) void k_copy_probe(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per lane
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
 }
 void launch_copy_probe(const void *src, void *dst, size_t bytes, int num_cus, hipStream_t s) {
   const size_t n16 = bytes / 16;
