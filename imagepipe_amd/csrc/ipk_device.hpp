@@ -42,6 +42,12 @@ __device__ __forceinline__ LutPair lut_pair_at(const float *__restrict__ tab, ui
   const float v1 = tab[key], v2 = tab[key + 1];
   return make_float2(v1, v2 - v1);
 }
+// the read alone -- {v[i], dv} from a pair table, {v[i], v[i+1]} from a plain one -- and the step that makes it a pair, for callers that
+// want all their reads in flight before the first subtraction waits for one
+__device__ __forceinline__ LutPair lut_raw_at(const LutPair *__restrict__ tab, uint32_t key) { return tab[key]; }
+__device__ __forceinline__ LutPair lut_raw_at(const float *__restrict__ tab, uint32_t key) { return make_float2(tab[key], tab[key + 1]); }
+__device__ __forceinline__ LutPair lut_raw_to_pair(const LutPair *, LutPair r) { return r; }
+__device__ __forceinline__ LutPair lut_raw_to_pair(const float *, LutPair r) { return make_float2(r.x, r.y - r.x); }
 template <typename Tab>
 __device__ __forceinline__ float lut_interp(const Tab *__restrict__ tab, float val) {
   const float pos = val * kLutMaxF;
@@ -351,6 +357,20 @@ __device__ __forceinline__ float spline_interpolate_3(const SplineDev &s, const 
 // Needs finite coefficients (0 * inf is NaN) and knot ordinates that are not -0.0: spline3_arith_ok(), checked by the host, which otherwise
 // keeps the form above.  Equality with the literal search on EVERY f32 argument is checked on the device for the curves the tests use
 // (ipk_selftest_spline3, tests/test_gpu_selftest.py).
+// the same in two halves, so that a caller can have the record reads of several pixels in flight before it needs the first of them
+struct Spline3Rec { float4 q; float k3, v1; };
+__device__ __forceinline__ Spline3Rec spline3a_fetch(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
+  Spline3Rec r;
+  r.v1 = fmaxf(val, s.px[0]);
+  const float *rec = lds_knots + kKnotSegRec + (r.v1 >= s.px[1] ? 8 : 0);
+  r.q = *reinterpret_cast<const float4 *>(rec);
+  r.k3 = rec[4];
+  return r;
+}
+__device__ __forceinline__ float spline3a_eval(const SplineDev &s, const Spline3Rec &r, float val) {
+  const float y = spline_poly(r.q.y, r.q.z, r.q.w, r.k3, r.v1 - r.q.x);
+  return (val >= s.px[2]) ? s.py[2] : y;
+}
 __device__ __forceinline__ float spline_interpolate_3a(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
   const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
   const float v1 = fmaxf(val, x0);

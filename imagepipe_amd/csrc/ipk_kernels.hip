@@ -84,6 +84,15 @@ using namespace ipkd;
 #else
 #define IPK_RARE(x) (x)
 #endif
+//   IPK_OPT_LDSORDER   the point-wise stages' LDS reads issued as batches with independent arithmetic behind them (pointwise4_fast): the multipliers and
+//                      the matrix asked for in front of the demosaic, all twelve Lab / gamma lookups back to back with their weights behind them, the
+//                      four curve records and the output matrix together with A and B computed meanwhile -- in hipcc's own order a row has about eight
+//                      LDS round trips with nothing behind them (four reads, consume, eight reads; the curve per pixel pair).  Measured on three boxes,
+//                      five repetitions: noise 0.5141 vs 0.5148 ms, photo 0.4090 vs 0.4092 (one box: photo -1.3 %, noise +1 %): the other three waves
+//                      of the SIMD already cover those waits.  Off: it costs the last spare VGPRs (128 of 128).
+#ifndef IPK_OPT_LDSORDER
+#define IPK_OPT_LDSORDER 0
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -1605,20 +1614,22 @@ struct FastBad { bool b; };
 template <bool PXG, bool TOLAB_ONLY = false, typename LT, typename GT>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const LT *__restrict__ s_lab,
                                                 const GT *__restrict__ s_gam, const float *__restrict__ s_knots,
-                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false) {
+                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false,
+                                                const float *__restrict__ par_regs = nullptr) {
   bool bad = false;
   float v[12], f[12];
   f2 y[2];
+  const float *const par0 = par_regs ? par_regs : par;       // par[0..14] already in registers (the caller read them early), or straight from LDS
   #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
     if (PXG) bad |= !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
-    const f2 r = min2(F2(pa.x, pb.x) * S2(par[0]), 1.0f);
-    const f2 gc = min2(F2(pa.y, pb.y) * S2(par[1]), 1.0f);
-    const f2 b = min2(F2(pa.z, pb.z) * S2(par[2]), 1.0f);
-    const f2 x = r * S2(par[4]) + gc * S2(par[5]) + b * S2(par[6]);
-    y[g] = r * S2(par[8]) + gc * S2(par[9]) + b * S2(par[10]);
-    const f2 z = r * S2(par[12]) + gc * S2(par[13]) + b * S2(par[14]);
+    const f2 r = min2(F2(pa.x, pb.x) * S2(par0[0]), 1.0f);
+    const f2 gc = min2(F2(pa.y, pb.y) * S2(par0[1]), 1.0f);
+    const f2 b = min2(F2(pa.z, pb.z) * S2(par0[2]), 1.0f);
+    const f2 x = r * S2(par0[4]) + gc * S2(par0[5]) + b * S2(par0[6]);
+    y[g] = r * S2(par0[8]) + gc * S2(par0[9]) + b * S2(par0[10]);
+    const f2 z = r * S2(par0[12]) + gc * S2(par0[13]) + b * S2(par0[14]);
     if (PXG) bad |= cdiv_guard(x.x) | cdiv_guard(x.y) | cdiv_guard(z.x) | cdiv_guard(z.y);
     const f2 xr = cdiv2s(x, rc_hi(kWhiteX), rc_lo(kWhiteX));
     const f2 zr = cdiv2s(z, rc_hi(kWhiteZ), rc_lo(kWhiteZ));
@@ -1628,10 +1639,26 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     float pos[12]; LutPair e[12];
     #pragma unroll
     for (int k = 0; k < 12; ++k) pos[k] = v[k] * kLutMaxF;
+#if IPK_OPT_LDSORDER
+    // all twelve keys first, then the twelve reads back to back with the twelve weights behind them: the first read's answer is needed some
+    // forty instructions after it was asked for (hipcc on its own issued four reads, consumed them, then the other eight)
+    uint32_t key[12]; float w[12];
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) key[k] = f32_as_u32_sat(pos[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) e[k] = lut_raw_at(s_lab, key[k]);
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) w[k] = __builtin_amdgcn_fractf(pos[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) { e[k] = lut_raw_to_pair(s_lab, e[k]); f[k] = e[k].x + w[k] * e[k].y; }
+#else
     #pragma unroll
     for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k]));
     #pragma unroll
     for (int k = 0; k < 12; ++k) f[k] = e[k].x + __builtin_amdgcn_fractf(pos[k]) * e[k].y;
+#endif
   }
 #if IPK_ABLATE < 1
   // (Tried and measured, round 1: compacting the v > 1 lanes of all 12 slots through a per-wave LDS queue -- ballot + mbcnt
@@ -1684,23 +1711,62 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
 #endif
 #endif
   f2 rr[2], gg[2], bb[2];
+  f2 Lq[2], Aq[2], Bq[2];
+  // the XYZ -> sRGB matrix (par[16..24]): read where LDS_ORDER puts the curve's reads, used at the very end
+  float pm[9];
+#if IPK_OPT_LDSORDER
+  constexpr bool kSplit = IPK_OPT_SPLINE3A && !TOLAB_ONLY;
+  if (kSplit && has_curve && curve3 && IPK_ABLATE < 3) {
+    // L of all four pixels first; their four curve-record reads and the nine matrix reads go out together; A and B are computed while those are
+    // in flight; then the four polynomials.  (Per pixel pair, as below, every pair paid the LDS round trip again.)
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f2 fy = F2(f[6 * g + 2], f[6 * g + 3]);
+      Lq[g] = cdiv2s(S2(116.0f) * fy - S2(16.0f), rc_hi(100.0f), rc_lo(100.0f));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Spline3Rec rec[4];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) { rec[2 * g] = spline3a_fetch(a.spline, s_knots, Lq[g].x); rec[2 * g + 1] = spline3a_fetch(a.spline, s_knots, Lq[g].y); }
+    #pragma unroll
+    for (int i = 0; i < 9; ++i) pm[i] = par[16 + i];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
+      Aq[g] = cdiv2s(S2(500.0f) * (fx - fy) + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+      Bq[g] = cdiv2s(S2(200.0f) * (fy - fz) + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) Lq[g] = F2(spline3a_eval(a.spline, rec[2 * g], Lq[g].x), spline3a_eval(a.spline, rec[2 * g + 1], Lq[g].y));
+  } else
+#endif
+  {
+    #pragma unroll
+    for (int i = 0; i < 9; ++i) pm[i] = TOLAB_ONLY ? 0.0f : par[16 + i];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
+      const f2 l = S2(116.0f) * fy - S2(16.0f);
+      const f2 a0 = S2(500.0f) * (fx - fy);
+      const f2 b0 = S2(200.0f) * (fy - fz);
+      f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
+      Aq[g] = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+      Bq[g] = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+      if (!TOLAB_ONLY && has_curve && IPK_ABLATE < 3) {
+        if (curve3) L = IPK_OPT_SPLINE3A ? F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y))
+                                         : F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
+        else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
+      }
+      Lq[g] = L;
+    }
+  }
   #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
-    const f2 l = S2(116.0f) * fy - S2(16.0f);
-    const f2 a0 = S2(500.0f) * (fx - fy);
-    const f2 b0 = S2(200.0f) * (fy - fz);
-    f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
-    const f2 A = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-    const f2 B = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
+    const f2 L = Lq[g], A = Aq[g], B = Bq[g];
     if (TOLAB_ONLY) {
       o[2 * g].r = L.x; o[2 * g].g = A.x; o[2 * g].b = B.x; o[2 * g + 1].r = L.y; o[2 * g + 1].g = A.y; o[2 * g + 1].b = B.y;
       continue;
-    }
-    if (has_curve && IPK_ABLATE < 3) {
-      if (curve3) L = IPK_OPT_SPLINE3A ? F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y))
-                                       : F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
-      else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
     }
     const f2 cl = L * S2(100.0f);
     const f2 ca = (A * S2(255.0f)) - S2(127.0f);
@@ -1742,9 +1808,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
 #endif
     const f2 X = xq * S2(kWhiteX), Y = yq, Z = zq * S2(kWhiteZ);
-    rr[g] = X * S2(par[16]) + Y * S2(par[17]) + Z * S2(par[18]);
-    gg[g] = X * S2(par[19]) + Y * S2(par[20]) + Z * S2(par[21]);
-    bb[g] = X * S2(par[22]) + Y * S2(par[23]) + Z * S2(par[24]);
+    rr[g] = X * S2(pm[0]) + Y * S2(pm[1]) + Z * S2(pm[2]);
+    gg[g] = X * S2(pm[3]) + Y * S2(pm[4]) + Z * S2(pm[5]);
+    bb[g] = X * S2(pm[6]) + Y * S2(pm[7]) + Z * S2(pm[8]);
   }
   if (TOLAB_ONLY) return bad;
   if (!linear && IPK_ABLATE < 2) {
@@ -1756,13 +1822,31 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       #pragma unroll
       for (int k = 0; k < 6; ++k) pos[6 * g + k] = c[k] * kLutMaxF;
     }
+#if IPK_OPT_LDSORDER
+    uint32_t key[12]; float wq[12];
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) key[k] = f32_as_u32_sat(pos[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) e[k] = lut_raw_at(s_gam, key[k]);
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) wq[k] = __builtin_amdgcn_fractf(pos[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+    for (int k = 0; k < 12; ++k) e[k] = lut_raw_to_pair(s_gam, e[k]);
+#else
     #pragma unroll
     for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_gam, f32_as_u32_sat(pos[k]));
+#endif
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
       float w[6];
       #pragma unroll
+#if IPK_OPT_LDSORDER
+      for (int k = 0; k < 6; ++k) w[k] = wq[6 * g + k];
+#else
       for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_fractf(pos[6 * g + k]);
+#endif
       const LutPair *p = e + 6 * g;
       rr[g] = F2(p[0].x, p[1].x) + F2(w[0], w[1]) * F2(p[0].y, p[1].y);
       gg[g] = F2(p[2].x, p[3].x) + F2(w[2], w[3]) * F2(p[2].y, p[3].y);
@@ -2234,6 +2318,15 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       }
 #endif
       const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
+#if IPK_OPT_LDSORDER
+      // the white-balance multipliers and the camera matrix come from the block's LDS copy (kept out of the scarce scalar registers): asked for
+      // here, in front of the demosaic's arithmetic, instead of where they are first used (a full LDS round trip in front of every row's first multiply)
+      float pv[16];
+      if (!DEMO) {
+        #pragma unroll
+        for (int i = 0; i < 15; ++i) pv[i] = s_par[i];
+      }
+#endif
       const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
       const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
       const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
@@ -2333,7 +2426,11 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
       bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
+#if IPK_OPT_LDSORDER
+      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN, pv);
+#else
       if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
+#endif
       if (IPK_RARE(__builtin_amdgcn_ballot_w64(bad) != 0)) {          // rare: an input outside the fast form's proven zone
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
