@@ -93,6 +93,12 @@ using namespace ipkd;
 #ifndef IPK_OPT_LDSORDER
 #define IPK_OPT_LDSORDER 0
 #endif
+//   IPK_OPT_NTOUT      the fused kernels' results (f32, 8-bit, 16-bit) through nontemporal stores (OutStage<>::flush): the result is written once and not
+//                      read again by the launch, and no longer displaces the mosaic rows in the caches: 100 MP noise 0.5040 -> 0.4969 ms, photo-like
+//                      0.4004 -> 0.3904, 24 MP 0.1275 -> 0.1239, 64 x 24 MP 0.1154 -> 0.1137 per frame (same box, four repetitions)
+#ifndef IPK_OPT_NTOUT
+#define IPK_OPT_NTOUT 1
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -182,6 +188,36 @@ static inline dim3 grid_rows_few(size_t width, size_t height, int bx, unsigned t
   size_t gy = total_blocks / gx; if (gy < 1) gy = 1; if (gy > height) gy = height; if (gy > 65535) gy = 65535;
   return dim3((unsigned)gx, (unsigned)gy, 1);
 }
+// Table-free streaming kernels (one element or four per thread) are launched FLAT -- as many blocks as the data needs, the grid-stride loop runs
+// once -- where round 2 capped them at 16 blocks per CU: neighbouring blocks run at the same time and touch neighbouring addresses, which the
+// memory system rewards (a plain copy: 5.0-5.2 TB/s through a capped grid-stride loop, 6.3-6.45 flat; tools/copy_probe.hip).  IPK_OPT_FLATGRID.
+#ifndef IPK_OPT_FLATGRID
+#define IPK_OPT_FLATGRID 1
+#endif
+static inline unsigned flat_cap(unsigned capped) { return IPK_OPT_FLATGRID ? 0x7FFFFFFFu : capped; }
+// The staged kernels read every byte once and write every byte once: nontemporal accesses (IPK_OPT_NT) keep those streams from displacing each
+// other in the L2 / Infinity Cache (plain copy 6.0 -> 6.45 TB/s, tools/copy_probe.hip).
+#ifndef IPK_OPT_NT
+#define IPK_OPT_NT 1
+#endif
+typedef float ipk_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream4(const float *p) {
+#if IPK_OPT_NT
+  const ipk_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ipk_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+__device__ __forceinline__ void st_stream4(float *p, float4 v) {
+#if IPK_OPT_NT
+  ipk_f4v q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w; __builtin_nontemporal_store(q, reinterpret_cast<ipk_f4v *>(p));
+#else
+  *reinterpret_cast<float4 *>(p) = v;
+#endif
+}
+__device__ __forceinline__ float ld_stream(const float *p) { return IPK_OPT_NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_stream(float *p, float v) { if (IPK_OPT_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <typename U> __device__ __forceinline__ void st_stream_u(U *p, U v) { if (IPK_OPT_NT) __builtin_nontemporal_store(v, p); else *p = v; }
 static inline unsigned grid_1d(size_t n, int bx, unsigned cap) {
   size_t g = (n + bx - 1) / bx;
   if (g < 1) g = 1;
@@ -1034,18 +1070,21 @@ __global__ __launch_bounds__(1024) void k_tolab(const float4 *__restrict__ src, 
 // OpBaseCurve::run (src/ops/curves.rs:44-48): channel 0 only, the rest is the clone
 __global__ void k_basecurve(const f3 *__restrict__ src, size_t n, SplineDev sp, f3 *__restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    f3 v = src[i];
-    v.x = spline_interpolate(sp, v.x);
-    dst[i] = v;
+    const float *pi = reinterpret_cast<const float *>(src + i);
+    float *po = reinterpret_cast<float *>(dst + i);
+    const float l = ld_stream(pi), ca = ld_stream(pi + 1), cb = ld_stream(pi + 2);
+    st_stream(po, spline_interpolate(sp, l)); st_stream(po + 1, ca); st_stream(po + 2, cb);
   }
 }
 // OpFromLab::run (src/ops/colorspaces.rs:128-136)
 __global__ void k_fromlab(const f3 *__restrict__ src, size_t n, Mat9 m, f3 *__restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const f3 v = src[i];
+    const float *pi = reinterpret_cast<const float *>(src + i);
+    float *po = reinterpret_cast<float *>(dst + i);
+    const float l = ld_stream(pi), ca = ld_stream(pi + 1), cb = ld_stream(pi + 2);
     f3 o;
-    lab_to_rgb(m, v.x, v.y, v.z, o.x, o.y, o.z);
-    dst[i] = o;
+    lab_to_rgb(m, l, ca, cb, o.x, o.y, o.z);
+    st_stream(po, o.x); st_stream(po + 1, o.y); st_stream(po + 2, o.z);
   }
 }
 // OpGamma::run (src/ops/gamma.rs:20-24): every sample
@@ -1057,8 +1096,8 @@ __global__ __launch_bounds__(1024) void k_gamma(const float *__restrict__ src, s
   // four samples per thread (16-byte accesses) while whole groups remain, then the tail one by one
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 ? n / 4 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4 *>(src)[i];
-    reinterpret_cast<float4 *>(dst)[i] = make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w));
+    const float4 v = ld_stream4(src + 4 * i);
+    st_stream4(dst + 4 * i, make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w)));
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = gamma_sample(s_gam, src[i]);
@@ -1082,16 +1121,17 @@ __global__ void k_rotate(const Px3<T> *__restrict__ src, uint32_t owidth, uint32
 __global__ void k_output8(const float *__restrict__ src, size_t n, uint8_t *__restrict__ dst) {
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 3)) == 0 ? n / 4 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4 *>(src)[i];
-    reinterpret_cast<uint32_t *>(dst)[i] = output8bit_x4(v.x, v.y, v.z, v.w);
+    const float4 v = ld_stream4(src + 4 * i);
+    st_stream_u(reinterpret_cast<uint32_t *>(dst) + i, output8bit_x4(v.x, v.y, v.z, v.w));
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output8bit(src[i]);
 }
 __global__ void k_output16(const float *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 7)) == 0 ? n / 4 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4 *>(src)[i];
-    reinterpret_cast<uint2 *>(dst)[i] = make_uint2((uint32_t)output16bit(v.x) | ((uint32_t)output16bit(v.y) << 16), (uint32_t)output16bit(v.z) | ((uint32_t)output16bit(v.w) << 16));
+    const float4 v = ld_stream4(src + 4 * i);
+    st_stream_u(reinterpret_cast<uint32_t *>(dst) + 2 * i, (uint32_t)output16bit(v.x) | ((uint32_t)output16bit(v.y) << 16));
+    st_stream_u(reinterpret_cast<uint32_t *>(dst) + 2 * i + 1, (uint32_t)output16bit(v.z) | ((uint32_t)output16bit(v.w) << 16));
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output16bit(src[i]);
 }
@@ -1125,12 +1165,12 @@ void launch_tolab(const float *src4, size_t npix, const float *mul4, const float
                      reinterpret_cast<const LutPair *>(lab_pairs), reinterpret_cast<f3 *>(dst3));
 }
 void launch_basecurve(const float *src3, size_t npix, const SplineHost &sp, float *dst3, int num_cus, hipStream_t s) {
-  hipLaunchKernelGGL(k_basecurve, dim3(grid_1d(npix, 256, (unsigned)num_cus * 16)), dim3(256), 0, s,
+  hipLaunchKernelGGL(k_basecurve, dim3(grid_1d(npix, 256, flat_cap((unsigned)num_cus * 16))), dim3(256), 0, s,
                      reinterpret_cast<const f3 *>(src3), npix, make_spline(sp), reinterpret_cast<f3 *>(dst3));
 }
 void launch_fromlab(const float *src3, size_t npix, const float *m9, float *dst3, int num_cus, hipStream_t s) {
   Mat9 m; for (int i = 0; i < 9; ++i) m.m[i] = m9[i];
-  hipLaunchKernelGGL(k_fromlab, dim3(grid_1d(npix, 256, (unsigned)num_cus * 16)), dim3(256), 0, s,
+  hipLaunchKernelGGL(k_fromlab, dim3(grid_1d(npix, 256, flat_cap((unsigned)num_cus * 16))), dim3(256), 0, s,
                      reinterpret_cast<const f3 *>(src3), npix, m, reinterpret_cast<f3 *>(dst3));
 }
 void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst, int num_cus, hipStream_t s) {
@@ -1253,7 +1293,7 @@ void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_of
 template void launch_rotate1<float>(const float *, size_t, size_t, int64_t, int64_t, int64_t, float *, hipStream_t);
 template void launch_rotate1<uint16_t>(const uint16_t *, size_t, size_t, int64_t, int64_t, int64_t, uint16_t *, hipStream_t);
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
-  hipLaunchKernelGGL(k_output8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+  hipLaunchKernelGGL(k_output8, dim3(grid_1d((n + 3) / 4, 256, flat_cap((unsigned)num_cus * 16))), dim3(256), 0, s, src, n, dst);
 }
 __global__ void k_chan_8_to_16(const uint8_t *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint16_t)(src[i] * 257u);
@@ -1268,7 +1308,7 @@ void launch_chan_16_to_8(const uint16_t *src, size_t n, uint8_t *dst, int num_cu
   hipLaunchKernelGGL(k_chan_16_to_8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
 }
 void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s) {
-  hipLaunchKernelGGL(k_output16, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+  hipLaunchKernelGGL(k_output16, dim3(grid_1d((n + 3) / 4, 256, flat_cap((unsigned)num_cus * 16))), dim3(256), 0, s, src, n, dst);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1968,7 +2008,18 @@ template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 store
     f4u *g = reinterpret_cast<f4u *>(reinterpret_cast<float *>(dst) + pix * 3);          // element-aligned 16-byte stores
     const float4 *s = reinterpret_cast<const float4 *>(stg);
     const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
+#if IPK_OPT_NTOUT
+    // the result is written once and not read again by this launch: nontemporal stores keep it from displacing the mosaic rows in the caches
+    // (element-aligned 16-byte stores, as below)
+    typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
+    f4a *gn = reinterpret_cast<f4a *>(reinterpret_cast<float *>(dst) + pix * 3);
+    f4a v0, v1, v2;
+    v0.x = q0.x; v0.y = q0.y; v0.z = q0.z; v0.w = q0.w; v1.x = q1.x; v1.y = q1.y; v1.z = q1.z; v1.w = q1.w; v2.x = q2.x; v2.y = q2.y; v2.z = q2.z; v2.w = q2.w;
+    __builtin_nontemporal_store(v0, gn + lane); __builtin_nontemporal_store(v1, gn + 64 + lane); __builtin_nontemporal_store(v2, gn + 128 + lane);
+    (void)g;
+#else
     g[lane] = f4u{q0.x, q0.y, q0.z, q0.w}; g[64 + lane] = f4u{q1.x, q1.y, q1.z, q1.w}; g[128 + lane] = f4u{q2.x, q2.y, q2.z, q2.w};
+#endif
   }
 };
 template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
@@ -1990,7 +2041,14 @@ template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
     u32u *g = reinterpret_cast<u32u *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);        // byte-aligned dword stores
     const uint32_t q0 = stg[lane], q1 = stg[64 + lane], q2 = stg[128 + lane];
+#if IPK_OPT_NTOUT
+    typedef uint32_t u32a __attribute__((aligned(1)));
+    u32a *gn = reinterpret_cast<u32a *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);
+    __builtin_nontemporal_store(q0, gn + lane); __builtin_nontemporal_store(q1, gn + 64 + lane); __builtin_nontemporal_store(q2, gn + 128 + lane);
+    (void)g;
+#else
     g[lane].v = q0; g[64 + lane].v = q1; g[128 + lane].v = q2;
+#endif
   }
 };
 template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
@@ -2007,7 +2065,15 @@ template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
     u64u *g = reinterpret_cast<u64u *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);      // 2-byte-aligned 8-byte stores
     const uint2 *s = reinterpret_cast<const uint2 *>(stg);
     const uint2 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
+#if IPK_OPT_NTOUT
+    typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(2)));
+    u2a *gn = reinterpret_cast<u2a *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);
+    u2a v0, v1, v2; v0.x = q0.x; v0.y = q0.y; v1.x = q1.x; v1.y = q1.y; v2.x = q2.x; v2.y = q2.y;
+    __builtin_nontemporal_store(v0, gn + lane); __builtin_nontemporal_store(v1, gn + 64 + lane); __builtin_nontemporal_store(v2, gn + 128 + lane);
+    (void)g;
+#else
     g[lane] = u64u{q0.x, q0.y}; g[64 + lane] = u64u{q1.x, q1.y}; g[128 + lane] = u64u{q2.x, q2.y};
+#endif
   }
 };
 
@@ -2023,6 +2089,7 @@ struct RgbeStage {
     f4u *g = reinterpret_cast<f4u *>(reinterpret_cast<float *>(dst) + pix * 4);
     const float4 *s = reinterpret_cast<const float4 *>(stg);
     const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane], q3 = s[192 + lane];
+    // (plain stores here: the RGBE buffer is the next staged kernel's input; nontemporal ones made this kernel 2.5 % slower, 422 -> 432 us)
     g[lane] = f4u{q0.x, q0.y, q0.z, q0.w}; g[64 + lane] = f4u{q1.x, q1.y, q1.z, q1.w}; g[128 + lane] = f4u{q2.x, q2.y, q2.z, q2.w}; g[192 + lane] = f4u{q3.x, q3.y, q3.z, q3.w};
   }
   static __device__ __forceinline__ void store_direct(void *dst, size_t pix, uint32_t nvalid, const float4 px[4]) {
@@ -2786,7 +2853,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint64_t i = base + 64u * j;
-      px[j] = src[i < npix ? i : npix - 1];               // clamped, unpredicated: the tail lanes recompute the last pixel
+      px[j] = ld_stream4(reinterpret_cast<const float *>(src + (i < npix ? i : npix - 1)));   // clamped, unpredicated: the tail lanes recompute the last pixel
     }
     PixOut o[4];
     // the fast form drops the E term (e * cm[i][3]): legal while the fourth channel is +0.0, as every producer on this
@@ -2807,7 +2874,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint64_t i = base + 64u * j;
-      if (i < npix) dst[i] = f3{o[j].r, o[j].g, o[j].b};
+      if (i < npix) { float *po = reinterpret_cast<float *>(dst + i); st_stream(po, o[j].r); st_stream(po + 1, o[j].g); st_stream(po + 2, o[j].b); }
     }
   }
 }
@@ -2980,21 +3047,22 @@ __global__ void k_selftest_clamp(SelftestOut *out) {
 }
 // output8bit: (v * 256).max(0).min(255) as u8 versus v_cvt_pk_u8_f32 of the product (variant 0), of its floor (variant 1), and
 // versus the saturating v_cvt_u32_f32 + unsigned min (variant 2), every bit pattern
-// The practical HBM ceiling the roofline figures are compared with: a plain copy, 16 bytes per lane, every lane of every CU streaming
-// (bench.py's copy_ceiling; MI355X_MICROARCH.md measures 6.29 TB/s for such a copy against the 8 TB/s spec peak).
-__global__ __launch_bounds__(256) void k_copy_probe(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per lane
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n16; i += stride) dst[i] = src[i];
+// The practical HBM ceiling the roofline figures are compared with: a plain copy, 16 bytes per lane, nothing else (bench.py's copy_ceiling;
+// MI355X_MICROARCH.md measures 6.29 TB/s for such a copy against the 8 TB/s spec peak).  Measured forms (tools/copy_probe.hip, 1.2 GB, one box):
+// a grid-stride loop over 2048 .. 16384 blocks 4.6-5.2 TB/s (hipMemcpyDtoD 5.26, torch's copy_ 4.7-5.3); ONE block per 1024 consecutive 16-byte
+// elements, four per lane, 6.0 TB/s, with nontemporal loads and stores 6.45; one element per lane 6.28.  The flat forms win because neighbouring
+// blocks -- which run at the same time -- touch neighbouring addresses; the probe is the best of them.
+__global__ __launch_bounds__(256) void k_copy_probe(const ipk_f4v *__restrict__ src, ipk_f4v *__restrict__ dst, size_t n16) {
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  ipk_f4v v[4];
+  #pragma unroll
+  for (int u = 0; u < 4; ++u) if (base + u * 256 < n16) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+  #pragma unroll
+  for (int u = 0; u < 4; ++u) if (base + u * 256 < n16) __builtin_nontemporal_store(v[u], dst + base + u * 256);
 }
-void launch_copy_probe(const void *src, void *dst, size_t bytes, int num_cus, hipStream_t s) {
+void launch_copy_probe(const void *src, void *dst, size_t bytes, int, hipStream_t s) {
   const size_t n16 = bytes / 16;
-  const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)(num_cus > 0 ? num_cus : 256) * 32);
-  hipLaunchKernelGGL(k_copy_probe, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), n16);
+  hipLaunchKernelGGL(k_copy_probe, dim3((unsigned)std::max<size_t>(1, (n16 + 1023) / 1024)), dim3(256), 0, s, reinterpret_cast<const ipk_f4v *>(src), reinterpret_cast<ipk_f4v *>(dst), n16);
 }
 // every f32 argument through the arithmetic 3-knot form against the literal search (curves.rs:126-157)
 __global__ void k_selftest_spline3(SplineDev sp, SelftestOut *out) {
