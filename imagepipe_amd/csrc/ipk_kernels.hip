@@ -22,6 +22,14 @@ using namespace ipkd;
 #ifndef IPK_ABLATE
 #define IPK_ABLATE 0
 #endif
+// development only, timing / counter studies of the complete fused kernel (wrong results): IPK_ABL_STORE 1 = the result goes through the LDS staging
+// buffer but is not stored, 2 = neither staged nor stored, 3 = stored into a cache-resident 12 MB; IPK_ABL_LOAD 1 = the row loop loads nothing (it reuses the rows its task was primed with)
+#ifndef IPK_ABL_STORE
+#define IPK_ABL_STORE 0
+#endif
+#ifndef IPK_ABL_LOAD
+#define IPK_ABL_LOAD 0
+#endif
 // Round-2 instruction-class substitutions (each measured on the same box against its =0 build, profiles/README.md):
 //   (tried, no gain: LDS table addresses by an f32 fma on denormal operands -- exact integer arithmetic at the full issue rate --
 //    instead of the half-rate v_lshl_add_u32: 0.628 vs 0.628 ms on noise, 0.499 vs 0.502 on photo-like data)
@@ -99,6 +107,16 @@ using namespace ipkd;
 #ifndef IPK_OPT_NTOUT
 #define IPK_OPT_NTOUT 1
 #endif
+//   IPK_OPT_LOADFIRST  (with PRIME4) the loads of row r+3 are issued BEFORE row r's stores (right behind the wait for row r+2), and a task primes row r0+2
+//                      first, so that nothing of the priming is in flight at the loop's entry: hipcc then waits for the row with a COUNT that leaves the three
+//                      younger stores in flight (s_waitcnt vmcnt(4) / vmcnt(3) instead of vmcnt(0)).  Measured neutral (noise 0.5055 -> 0.5054 ms, photo-like
+//                      0.4012 -> 0.3988, two repetitions): the waves do not wait for their stores -- a probe build has them parked 18 (noise) / 60 (photo-like)
+//                      cycles per row at that wait, 0.2 % / 0.9 % of their time (tools/wave_timeline.py).  Keeping TWO rows of loads in flight (two register
+//                      sets in alternating roles, row loop unrolled twice) cannot be expressed: hipcc's wait for the older set is vmcnt(4) where vmcnt(9) would
+//                      do, which waits for the younger set as well.  Left off.
+#ifndef IPK_OPT_LOADFIRST
+#define IPK_OPT_LOADFIRST 0
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -111,7 +129,11 @@ namespace ipk {
 
 #ifdef IPK_DEV_PROBE   // development only (tools/wave_timeline.py): per-wave time stamps of the row-walking kernels, 8 x u64 per wave
 __device__ unsigned long long g_probe[4096 * 8];
+__device__ unsigned long long g_probe2[4096 * 4];   // per wave: cycles in the wait for the next row's loads, cycles from staging to the last store's issue, spare, spare
 }  // namespace ipk
+extern "C" __attribute__((visibility("default"))) int ipk_dev_probe2_read(unsigned long long *out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipk::g_probe2), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
 extern "C" __attribute__((visibility("default"))) int ipk_dev_probe_read(unsigned long long *out, size_t n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipk::g_probe), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }
@@ -2015,7 +2037,10 @@ template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 store
     f4a *gn = reinterpret_cast<f4a *>(reinterpret_cast<float *>(dst) + pix * 3);
     f4a v0, v1, v2;
     v0.x = q0.x; v0.y = q0.y; v0.z = q0.z; v0.w = q0.w; v1.x = q1.x; v1.y = q1.y; v1.z = q1.z; v1.w = q1.w; v2.x = q2.x; v2.y = q2.y; v2.z = q2.z; v2.w = q2.w;
-    __builtin_nontemporal_store(v0, gn + lane); __builtin_nontemporal_store(v1, gn + 64 + lane); __builtin_nontemporal_store(v2, gn + 128 + lane);
+#if IPK_ABL_STORE == 1
+    if (q0.x == 123.456f && q1.y == 654.321f && q2.z == 1.5f)
+#endif
+    { __builtin_nontemporal_store(v0, gn + lane); __builtin_nontemporal_store(v1, gn + 64 + lane); __builtin_nontemporal_store(v2, gn + 128 + lane); }
     (void)g;
 #else
     g[lane] = f4u{q0.x, q0.y, q0.z, q0.w}; g[64 + lane] = f4u{q1.x, q1.y, q1.z, q1.w}; g[128 + lane] = f4u{q2.x, q2.y, q2.z, q2.w};
@@ -2181,7 +2206,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // Units of 4 rows numbered strip after strip (chunks of vertically adjacent units) were worse still: a block's sixteen waves then read sixteen 1 KB
   // pieces 1.4 MB apart instead of 16 KB of one row, rows ran 6-10 % slower.  Kept from all of it: the self-resetting queue.)
 #ifdef IPK_DEV_PROBE
-  unsigned long long pb_t0 = __builtin_readcyclecounter(), pb_draw = 0, pb_tasks = 0, pb_atomics = 0, pb_rows = 0, pb_prime = 0;
+  unsigned long long pb_t0 = __builtin_readcyclecounter(), pb_draw = 0, pb_tasks = 0, pb_atomics = 0, pb_rows = 0, pb_prime = 0, pb_vm = 0, pb_st = 0;
   const unsigned long long pb_w0 = wall_clock64();
 #endif
   auto draw = [&]() -> uint32_t {
@@ -2339,8 +2364,15 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
 #if IPK_OPT_PRIME4
     RawRowT raw_next;
     {
+#if IPK_OPT_LOADFIRST
+      // row r0+2 FIRST: the wait for the youngest of the four (row r0+1) then leaves nothing of this task's priming in flight at the loop's entry, and
+      // the loop's own wait can be a count that excludes the stores (see row_step)
+      raw_next = issue_row(min(r0 + 2, Hm1));
+      const RawRowT rp = issue_row(r0 > 0 ? r0 - 1 : 0u), rc = issue_row(r0), rn = issue_row(min(r0 + 1, Hm1));
+#else
       const RawRowT rp = issue_row(r0 > 0 ? r0 - 1 : 0u), rc = issue_row(r0), rn = issue_row(min(r0 + 1, Hm1));
       raw_next = issue_row(min(r0 + 2, Hm1));
+#endif
       P = finish_row(rp, fP); C = finish_row(rc, fC); N = finish_row(rn, fN);
     }
 #else
@@ -2507,16 +2539,31 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       }
 #endif
       bool fNN;
+#ifdef IPK_DEV_PROBE
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long pb_v0 = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);   // vmcnt(0) alone (expcnt, lgkmcnt left at their maxima)
+      const unsigned long long pb_v1 = __builtin_readcyclecounter();
+      pb_vm += pb_v1 - pb_v0;
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const RowWin NN = finish_row(raw_next, fNN);         // row r+2: the wait for its loads sits before this row's stores
       __builtin_amdgcn_sched_barrier(0);
+#ifdef IPK_DEV_PROBE
+      const unsigned long long pb_s0 = __builtin_readcyclecounter();
+#endif
+#if IPK_OPT_LOADFIRST && !IPK_ABL_LOAD
+      raw_next = issue_row(min(r + 3, Hm1));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
       if (OUT == 0 && FULL) {
         float *rowp = reinterpret_cast<float *>(frame_dst) + ((size_t)(r - a.out_r0) * a.W + pc0) * 3;
         f4u q0{o[0].r, o[0].g, o[0].b, o[1].r}, q1{o[1].g, o[1].b, o[2].r, o[2].g}, q2{o[2].b, o[3].r, o[3].g, o[3].b};
         reinterpret_cast<f4u *>(rowp)[lane] = q0; reinterpret_cast<f4u *>(rowp)[64 + lane] = q1; reinterpret_cast<f4u *>(rowp)[128 + lane] = q2;
       }
-#elif IPK_ABLATE == 7    // timing only: no stores
-      if (o[0].r == 123.456f) reinterpret_cast<float *>(frame_dst)[lane] = o[1].g + o[2].b + o[3].r;
+#elif IPK_ABLATE == 7 || IPK_ABL_STORE == 2   // timing only: no stores
+      if (o[0].r == 123.456f && o[0].g == 3.25f && o[2].g == 7.5f) reinterpret_cast<float *>(frame_dst)[lane] = o[1].g + o[2].b + o[3].r + o[0].b + o[1].r + o[1].b + o[2].r + o[3].g + o[3].b;
 #else
       if (FULL) {
         // Lane-blocked -> lane-interleaved through the wave's LDS staging buffer, then three stores per lane whose
@@ -2528,14 +2575,26 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
         OutStage<OUT>::stage(stg, lane, o);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if IPK_ABL_STORE == 3   // timing only: every wave overwrites its own 3 KB of the frame's first 12 MB (the stores are issued, HBM sees next to nothing of them)
+        OutStage<OUT>::flush(stg, lane, frame_dst, (size_t)(blockIdx.x * 16u + (threadIdx.x >> 6)) * 256u);
+#else
         OutStage<OUT>::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       } else {
         if (lane_on) OutStore<OUT>::store(frame_dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
+#ifdef IPK_DEV_PROBE
+      pb_st += __builtin_readcyclecounter() - pb_s0;
+#endif
+#if IPK_OPT_LOADFIRST && !IPK_ABL_LOAD
+#elif !IPK_ABL_LOAD
       raw_next = issue_row(min(r + 3, Hm1));
+#else
+      asm volatile("" : "+v"(raw_next.v0), "+v"(raw_next.v1), "+v"(raw_next.v2), "+v"(raw_next.v3), "+v"(raw_next.h));   // opaque: nothing of finish_row is hoisted
+#endif
       P = NN; fP = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
     };
@@ -2568,6 +2627,8 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       unsigned long long *q = g_probe + 8 * w;
       q[0] = pb_t0; q[1] = __builtin_readcyclecounter(); q[2] = pb_draw | (pb_atomics << 48); q[3] = pb_tasks; q[4] = pb_prime; q[5] = pb_rows;
       q[6] = pb_w0; q[7] = wall_clock64();
+      unsigned long long *q2 = g_probe2 + 4 * w;
+      q2[0] = pb_vm; q2[1] = pb_st; q2[2] = 0; q2[3] = 0;
     }
   }
 #endif

@@ -51,3 +51,12 @@ for f in (0.5, 0.75, 0.9, 0.95):
     print("  at %.0f %% of the span (%.0f us): %d of %d waves still resident" % (f * 100, t, int((ends > t).sum()), n_live))
 per_row = life / np.maximum(q[:, 5] + 2.5 * q[:, 3], 1)
 print("  us per row-equivalent (rows + 2.5 per task): mean %.3f" % per_row.mean())
+if hasattr(L, "ipk_dev_probe2_read"):
+    b2 = np.zeros(4096 * 4, dtype=np.uint64)
+    rc = L.ipk_dev_probe2_read(b2.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b2.size)); assert rc == 0, rc
+    q2 = b2.reshape(4096, 4).astype(np.float64)[live]
+    print("  share of the wave's cycles in the wait for the next row's loads (and older stores): mean %.4f p10 %.4f p90 %.4f; cycles per row: %.0f" % (
+        (q2[:, 0] / cyc).mean(), np.percentile(q2[:, 0] / cyc, 10), np.percentile(q2[:, 0] / cyc, 90), (q2[:, 0] / np.maximum(q[:, 5], 1)).mean()))
+    print("  share from normalising the next row to the last store's issue (finish_row, LDS staging round trip, three stores): mean %.4f; cycles per row: %.0f" % (
+        (q2[:, 1] / cyc).mean(), (q2[:, 1] / np.maximum(q[:, 5], 1)).mean()))
+    print("  cycles per row overall: %.0f" % (cyc / np.maximum(q[:, 5], 1)).mean())
