@@ -117,6 +117,17 @@ using namespace ipkd;
 #ifndef IPK_OPT_LOADFIRST
 #define IPK_OPT_LOADFIRST 0
 #endif
+//   IPK_OPT_STEAL      once the task queue is dry, a wave that has finished takes over the lower half of the rows that the wave of its BLOCK with the
+//                      most rows left has not begun (descriptors in LDS, one 64-bit compare-and-swap per takeover; see fused_bayer_body)
+#ifndef IPK_OPT_STEAL
+#define IPK_OPT_STEAL 1
+#endif
+#ifndef IPK_STEAL_MIN
+#define IPK_STEAL_MIN 4
+#endif
+#ifndef IPK_STEAL_STATIC   // takeovers also in launches that draw nothing (one task per wave: frames under ~65 MP)
+#define IPK_STEAL_STATIC 1
+#endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
 //   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
 #ifndef IPK_OPT_SLOTMASK
@@ -2166,6 +2177,11 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
+  // what the block's waves are working on, for takeovers once the queue is dry (IPK_OPT_STEAL): per wave slot one 64-bit descriptor -- low word: the
+  // row its task ends in front of; high word: serial << 22 | frame << 16 | strip -- and the row it is at
+  __shared__ unsigned long long s_tdesc[16];
+  __shared__ uint32_t s_tcur[16];
+  if (threadIdx.x < 16) { s_tdesc[threadIdx.x] = 0ull; s_tcur[threadIdx.x] = 0u; }
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -2225,16 +2241,59 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     return t;
   };
   const bool queued = a.task_ctr != nullptr && n_tasks > n_waves;
-  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gt < n_tasks; gt = queued ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
-    const uint32_t frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
-    // the task index is wave-uniform, and the compiler is told so: row counter, row parity and strip parity then live in scalar registers and the
-    // demosaic's role dispatch is scalar branches instead of exec-mask regions (noise 0.529 -> 0.521 ms)
-    const uint32_t task = (uint32_t)__builtin_amdgcn_readfirstlane((int)(BATCH ? gt - frame * per_frame : gt));
-    const uint32_t strip = task % a.n_strips, seg = task / a.n_strips;
-    // rows: this segment's output rows [r0, r1)
-    const uint32_t nrows = a.out_r1 - a.out_r0;
-    const uint32_t r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
-    const uint32_t r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
+  // Takeovers (IPK_OPT_STEAL).  The sixteen waves of a block are served unevenly by their SIMDs (oldest first: the same 32 rows take one wave 113 us and
+  // another 347), so when the queue runs dry the slow ones have most of a task ahead of them: the median wave of a 100 MP launch used to leave 59-74 us
+  // before the launch ended, and its last tenth ran on 4-15 % of the waves.  A wave that finds the queue dry now looks at what the other waves of its block
+  // have left (LDS: s_tdesc / s_tcur), and takes over the lower half of the rows that the one with the most has not begun: one 64-bit compare-and-swap on
+  // that wave's descriptor moves its end row up, and the owner, which re-reads its end row once per row, stops there.  The swap succeeds only on the
+  // descriptor the taker looked at (same task, same end), so two takers cannot both get the same rows, and a descriptor that has moved on is simply looked
+  // at again.  An owner that was already past the new end when it moved computes those rows too: the same values written twice.  Costs a wave two LDS
+  // operations per row; nothing is drawn, staged or primed that was not before, except the priming of the taken-over half.
+  constexpr bool STEAL = IPK_OPT_STEAL && !IPK_OPT_UNROLL3;
+  const uint32_t wslot = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+  const bool steal_on = STEAL && (queued || IPK_STEAL_STATIC);
+  uint32_t tserial = 0;
+  auto take_over = [&](uint32_t &frame, uint32_t &strip, uint32_t &r0, uint32_t &r1) -> bool {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      unsigned long long d = 0ull; uint32_t c = 0u;
+      if (lane < nwb) {
+        d = __hip_atomic_load(&s_tdesc[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __hip_atomic_load(&s_tcur[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      const uint32_t e = (uint32_t)d;
+      const uint32_t rem = e > c + 1u ? e - c - 1u : 0u;   // rows behind the one the owner is at
+      uint32_t best = 0u, bl = 0u;
+      for (uint32_t i = 0; i < 16u; ++i) { const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)rem, (int)i); if (x > best) { best = x; bl = i; } }
+      if (best < (uint32_t)IPK_STEAL_MIN) return false;
+      const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, (int)bl), dhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d >> 32), (int)bl);
+      const uint32_t mid = dlo - best / 2u;
+      const unsigned long long dv = ((unsigned long long)dhi << 32) | dlo, nv = ((unsigned long long)dhi << 32) | mid;
+      uint32_t ok = 0u;
+      if (lane == 0) ok = atomicCAS(&s_tdesc[bl], dv, nv) == dv ? 1u : 0u;
+      if (__builtin_amdgcn_readfirstlane((int)ok) != 0) { strip = dhi & 0xFFFFu; frame = (dhi >> 16) & 63u; r0 = mid; r1 = dlo; return true; }
+    }
+    return false;
+  };
+  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);; gt = (queued && gt < n_tasks) ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
+    uint32_t frame = 0u, strip, r0, r1;
+    if (gt < n_tasks) {
+      frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
+      // the task index is wave-uniform, and the compiler is told so: row counter, row parity and strip parity then live in scalar registers and the
+      // demosaic's role dispatch is scalar branches instead of exec-mask regions (noise 0.529 -> 0.521 ms)
+      const uint32_t task = (uint32_t)__builtin_amdgcn_readfirstlane((int)(BATCH ? gt - frame * per_frame : gt));
+      strip = task % a.n_strips;
+      const uint32_t seg = task / a.n_strips;
+      // rows: this segment's output rows [r0, r1)
+      const uint32_t nrows = a.out_r1 - a.out_r0;
+      r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
+      r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
+    } else {
+      if (!steal_on) break;
+      if (lane == 0) __hip_atomic_store(&s_tdesc[wslot], (unsigned long long)(++tserial & 0x3FFu) << 54, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // nothing left here
+      if (!take_over(frame, strip, r0, r1)) break;
+      strip = (uint32_t)__builtin_amdgcn_readfirstlane((int)strip); r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0); r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1);
+      if (BATCH) frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
+    }
     const void *const frame_src = BATCH ? bp->src[frame] : a.src;
     void *const frame_dst = BATCH ? bp->dst[frame] : a.dst;
 
@@ -2261,8 +2320,12 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // (a compile-time false for the Bayer variants, so that they carry no trace of it)
     const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
     if (r0 >= r1) continue;
+    if (steal_on && lane == 0) {                            // this wave's task, for takers: the row first, then the descriptor (one wave's LDS operations run in order)
+      __hip_atomic_store(&s_tcur[wslot], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&s_tdesc[wslot], ((unsigned long long)(((++tserial & 0x3FFu) << 22) | (frame << 16) | strip) << 32) | r1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 #ifdef IPK_DEV_PROBE
-    pb_tasks += 1; pb_rows += r1 - r0;
+    pb_tasks += 1;
     const unsigned long long pb_p0 = __builtin_readcyclecounter();
 #endif
 
@@ -2607,9 +2670,18 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       }
     } else
 #endif
-    for (uint32_t r = r0; r < r1; ++r) {
+    for (uint32_t r = r0, r1d = r1; r < r1d; ++r) {
+      uint32_t e_now = r1;
+      if (steal_on) {                                       // where this wave is, and where its task ends by now (asked for here, looked at behind the row)
+        if (lane == 0) __hip_atomic_store(&s_tcur[wslot], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        e_now = (uint32_t)__hip_atomic_load(reinterpret_cast<uint32_t *>(&s_tdesc[wslot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       row_step(P, C, N, fP, fC, fN, r);
+#ifdef IPK_DEV_PROBE
+      pb_rows += 1;
+#endif
       { const RowWin t = P; P = C; C = N; N = t; const bool ft = fP; fP = fC; fC = fN; fN = ft; }   // back to rolling order
+      if (steal_on) r1d = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_now);
     }
   }
   // the last wave to leave zeroes the queue for the stream's next launch (every other wave's draws have returned before it arrived here)
@@ -2771,18 +2843,23 @@ void release_task_counters() {
 
 // Task grid: strips of <= 64 lane-columns x row segments.  A task costs its rows plus about 2.5 rows' worth of set-up (two halo rows, the three-row
 // priming of the walker), and the queue should hold several tasks per wave for the draws to even anything out:
-//   a wave's even share of the work is at least 40 rows of a strip (frames above ~40 MP, or any batch): segments of ~32 rows, drawn from the queue.
+//   a wave's even share of the work is at least 64 rows of a strip (frames above ~65 MP, or any large batch; 40 rows until round 3): segments of ~32 rows, drawn from the queue.
 //     100 MP frame (tools/task_rows_sweep.sh, one box): 24 / 32 / 48 rows 0.531 / 0.535 / 0.584 ms noise, 0.417 / 0.419 / 0.439 photo; 12 / 16 / 20 rows
 //     within 2 % of 32 on another; a tall first task per wave followed by short ones (50-80 % of the rows, then 8-24-row tasks) 0.531-0.551: no better
 //     than uniform; ONE task per wave (nothing to draw) 0.576 / 0.497; round 2's launch (two blocks per CU in turn, one task per wave) 0.587 / 0.472;
 //   smaller frames, or no queue for this stream (task_ctr == null): one task per wave, at least 8 rows (24 MP: 23 rows each, 0.148 ms either way).
+//   Round 3, with takeovers inside a block (IPK_OPT_STEAL: a finished wave takes the lower half of what the slowest wave of its block has left): the static
+//   schedule lost its tail -- 24 MP 0.134 -> 0.118 ms noise, 0.118 -> 0.099 photo-like -- and is the better one up to a share of ~64 rows: 48 MP (47 rows)
+//   static 0.224 / 0.189 ms against drawn 0.242 / 0.195; 100 MP (98 rows) static 0.484 / 0.401 against drawn 0.490 / 0.382 -- uniform noise no longer needs
+//   the queue, a frame whose regions differ (photo-like: saturated patches) does, because takeovers stay inside a block and only the queue moves work
+//   between blocks (tools/share_min_sweep.sh, one box).
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
   const uint32_t waves_per_block = 16;
 #ifdef IPK_DEV_KNOBS
   static const uint32_t uni = getenv("IPK_DEV_TASK_ROWS") ? (uint32_t)atoi(getenv("IPK_DEV_TASK_ROWS")) : 32u;
-  static const uint32_t share_min = getenv("IPK_DEV_SHARE_MIN") ? (uint32_t)atoi(getenv("IPK_DEV_SHARE_MIN")) : 40u;
+  static const uint32_t share_min = getenv("IPK_DEV_SHARE_MIN") ? (uint32_t)atoi(getenv("IPK_DEV_SHARE_MIN")) : 64u;
 #else
-  const uint32_t uni = 32u, share_min = 40u;
+  const uint32_t uni = 32u, share_min = 64u;
 #endif
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;

@@ -995,11 +995,11 @@ def test_batch_launch_falls_back_frame_by_frame(ipa, orc):
 
 def test_task_queues_under_concurrent_launches(ipa):
     """the persistent kernel draws its tasks from a per-stream queue pair that consecutive launches use alternately: four host threads launch
-    48 MP frames (large enough for drawn tasks) on two shared streams and on the null stream at once; every output must equal the frame's
+    72 MP frames (large enough for drawn tasks) on two shared streams and on the null stream at once; every output must equal the frame's
     single-threaded result"""
     import threading
     import torch
-    h, w = 6000, 8000
+    h, w = 8000, 9000
     plan = ipa.FusedPlan(width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
                          cam_to_xyz_normalized=util.cam_matrix(), out_type=ipa.OUT_U8)
     g = torch.Generator(device="cuda"); g.manual_seed(77)
@@ -1026,10 +1026,11 @@ def test_task_queues_under_concurrent_launches(ipa):
             assert torch.equal(outs[t][i], want[t]), (t, i)
 
 
-@pytest.mark.parametrize("cfa,shape", [("GBRG", (100003, 300)), (XT, (90001, 517)), ("RGGB", (70000, 200))])
+@pytest.mark.parametrize("cfa,shape", [("GBRG", (140003, 300)), (XT, (100001, 517)), ("RGGB", (70000, 200))])
 def test_drawn_tasks_on_tall_narrow_frames(ipa, orc, cfa, shape):
-    """frames whose waves get 40+ rows each run with tasks DRAWN from the stream's queue (one or three strips, thousands of 32-row segments;
-    the 200-pixel-wide one takes the predicated-tail variant): every sample against the oracle"""
+    """frames whose waves get 64+ rows each run with tasks DRAWN from the stream's queue (two or three strips, thousands of 32-row segments); the
+    200-pixel-wide one takes the predicated-tail variant on the static schedule, one task per wave with takeovers inside the blocks: every sample against
+    the oracle"""
     h, w = shape
     raw = util.noise_u16(util.SEED + h, h, w)
     pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, cfa))
@@ -1038,10 +1039,42 @@ def test_drawn_tasks_on_tall_narrow_frames(ipa, orc, cfa, shape):
     assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa)), "drawn tasks %s %dx%d" % (cfa[:4], w, h))
 
 
-def test_drawn_tasks_in_a_batch_launch(ipa):
-    """64 frames of 2304 x 300 in one persistent launch: 64 x 9 strips x 9 segments queue up behind the first round; each frame against its own launch"""
+@pytest.mark.parametrize("h,w", [(6000, 8000), (9000, 9000)])
+def test_takeovers_do_not_change_the_result(ipa, orc, h, w):
+    """A wave that has run out of work (one task per wave at 48 MP; the stream's queue dry at 81 MP) takes over the lower half of the rows a slower wave
+    of its block has not begun (one compare-and-swap on that wave's descriptor in LDS).  Which rows change hands depends on how the waves happened to
+    run, so: a frame whose left half saturates (those strips run the cube-root branch in every slot and take about twice as long per row) against the
+    oracle, and twenty further launches of it, alternating with launches of another frame on a second stream, bit-identical to the first."""
     import torch
-    h, w, n = 300, 2304, 64
+    raw = util.noise_u16(util.SEED + 91, h, w)
+    raw[:, : w // 2] = np.maximum(raw[:, : w // 2], np.uint16(16000))       # saturated half: every slot of these strips leaves the table
+    raw[h // 3: h // 2, :] = np.uint16(700)                                  # and a dark band that takes lab_to_xyz's linear branches
+    plan = ipa.FusedPlan(width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
+                         cam_to_xyz_normalized=util.cam_matrix())
+    src = ipa.upload_u16(raw)
+    first = plan.run(src, plan.new_output()).clone()
+    torch.cuda.synchronize()
+    want = torch.from_numpy(orc.pipeline_run(_oracle_desc(orc, raw, "RGGB")).reshape(-1))
+    assert torch.equal(first.cpu().view(torch.int32), want.view(torch.int32))
+    other = ipa.upload_u16(util.noise_u16(util.SEED + 92, h, w))
+    side = torch.cuda.Stream()
+    outs = [plan.new_output() for _ in range(4)]
+    scratch = plan.new_output()
+    for i in range(20):
+        plan.run(other, scratch, side.cuda_stream)                           # a second launch competing for the CUs changes every wave's pace
+        plan.run(src, outs[i % 4])
+        if i % 4 == 3:
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o.view(torch.int32), first.view(torch.int32)), i
+                o.zero_()
+    torch.cuda.synchronize()
+
+
+def test_drawn_tasks_in_a_batch_launch(ipa):
+    """64 frames of 2304 x 480 in one persistent launch: 64 x 9 strips x 15 segments queue up behind the first round; each frame against its own launch"""
+    import torch
+    h, w, n = 480, 2304, 64
     plan = ipa.FusedPlan(width=w, height=h, is_float=True, black0=util.BLACK, white0=util.WHITE, cfa="BGGR", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
     g = torch.Generator(device="cuda"); g.manual_seed(11)
     srcs = [torch.randint(0, 16384, (h * w,), device="cuda", generator=g, dtype=torch.int32).to(torch.float32) for _ in range(n)]
@@ -1068,7 +1101,7 @@ st = C.c_void_p()
 assert hip.hipStreamCreate(C.byref(st)) == 0
 dead = st.value
 assert hip.hipStreamSynchronize(st) == 0 and hip.hipStreamDestroy(st) == 0
-H, W = 5000, 9000                                   # 45 MP: above the queue's threshold, tasks are drawn
+H, W = 8000, 9000                                   # 72 MP: above the queue's threshold, tasks are drawn
 raw = util.noise_u16(util.SEED + 5, H, W)
 cm = util.cam_matrix()
 plan = ipa.FusedPlan(width=W, height=H, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
@@ -1100,7 +1133,7 @@ def test_fused_launch_captured_in_a_graph_replays_correctly(ipa, orc):
     one left it -- zeroed by its last wave -- so each replay produces the whole frame (round 2's queues broke on the second replay), and a direct
     launch afterwards is still right.  Nothing is allocated at launch time (capture forbids it)."""
     import torch
-    H, W = 5000, 9000
+    H, W = 8000, 9000                                      # 72 MP: tasks are drawn
     raw = util.noise_u16(util.SEED + 6, H, W)
     cm = util.cam_matrix()
     plan = ipa.FusedPlan(width=W, height=H, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
