@@ -1755,6 +1755,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // 1 adds one compare, the cube root and one select, and the negative / NaN lanes (their own compare: as a bit pattern they are exactly the
   // values above +inf's) the linear branch.  (Round 2 derived the third mask from the first two -- hipcc moves such a mask through a VGPR to
   // branch on it -- and copied each mask into vcc: 36 instructions per entered slot, 27 now; the uniform noise frame enters 8 of 12 per row.)
+  // (Round 3, two slots per test -- the x, y or z ratios of a pixel pair under one unsigned maximum and one compare: with the two cube roots side by
+  // side, two independent f64 chains in flight, noise 0.494 -> 0.533 ms, photo-like 0.388 -> 0.383 (a pair is evaluated whenever either slot needs
+  // it); with the slots evaluated one by one inside the pair's branch noise 0.511 -> 0.521, photo-like 0.400 -> 0.395, smooth 0.446 -> 0.450.  Not kept.)
   #pragma unroll
   for (int k = 0; k < 12; ++k) {
     if (IPK_RARE(__builtin_amdgcn_ballot_w64(__float_as_uint(v[k]) > 0x3F800000u) != 0)) {   // some lane has v > 1, v < 0, -0 or NaN
@@ -2852,7 +2855,10 @@ void release_task_counters() {
 //   schedule lost its tail -- 24 MP 0.134 -> 0.118 ms noise, 0.118 -> 0.099 photo-like -- and is the better one up to a share of ~64 rows: 48 MP (47 rows)
 //   static 0.224 / 0.189 ms against drawn 0.242 / 0.195; 100 MP (98 rows) static 0.484 / 0.401 against drawn 0.490 / 0.382 -- uniform noise no longer needs
 //   the queue, a frame whose regions differ (photo-like: saturated patches) does, because takeovers stay inside a block and only the queue moves work
-//   between blocks (tools/share_min_sweep.sh, one box).
+//   between blocks (tools/share_min_sweep.sh, one box).  (Also tried with the takeovers in place, 100 MP: a tall static first task per wave over the first
+//   50 / 65 / 80 % of the rows and 32- or 16-row drawn tasks for the rest -- a third fewer primings and draws: noise 0.492 -> 0.490 / 0.490 / 0.485 ms,
+//   photo-like 0.391 -> 0.384 / 0.398 / 0.404 -- and drawn tasks of 24 / 48 / 64 / 96 rows: 0.497 / 0.508 / 0.496 / 0.522 against 0.501 for 32,
+//   photo-like 0.407 / 0.397 / 0.406 / 0.464 against 0.395.  The uniform 32-row grid stays.)
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
   const uint32_t waves_per_block = 16;
 #ifdef IPK_DEV_KNOBS
