@@ -60,9 +60,11 @@ using namespace ipkd;
 #ifndef IPK_OPT_GAMPAIRS
 #define IPK_OPT_GAMPAIRS 1
 #endif
-//   IPK_OPT_PRIME4     a task's first four row loads issued together (measured: no gain, see fused_bayer_body)
+//   IPK_OPT_PRIME4     a task's first four row loads issued together: one memory round trip per task instead of three (priming 3.1 -> 2.0 us per task in
+//                      the probe build).  No gain when first measured; with the takeovers a wave starts a few more tasks and it is worth 0.7-1 % at
+//                      100 MP (noise 0.4972 -> 0.4923 ms, photo-like 0.3880 -> 0.3853, four repetitions), nothing at 24 MP: on since then
 #ifndef IPK_OPT_PRIME4
-#define IPK_OPT_PRIME4 0
+#define IPK_OPT_PRIME4 1
 #endif
 //   IPK_OPT_SPLINE3A   the common-parameter variants' 3-knot base curve with its lower clamp and knot hit as arithmetic (spline_interpolate_3a); the
 //                      host admits a curve to those variants only when spline3_arith_ok() holds
