@@ -1130,7 +1130,16 @@ __global__ __launch_bounds__(1024) void k_gamma(const float *__restrict__ src, s
   __syncthreads();
   // four samples per thread (16-byte accesses) while whole groups remain, then the tail one by one
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 ? n / 4 : 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+  // two groups per thread and iteration, both loads issued before the first lookup: 0.467 -> 0.458 ms at 100 MP (5.1 -> 5.2 TB/s; the random table
+  // gathers in LDS, not the loads, are what keeps it under the 6.2-6.5 TB/s the box copies at)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 v = ld_stream4(src + 4 * i), w = ld_stream4(src + 4 * (i + stride));
+    st_stream4(dst + 4 * i, make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w)));
+    st_stream4(dst + 4 * (i + stride), make_float4(gamma_sample(s_gam, w.x), gamma_sample(s_gam, w.y), gamma_sample(s_gam, w.z), gamma_sample(s_gam, w.w)));
+  }
+  for (; i < n4; i += stride) {
     const float4 v = ld_stream4(src + 4 * i);
     st_stream4(dst + 4 * i, make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w)));
   }
@@ -2279,7 +2288,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     }
     return false;
   };
-  for (uint32_t gt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);; gt = (queued && gt < n_tasks) ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
+  // (everything that decides the control flow here is made wave-uniform FOR THE COMPILER -- readfirstlane -- or the row counter, the row parity and the
+  // addresses of the task loop below end up in vector registers behind exec-mask loops: the first form of the takeovers cost 6.6 M integer instructions)
+  for (uint32_t gt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));; gt = (queued && gt < n_tasks) ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
     uint32_t frame = 0u, strip, r0, r1;
     if (gt < n_tasks) {
       frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
@@ -2295,10 +2306,10 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     } else {
       if (!steal_on) break;
       if (lane == 0) __hip_atomic_store(&s_tdesc[wslot], (unsigned long long)(++tserial & 0x3FFu) << 54, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // nothing left here
-      if (!take_over(frame, strip, r0, r1)) break;
-      strip = (uint32_t)__builtin_amdgcn_readfirstlane((int)strip); r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0); r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1);
-      if (BATCH) frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
+      if (__builtin_amdgcn_readfirstlane(take_over(frame, strip, r0, r1) ? 1 : 0) == 0) break;
     }
+    strip = (uint32_t)__builtin_amdgcn_readfirstlane((int)strip); r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0); r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1);
+    if (BATCH) frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
     const void *const frame_src = BATCH ? bp->src[frame] : a.src;
     void *const frame_dst = BATCH ? bp->dst[frame] : a.dst;
 
@@ -2993,6 +3004,8 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
   const uint64_t nchunks = (npix + 255) / 256;
   const float4 *src = reinterpret_cast<const float4 *>(a.src);
   f3 *dst = reinterpret_cast<f3 *>(a.dst);
+  // (Round 3: the loads of a wave's NEXT chunk issued before the current one is computed -- 16 more registers -- made the staged ipk_tolab slower,
+  // 0.527 -> 0.551 ms at 100 MP: the kernel is not waiting for its loads)
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t base = chunk * 256 + lane;
     float4 px[4];
