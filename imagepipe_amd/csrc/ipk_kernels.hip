@@ -124,10 +124,13 @@ using namespace ipkd;
 #ifndef IPK_OPT_STEAL
 #define IPK_OPT_STEAL 1
 #endif
+#ifndef IPK_OPT_SPREAD
+#define IPK_OPT_SPREAD 4
+#endif
 #ifndef IPK_STEAL_MIN
 #define IPK_STEAL_MIN 4
 #endif
-#ifndef IPK_STEAL_STATIC   // takeovers also in launches that draw nothing (one task per wave: frames under ~65 MP)
+#ifndef IPK_STEAL_STATIC   // takeovers also in launches that draw nothing (one task per wave: single frames under ~130 MP)
 #define IPK_STEAL_STATIC 1
 #endif
 // Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
@@ -2290,7 +2293,18 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   };
   // (everything that decides the control flow here is made wave-uniform FOR THE COMPILER -- readfirstlane -- or the row counter, the row parity and the
   // addresses of the task loop below end up in vector registers behind exec-mask loops: the first form of the takeovers cost 6.6 M integer instructions)
-  for (uint32_t gt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));; gt = (queued && gt < n_tasks) ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
+#if IPK_OPT_SPREAD
+  // Static schedule (IPK_OPT_SPREAD = G): a block's sixteen waves start on 16 / G groups of G neighbouring tasks, the groups a whole round of blocks
+  // apart, so that every block's share is a sample of the whole frame -- takeovers only even out what is inside a block -- while neighbouring strips
+  // still share a block (their halo columns, the rows they read at the same time).  24 MP photo-like frame (saturated patches): G = 16 (none) / 8 / 4 / 2 / 1
+  // 0.102 / 0.099 / 0.093 / 0.095 / 0.098 ms, noise 0.1215 / 0.1185 / 0.1221 / 0.1193 / 0.1225; 48 MP photo-like 0.193 / 0.192 / 0.184 / 0.187 / 0.189
+  // (G = 1 on noise: 0.231 -> 0.247: every strip's neighbours on other XCDs).  G = 4.
+  const uint32_t gt0 = queued ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)
+                              : (((threadIdx.x >> 6) / IPK_OPT_SPREAD) * gridDim.x + blockIdx.x) * IPK_OPT_SPREAD + ((threadIdx.x >> 6) % IPK_OPT_SPREAD);
+#else
+  const uint32_t gt0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+#endif
+  for (uint32_t gt = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt0);; gt = (queued && gt < n_tasks) ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
     uint32_t frame = 0u, strip, r0, r1;
     if (gt < n_tasks) {
       frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
@@ -2859,7 +2873,7 @@ void release_task_counters() {
 
 // Task grid: strips of <= 64 lane-columns x row segments.  A task costs its rows plus about 2.5 rows' worth of set-up (two halo rows, the three-row
 // priming of the walker), and the queue should hold several tasks per wave for the draws to even anything out:
-//   a wave's even share of the work is at least 64 rows of a strip (frames above ~65 MP, or any large batch; 40 rows until round 3): segments of ~32 rows, drawn from the queue.
+//   a wave's even share of the work is at least 128 rows of a strip for one frame (above ~130 MP), 64 for a batch (40 for both until round 3): segments of ~32 rows, drawn from the queue.
 //     100 MP frame (tools/task_rows_sweep.sh, one box): 24 / 32 / 48 rows 0.531 / 0.535 / 0.584 ms noise, 0.417 / 0.419 / 0.439 photo; 12 / 16 / 20 rows
 //     within 2 % of 32 on another; a tall first task per wave followed by short ones (50-80 % of the rows, then 8-24-row tasks) 0.531-0.551: no better
 //     than uniform; ONE task per wave (nothing to draw) 0.576 / 0.497; round 2's launch (two blocks per CU in turn, one task per wave) 0.587 / 0.472;
@@ -2872,13 +2886,18 @@ void release_task_counters() {
 //   50 / 65 / 80 % of the rows and 32- or 16-row drawn tasks for the rest -- a third fewer primings and draws: noise 0.492 -> 0.490 / 0.490 / 0.485 ms,
 //   photo-like 0.391 -> 0.384 / 0.398 / 0.404 -- and drawn tasks of 24 / 48 / 64 / 96 rows: 0.497 / 0.508 / 0.496 / 0.522 against 0.501 for 32,
 //   photo-like 0.407 / 0.397 / 0.406 / 0.464 against 0.395.  The uniform 32-row grid stays.)
+//   And with the static round spread over the blocks in groups of four tasks (IPK_OPT_SPREAD, fused_bayer_body) a block's share is a sample of the whole
+//   frame and the static schedule needs no queue for ONE frame up to a share of ~128 rows: 72 MP static 0.349 / 0.277 ms against drawn 0.353 / 0.285,
+//   100 MP 0.479 / 0.382 against 0.487 / 0.384, 196 MP 0.928 / 0.730 against 0.929 / 0.714.  A batch keeps the queue from a share of 64 rows: one task per
+//   wave would be thousands of rows of one frame (64 x 24 MP: 7.31 ms drawn, 8.81 static).
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
   const uint32_t waves_per_block = 16;
 #ifdef IPK_DEV_KNOBS
   static const uint32_t uni = getenv("IPK_DEV_TASK_ROWS") ? (uint32_t)atoi(getenv("IPK_DEV_TASK_ROWS")) : 32u;
-  static const uint32_t share_min = getenv("IPK_DEV_SHARE_MIN") ? (uint32_t)atoi(getenv("IPK_DEV_SHARE_MIN")) : 64u;
+  static const uint32_t share_min_env = getenv("IPK_DEV_SHARE_MIN") ? (uint32_t)atoi(getenv("IPK_DEV_SHARE_MIN")) : 0u;
+  const uint32_t share_min = share_min_env ? share_min_env : (frames == 1 ? 128u : 64u);
 #else
-  const uint32_t uni = 32u, share_min = 64u;
+  const uint32_t uni = 32u, share_min = frames == 1 ? 128u : 64u;
 #endif
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;

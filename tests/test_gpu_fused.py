@@ -995,11 +995,11 @@ def test_batch_launch_falls_back_frame_by_frame(ipa, orc):
 
 def test_task_queues_under_concurrent_launches(ipa):
     """the persistent kernel draws its tasks from a per-stream queue pair that consecutive launches use alternately: four host threads launch
-    72 MP frames (large enough for drawn tasks) on two shared streams and on the null stream at once; every output must equal the frame's
+    144 MP frames (large enough for drawn tasks) on two shared streams and on the null stream at once; every output must equal the frame's
     single-threaded result"""
     import threading
     import torch
-    h, w = 8000, 9000
+    h, w = 12000, 12000
     plan = ipa.FusedPlan(width=w, height=h, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB,
                          cam_to_xyz_normalized=util.cam_matrix(), out_type=ipa.OUT_U8)
     g = torch.Generator(device="cuda"); g.manual_seed(77)
@@ -1026,9 +1026,9 @@ def test_task_queues_under_concurrent_launches(ipa):
             assert torch.equal(outs[t][i], want[t]), (t, i)
 
 
-@pytest.mark.parametrize("cfa,shape", [("GBRG", (140003, 300)), (XT, (100001, 517)), ("RGGB", (70000, 200))])
+@pytest.mark.parametrize("cfa,shape", [("GBRG", (270001, 300)), (XT, (180001, 517)), ("RGGB", (70000, 200))])
 def test_drawn_tasks_on_tall_narrow_frames(ipa, orc, cfa, shape):
-    """frames whose waves get 64+ rows each run with tasks DRAWN from the stream's queue (two or three strips, thousands of 32-row segments); the
+    """frames whose waves get 128+ rows each run with tasks DRAWN from the stream's queue (two or three strips, thousands of 32-row segments); the
     200-pixel-wide one takes the predicated-tail variant on the static schedule, one task per wave with takeovers inside the blocks: every sample against
     the oracle"""
     h, w = shape
@@ -1039,9 +1039,9 @@ def test_drawn_tasks_on_tall_narrow_frames(ipa, orc, cfa, shape):
     assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, cfa)), "drawn tasks %s %dx%d" % (cfa[:4], w, h))
 
 
-@pytest.mark.parametrize("h,w", [(6000, 8000), (9000, 9000)])
+@pytest.mark.parametrize("h,w", [(6000, 8000), (12000, 12000)])
 def test_takeovers_do_not_change_the_result(ipa, orc, h, w):
-    """A wave that has run out of work (one task per wave at 48 MP; the stream's queue dry at 81 MP) takes over the lower half of the rows a slower wave
+    """A wave that has run out of work (one task per wave at 48 MP; the stream's queue dry at 144 MP) takes over the lower half of the rows a slower wave
     of its block has not begun (one compare-and-swap on that wave's descriptor in LDS).  Which rows change hands depends on how the waves happened to
     run, so: a frame whose left half saturates (those strips run the cube-root branch in every slot and take about twice as long per row) against the
     oracle, and twenty further launches of it, alternating with launches of another frame on a second stream, bit-identical to the first."""
@@ -1069,6 +1069,20 @@ def test_takeovers_do_not_change_the_result(ipa, orc, h, w):
                 assert torch.equal(o.view(torch.int32), first.view(torch.int32)), i
                 o.zero_()
     torch.cuda.synchronize()
+
+
+def test_takeovers_generic_cfa_8bit_output(ipa, orc):
+    """the same for the generic-CFA variant with the 8-bit epilogue: a 50 MP X-Trans frame (one static task per wave, takeovers inside the blocks) whose left
+    half saturates, `output_8bit` six times, every one equal to the oracle's"""
+    h, w = 5760, 8640
+    raw = util.noise_u16(util.SEED + 93, h, w)
+    raw[:, : w // 2] = np.maximum(raw[:, : w // 2], np.uint16(16000))
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, XTRANS))
+    want = orc.pipeline_output_8bit(_oracle_desc(orc, raw, XTRANS))
+    for i in range(6):
+        ww, hh, o8 = pipe.output_8bit()
+        assert pipe.last_used_fused and (ww, hh) == (w, h)
+        assert np.array_equal(o8.cpu().numpy().reshape(hh, ww, 3), want), i
 
 
 def test_drawn_tasks_in_a_batch_launch(ipa):
@@ -1101,7 +1115,7 @@ st = C.c_void_p()
 assert hip.hipStreamCreate(C.byref(st)) == 0
 dead = st.value
 assert hip.hipStreamSynchronize(st) == 0 and hip.hipStreamDestroy(st) == 0
-H, W = 8000, 9000                                   # 72 MP: above the queue's threshold, tasks are drawn
+H, W = 12000, 12000                                 # 144 MP: above the queue's threshold, tasks are drawn
 raw = util.noise_u16(util.SEED + 5, H, W)
 cm = util.cam_matrix()
 plan = ipa.FusedPlan(width=W, height=H, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=cm)
@@ -1133,7 +1147,7 @@ def test_fused_launch_captured_in_a_graph_replays_correctly(ipa, orc):
     one left it -- zeroed by its last wave -- so each replay produces the whole frame (round 2's queues broke on the second replay), and a direct
     launch afterwards is still right.  Nothing is allocated at launch time (capture forbids it)."""
     import torch
-    H, W = 8000, 9000                                      # 72 MP: tasks are drawn
+    H, W = 12000, 12000                                    # 144 MP: tasks are drawn
     raw = util.noise_u16(util.SEED + 6, H, W)
     cm = util.cam_matrix()
     plan = ipa.FusedPlan(width=W, height=H, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=cm)

@@ -12,3 +12,10 @@ for sz in ${SIZES:-4000x6000 6000x8000 10000x10000}; do
     done
   done
 done
+if [ -n "$BATCH_TOO" ]; then
+  for m in ${MINS:-64 1000000}; do
+    for rep in 1 2; do
+    IPK_DEV_SHARE_MIN=$m IPK_SO_OVERRIDE=$PWD/imagepipe_amd/csrc/build/ablate/lib${LIB:-knobs}.so python bench.py --config c4 --no-cpu-baseline --no-check --steps 5 --warmup 1 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c4 64x24MP share_min=$m', d['ms_per_step'], 'ms per batch')"
+    done
+  done
+fi
