@@ -128,6 +128,12 @@ using namespace ipkd;
 //                      need it instead of on all lanes with a select behind: the same instructions are issued, but on the noise frame only a tenth to a
 //                      third of the lanes switch the f64 data path.  The kernel is bound by the socket's power cap: what the idle lanes
 //                      do not burn comes back as clock -- 100 MP noise 0.4748 -> 0.4517 ms, 24 MP 0.1173 -> 0.1120; photo-like and smooth data unchanged
+//   IPK_OPT_SPAR       white-balance multipliers, camera matrix and XYZ -> RGB matrix as SCALAR operands from the kernel arguments instead of 24 broadcast reads of
+//                      their LDS copy per row into vector registers (round 1 moved them to LDS to spare scalar registers): 24 LDS instructions per row and a
+//                      vector-register read per multiply less -- 100 MP noise 0.4761 -> 0.4673 ms, photo-like 0.3928 -> 0.3835, 24 MP 0.1174 -> 0.1159 / 0.0962 -> 0.0941
+#ifndef IPK_OPT_SPAR
+#define IPK_OPT_SPAR 1
+#endif
 #ifndef IPK_OPT_CBRT_EXEC
 #define IPK_OPT_CBRT_EXEC 1
 #endif
@@ -1716,7 +1722,15 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   bool bad = false;
   float v[12], f[12];
   f2 y[2];
+#if IPK_OPT_SPAR
+  // the multipliers and the camera matrix as SCALAR operands straight from the kernel arguments (s_load through the constant cache, re-read where the
+  // scalar registers are short) instead of sixteen broadcast reads of the LDS copy per row into vector registers
+  const float spar[16] = {a.tolab.mul[0], a.tolab.mul[1], a.tolab.mul[2], a.tolab.mul[3], a.tolab.cm[0], a.tolab.cm[1], a.tolab.cm[2], a.tolab.cm[3], a.tolab.cm[4],
+                          a.tolab.cm[5], a.tolab.cm[6], a.tolab.cm[7], a.tolab.cm[8], a.tolab.cm[9], a.tolab.cm[10], a.tolab.cm[11]};
+  const float *const par0 = spar;
+#else
   const float *const par0 = par_regs ? par_regs : par;       // par[0..14] already in registers (the caller read them early), or straight from LDS
+#endif
   #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
@@ -1853,7 +1867,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
 #endif
   {
     #pragma unroll
-    for (int i = 0; i < 9; ++i) pm[i] = TOLAB_ONLY ? 0.0f : par[16 + i];
+    for (int i = 0; i < 9; ++i) pm[i] = TOLAB_ONLY ? 0.0f : (IPK_OPT_SPAR ? a.rgbm.m[i] : par[16 + i]);
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
