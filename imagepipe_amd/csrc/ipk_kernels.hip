@@ -1802,9 +1802,10 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       const bool hi = v[k] > 1.0f;
       // the cube root under the lanes' own mask: the same instructions are issued, but only the lanes above 1 -- a tenth to a third of them on
       // the noise frame -- switch the f64 data path.  The kernel is bound by the socket's power cap, so what the idle lanes do not burn comes back as clock.
-      // Only in the common-parameter variants without per-pixel guards (PXG == false, CMN -- `curve3`): with the guards' registers live as well the
-      // masked regions spill (X-Trans full resolution 0.295 -> 0.338 ms with 36 bytes of scratch), and those keep the select form.
-      if (IPK_OPT_CBRT_EXEC && !PXG && curve3) { if (__builtin_amdgcn_ballot_w64(hi) != 0) { if (hi) f[k] = lab_cbrt(v[k], true); } }
+      // In the common-parameter variants (CMN -- `curve3`); the linear branch for negative ratios below is masked only where there are no per-pixel
+      // guards (PXG == false): with the guards' registers live as well BOTH masked regions spill (X-Trans full resolution 0.295 -> 0.338 ms with 36
+      // bytes of scratch), the cube root's alone does not (X-Trans noise 0.305 -> 0.288 ms).
+      if (IPK_OPT_CBRT_EXEC && curve3) { if (__builtin_amdgcn_ballot_w64(hi) != 0) { if (hi) f[k] = lab_cbrt(v[k], true); } }
       else if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
       const bool lo = __float_as_uint(v[k]) > 0x7F800000u;            // negative (or -0), or NaN: out of the table and not above 1
       if (IPK_OPT_CBRT_EXEC && !PXG && curve3) { if (__builtin_amdgcn_ballot_w64(lo) != 0) { if (lo) { const float dv = kLabK * v[k] + 16.0f; f[k] = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); } } }
