@@ -134,6 +134,9 @@ using namespace ipkd;
 #ifndef IPK_OPT_SPAR
 #define IPK_OPT_SPAR 1
 #endif
+#ifndef IPK_OPT_CBRT_LIKELY
+#define IPK_OPT_CBRT_LIKELY 1
+#endif
 #ifndef IPK_OPT_CBRT_EXEC
 #define IPK_OPT_CBRT_EXEC 1
 #endif
@@ -1676,7 +1679,11 @@ __device__ __forceinline__ float cdiv3s1(float x, float c, float rc) {
 // XYZ_LAB_TRANSFORM.lookup's direct branch for v > 1 (color_conversions.rs:103-104,123): cbrtf; the short form when the
 // whole wave's out-of-table values are below 2
 __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
+#if IPK_OPT_CBRT_LIKELY
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(hi && v >= 2.0f) == 0, 1)) return cbrtf_glibc_1to2(v);
+#else
   if (__builtin_amdgcn_ballot_w64(hi && v >= 2.0f) == 0) return cbrtf_glibc_1to2(v);
+#endif
   return cbrtf_glibc_sel(v);
 }
 
