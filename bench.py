@@ -43,6 +43,9 @@ CONFIGS = {            # name: (width, height, cfa, maxwidth, frames per step [N
 }
 
 
+CURVES = {"default": [(0.5, 0.6)], "none": [], "user5": [(0.1, 0.07), (0.3, 0.27), (0.5, 0.6), (0.7, 0.82), (0.9, 0.95)]}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +60,13 @@ def parse():
                          "photo: low-frequency mid-tone scene with shot-like noise and ~2 %% blown highlights; flat / white: development extremes (nothing / everything saturated)")
     ap.add_argument("--src", choices=["f32", "u16"], default="f32")
     ap.add_argument("--out", choices=["f32", "u8", "u16"], default="f32")
+    ap.add_argument("--curve", choices=sorted(CURVES), default="default",
+                    help="OpBaseCurve.points (src/ops/curves.rs:12-49): default = the raw default [(0.5, 0.6)] (3 knots, the compiled-in form); none = no points "
+                         "(the op is a no-op unless --exposure is set); user5 = five user points (7 knots: the binary search of SplineFunc::interpolate)")
+    ap.add_argument("--exposure", type=float, default=0.0, help="OpBaseCurve.exposure")
+    ap.add_argument("--linear", action="store_true", help="PipelineSettings.linear: no OpGamma (src/ops/gamma.rs:17); u16 output forces it as output_16bit does")
+    ap.add_argument("--kernel-stats", type=int, default=0, metavar="N",
+                    help="additionally time N single launches with an event pair each and report min / median / p95 / max / stddev (roofline.launch_stats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-check", action="store_true")
@@ -232,7 +242,7 @@ def timed(ctx, step, steps, warmup, prewarm_ms=0.0):
 class FusedBatch:
     """B frames of W x H through the fused raw->sRGB launch, frame i on rank i mod N; every frame keeps its own output buffer"""
 
-    def __init__(self, ctx, ipa, util, W, H, B, cfa, src_kind, out_kind, data, seed0):
+    def __init__(self, ctx, ipa, util, W, H, B, cfa, src_kind, out_kind, data, seed0, points=((0.5, 0.6),), exposure=0.0, linear=False):
         torch = ctx.torch
         self.ctx, self.W, self.H, self.B = ctx, W, H, B
         self.is_float = src_kind == "f32"
@@ -248,7 +258,8 @@ class FusedBatch:
         self.cm = util.cam_matrix()
         self.black, self.white, self.wb = util.BLACK, util.WHITE, util.WB
         self.plan = ipa.FusedPlan(width=W, height=H, is_float=self.is_float, black0=util.BLACK, white0=util.WHITE, cfa=cfa, wb_coeffs=util.WB,
-                                  cam_to_xyz_normalized=self.cm, out_type=self.out_type)
+                                  cam_to_xyz_normalized=self.cm, out_type=self.out_type, points=tuple(points), exposure=exposure, linear=linear)
+        self.points, self.exposure, self.linear = [tuple(p) for p in points], exposure, linear
         self.stream = torch.cuda.current_stream().cuda_stream
         self.in_b = 4.0 if self.is_float else 2.0
         self.out_b = {"f32": 12.0, "u8": 3.0, "u16": 6.0}[out_kind]
@@ -278,11 +289,19 @@ def oracle_check(ctx, util, wl, rows=None):
     def compare(n):
         part = src[: min(H, n + 2) * W].cpu().numpy().reshape(-1, W)
         desc = oracle.make_pipeline(part if wl.is_float else part.view(np.uint16), cfa="RGGB", source_kind=1 if wl.is_float else 0,
-                                    blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=wl.cm)
-        want = torch.from_numpy(oracle.pipeline_run(desc)[:n].reshape(-1))
+                                    blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=wl.cm,
+                                    points=wl.points, exposure=wl.exposure, linear=wl.linear)
         got = dst[: n * W * 3].cpu()
-        if not torch.equal(got.view(torch.int32), want.view(torch.int32)):
-            util.assert_bits_equal(got.numpy().reshape(n, W, 3), want.numpy().reshape(n, W, 3), "bench parity check")
+        if wl.out_b == 12.0:
+            want = torch.from_numpy(oracle.pipeline_run(desc)[:n].reshape(-1))
+            if not torch.equal(got.view(torch.int32), want.view(torch.int32)):
+                util.assert_bits_equal(got.numpy().reshape(n, W, 3), want.numpy().reshape(n, W, 3), "bench parity check")
+        else:                                              # the quantised outputs: output_8bit / output_16bit (src/pipeline.rs:404-421, :451-468)
+            q = (oracle.pipeline_output_8bit if wl.out_b == 3.0 else oracle.pipeline_output_16bit)(desc)[:n].reshape(-1)
+            g = got.numpy() if wl.out_b == 3.0 else got.numpy().view(np.uint16)
+            if not np.array_equal(g, q):
+                bad = np.flatnonzero(g != q)
+                raise AssertionError("bench parity check: %d of %d quantised samples differ, first at %d: got %d want %d" % (bad.size, q.size, bad[0], g[bad[0]], q[bad[0]]))
     if rows is not None:
         compare(rows)
         return "first %d rows of the rank's first frame bit-identical to the CPU oracle" % rows
@@ -321,6 +340,41 @@ def copy_ceiling(ctx, nbytes):
     own, tch = run(probe), run(lambda: b.copy_(a))
     del a, b
     return own, tch
+
+
+def ceiling_leg(ctx, wl, steps, warmup):
+    """The fused kernel's own memory skeleton timed in this session (ipk_stream_probe: the same persistent launch, task walk, row loads, OpGoFloat,
+    demosaic, LDS staging and nontemporal f32 stores, no point-wise stages): the time the kernel would take if its colour arithmetic were free.
+    Same frame, same stream, its own short clock pre-warm.  Returns (mean ms, median ms) or None when the probe has no variant for the workload."""
+    torch = ctx.torch
+    if not wl.srcs:
+        return None
+    out = torch.empty(wl.H * wl.W * 3, dtype=torch.float32, device="cuda")
+    try:
+        wl.plan.probe(wl.srcs[0], out, wl.stream)
+    except Exception as e:
+        sys.stderr.write("bench.py: no stream probe for this workload: %s\n" % e)
+        return None
+    _, m, md = timed(ctx, lambda: wl.plan.probe(wl.srcs[0], out, wl.stream), steps, warmup, 120.0)
+    del out
+    return m, md
+
+
+def launch_stats(ctx, wl, n):
+    """n single launches, an event pair around each (the marker costs the queue a few microseconds, so these run a little slower than the
+    back-to-back mean): min / median / p95 / max / stddev of the launch duration in ms"""
+    torch = ctx.torch
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for _ in range(8):
+        wl.step()
+    for a, b in evs:
+        a.record(); wl.step(); b.record()
+    torch.cuda.synchronize()
+    per = sorted(a.elapsed_time(b) / wl.launches_per_step for a, b in evs)
+    mean = sum(per) / n
+    sd = (sum((x - mean) ** 2 for x in per) / n) ** 0.5
+    return {"launches": n, "min_ms": round(per[0], 4), "median_ms": round(per[n // 2], 4), "p95_ms": round(per[min(n - 1, int(0.95 * n))], 4), "max_ms": round(per[-1], 4),
+            "mean_ms": round(mean, 4), "stddev_ms": round(sd, 4), "stddev_frac": round(sd / mean, 4), "over_1p2x_median": sum(1 for x in per if x > 1.2 * per[n // 2])}
 
 
 def valu_model(kernel_ms, data):
@@ -379,11 +433,14 @@ def main():
     if args.config in ("c5", "c5b") and (args.width is None and args.height is None):
         return main_xtrans(args, ctx, ipa, util, W, H, cfa, maxw)
 
-    wl = FusedBatch(ctx, ipa, util, W, H, B, cfa, args.src, args.out, args.data, util.SEED + 2)
+    # output_8bit forces linear = false, output_16bit linear = true (src/pipeline.rs:405, :452); Pipeline::run (f32) takes the setting
+    linear = {"f32": args.linear, "u8": False, "u16": True}[args.out]
+    curve_kw = dict(points=CURVES[args.curve], exposure=args.exposure, linear=linear)
+    wl = FusedBatch(ctx, ipa, util, W, H, B, cfa, args.src, args.out, args.data, util.SEED + 2, **curve_kw)
 
     # ---- correctness check against the CPU oracle (outside the timed region) ----
     checked = None
-    if not args.no_check and rank == 0 and args.out == "f32" and cfa == "RGGB" and wl.mine:
+    if not args.no_check and rank == 0 and cfa == "RGGB" and wl.mine:
         checked = oracle_check(ctx, util, wl, rows=None if B <= world else 64)
 
     extras = (not args.no_extras) and args.config == "c3" and args.width is None and args.height is None and args.batch is None
@@ -415,6 +472,7 @@ def main():
                                   "one frame per GPU per step" if weak else "%d frames per step, frame i on rank i mod N" % B),
                    "baseline_config": "BASELINE.json configs[%d]" % cidx,
                    "frame": [W, H], "src": args.src, "out": args.out, "frames_per_step": B, "prewarm_ms": args.prewarm_ms,
+                   "curve": args.curve, "curve_points": [list(p) for p in CURVES[args.curve]], "exposure": args.exposure, "linear": linear,
                    "sharding": "independent frames, no data-path collective", "host_glibc": glibc_version(),
                    "host_cbrtf_matches_device": ipa.lib().ipk_host_libm_matches(None) == 1},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -444,6 +502,19 @@ def main():
         if vm:
             result["roofline_valu"] = vm
 
+    if args.kernel_stats > 0 or extras:
+        result["roofline"]["launch_stats"] = launch_stats(ctx, wl, args.kernel_stats if args.kernel_stats > 0 else (40 if dev_small else 500))
+    if (not args.no_extras) and args.out == "f32" and cfa == "RGGB":
+        # the ceiling for THIS access pattern and read:write mix (4 B read + 12 B nontemporal write per pixel on the kernel's own strip / row walk),
+        # measured in this session by the kernel's memory skeleton as a launch of its own; the 1:1 copy ceiling below is a different mix
+        ce = ceiling_leg(ctx, wl, args.steps, args.warmup)
+        if ce is not None:
+            result["roofline"]["ceiling_ms"] = round(ce[0], 4)
+            result["roofline"]["ceiling_ms_median"] = round(ce[1], 4)
+            result["roofline"]["ceiling_GBps"] = round(alg_bytes / (ce[0] * 1e-3) / 1e9, 1)
+            result["roofline"]["ceiling_frac_of_peak"] = round(alg_bytes / (ce[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            result["roofline"]["frac_of_ceiling"] = round(ce[0] / kernel_ms, 4)
+            result["roofline"]["ceiling_kernel"] = "ipk_stream_probe = k_fused_bayer<..., 4, ...>: the fused kernel's launch, loads, OpGoFloat, demosaic, staging and stores without OpToLab..OpGamma"
     if extras:
         own, tch = copy_ceiling(ctx, (12 if dev_small else 1200) * 1000 * 1000)     # every rank (keeps the ranks in step)
         result["roofline"]["copy_ceiling_GBps"] = round(max(own, tch), 1)

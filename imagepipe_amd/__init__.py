@@ -663,6 +663,15 @@ class FusedPlan:
         return out
 
 
+    def probe(self, src: torch.Tensor, out_f32: torch.Tensor, stream=None):
+        """ipk_stream_probe: the fused kernel's memory skeleton (loads, OpGoFloat, demosaic, staging, stores) without the point-wise stages;
+        out_f32 receives the demosaiced R, G, B as rows*width*3 f32"""
+        rc = lib().ipk_stream_probe(self._ref, src.data_ptr(), out_f32.data_ptr(), stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        if rc < 0:
+            _lib.check(rc, "ipk_stream_probe")
+        return out_f32
+
+
 class FusedBatchPlan:
     """ipk_raw_to_srgb_batch over fixed lists of same-shaped frames: the pointer arrays are built once, run() is one C call (one persistent
     launch per 64 frames where the kernel has a batch variant)."""

@@ -152,9 +152,11 @@ SIGNATURES = {
     "ipk_selftest_lut_weight": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_clamp01": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_copy_probe": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ipk_stream_probe": (C.c_int, [C.POINTER(FusedParams), _vp, _vp, _vp]),
     "ipk_selftest_spline3": (C.c_int, [C.c_float, _fp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_quant8": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_cbrtf": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
+    "ipk_selftest_task_queue": (C.c_int, [C.c_int]),
     "ipk_selftest_cache_put": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ipk_selftest_sha256": (C.c_int, [C.c_char_p, _sz, C.c_char_p]),
     "ipk_pointwise_chain": (C.c_int, [_vp, _sz, _sz, C.c_int, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, _vp, _vp]),

@@ -785,7 +785,7 @@ static int get_rot_cells(const char *pat, const ipk::Cfa &cfa, int ori, size_t w
 // so that dst receives OpTransform's output directly; IPK_ERR_UNSUPPORTED (nothing launched) when no such variant exists.
 // nbatch > 0: the frames srcs[0..nbatch) -> dsts[0..nbatch), all with the geometry and parameters of *p (src / dst = the first pair)
 static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, void *stream, int ori,
-                      size_t nbatch = 0, const void *const *srcs = nullptr, void *const *dsts = nullptr) {
+                      size_t nbatch = 0, const void *const *srcs = nullptr, void *const *dsts = nullptr, bool probe = false) {
   REQUIRE_INIT();
   if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
   IPK_FOLD_CFA(ipk_fused_params, p)
@@ -899,16 +899,22 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   }
   f.spline = &sp;
   f.linear = p->linear;
-  f.out_type = p->out_type;
+  f.out_type = probe ? 4 : p->out_type;
   f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
   f.num_cus = g.num_cus;
   { const int lrc = ipk::launch_fused_bayer(f, S(stream));
     if (lrc == -4) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued; the stream's task queue is untouched)");
-    if (lrc != 0) return fail(IPK_ERR_UNSUPPORTED, "no rotated-space variant for these parameters"); }
+    if (lrc != 0) return fail(IPK_ERR_UNSUPPORTED, probe ? "the stream probe exists for Bayer frames of 256+ columns with validated levels" : "no rotated-space variant for these parameters"); }
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
 int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void *stream) { return fused_impl(p, src, dst, stream, 0); }
+// Measurement aid: the fused kernel's memory skeleton (its launch, task walk, row loads, OpGoFloat, demosaic::full, LDS staging, nontemporal stores) without
+// the point-wise stages -- dst receives the demosaiced R, G, B as width*rows*3 f32.  bench.py times it next to ipk_raw_to_srgb (roofline.ceiling_ms).
+int ipk_stream_probe(const ipk_fused_params *p, const void *src, void *dst, void *stream) {
+  if (p && p->band_out_rows != 0) return fail(IPK_ERR_INVALID, "the stream probe takes whole frames");
+  return fused_impl(p, src, dst, stream, 0, 0, nullptr, nullptr, true);
+}
 // A batch of same-shaped frames through one descriptor: Pipeline::run over a shoot.  One persistent launch per 64 frames where the
 // kernel has a batch variant (ordinary Bayer parameters), one launch per frame otherwise -- the results are the single-frame ones.
 int ipk_raw_to_srgb_batch(const ipk_fused_params *p, const void *const *srcs, void *const *dsts, size_t n, void *stream) {
@@ -1033,6 +1039,7 @@ int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream) {
   ipk::launch_copy_probe(src, dst, bytes, g.num_cus, S(stream)); HIPCHK(hipGetLastError());
   return IPK_OK;
 }
+int ipk_selftest_task_queue(int enabled) { REQUIRE_INIT(); ipk::selftest_task_queue(enabled != 0); return IPK_OK; }
 int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint64_t *n_bad, uint32_t *first_bad_bits) {
   REQUIRE_INIT();
   if (!n_bad || (npoints > 0 && !points)) return fail(IPK_ERR_INVALID, "bad selftest arguments");

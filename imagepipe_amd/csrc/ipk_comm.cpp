@@ -183,7 +183,7 @@ int ipk_comm_init_host(int rank, int nranks, ipk_exchange_fn exchange, void *ctx
 
 int ipk_comm_free(ipk_comm *c) {
   if (!c) return IPK_OK;
-  if (c->pending && c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);   // whatever was begun on it is drained before its events and the stream go
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
@@ -350,9 +350,10 @@ int ipk_band_gather_begin(ipk_comm *c, void *frame, size_t out_row_bytes, const 
 
 int ipk_comm_wait(ipk_comm *c, void *stream) {
   if (!c) return internal_fail(IPK_ERR_INVALID, "null communicator");
-  if (!c->pending) return IPK_OK;
+  if (!c->pending) return IPK_OK;       // no gather has ever been begun on this communicator: nothing to be ordered behind
+  // Every caller gets the wait, however many streams ask (a download stream next to the compute stream): `pending` stays set once a gather has
+  // begun -- ev_out always holds the LAST gather's completion, and waiting for an event that has already fired costs nothing.
   HIPCHK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->ev_out, 0));
-  c->pending = false;                   // `stream` is now ordered behind every gather begun so far; a later begin sets it again
   return IPK_OK;
 }
 

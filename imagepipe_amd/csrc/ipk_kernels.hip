@@ -2214,20 +2214,25 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
   constexpr bool DEMO = OUT == 3;                        // demosaic only (staged OpDemosaic)
+  // OUT == 4: the kernel's memory skeleton as an entry point of its own (ipk_stream_probe) -- the same launch, task walk, row loads, normalisation,
+  // demosaic, LDS staging and nontemporal f32 stores, with the point-wise stages left out: the demosaiced R, G, B leave as the three output channels.
+  // 4 (2) bytes in and 12 out per pixel on the fused kernel's own access pattern: the ceiling its time is compared with (bench.py roofline.ceiling_ms).
+  constexpr bool SKEL = OUT == 4;
+  constexpr int OUTS = SKEL ? 0 : OUT;                   // the output layout (OutStage / OutStore) the variant writes
   constexpr bool ZA = DEMO || !IPK_OPT_NOZEROADD;        // literal `0.0 + tap` sums where the demosaic result itself is the output
   constexpr bool GUARD_NORM = sizeof(SrcT) == 4 && !DEMO;
   // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB; pairs when the output is 8/16-bit), curve knots, and one staging
   // buffer per wave (3 KB for f32) that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
   // (the generic-CFA variants also hold their cell records in LDS and keep both tables plain)
   typedef typename std::conditional<GEN, float, LabTab>::type LabT;
-  typedef typename std::conditional<GEN || OUT == 0, float, GamTab>::type GamT;   // f32 output: 48 KB of staging, no room for two pair tables
+  typedef typename std::conditional<GEN || OUTS == 0, float, GamTab>::type GamT;   // f32 output: 48 KB of staging, no room for two pair tables
   __shared__ LabT s_lab[DEMO ? 4 : kLutPairs + 4];
   __shared__ GamT s_gam[DEMO ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];   // base-curve knots + the 3-knot form's segment records
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
   __shared__ __attribute__((aligned(16))) float s_cells[GEN ? kGenMaxCells * kGenCellFloats : 4];   // generic-CFA cell records
   if (GEN) for (uint32_t i = threadIdx.x; i < a.gen_pw * a.gen_ph * kGenCellFloats; i += blockDim.x) s_cells[i] = a.gen_cells[i];
-  constexpr int STG = DEMO ? 1024 : (OUT == 0 ? 768 : (OUT == 1 ? 192 : 384));   // dwords of staging per wave: one output row segment
+  constexpr int STG = DEMO ? 1024 : (OUTS == 0 ? 768 : (OUTS == 1 ? 192 : 384));   // dwords of staging per wave: one output row segment
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * STG : 4];
   if (!DEMO) fill_lds_tables(s_lab, a.lab_table, s_gam, a.gam_table);
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
@@ -2308,7 +2313,8 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // operations per row; nothing is drawn, staged or primed that was not before, except the priming of the taken-over half.
   constexpr bool STEAL = IPK_OPT_STEAL && !IPK_OPT_UNROLL3;
   const uint32_t wslot = threadIdx.x >> 6, nwb = blockDim.x >> 6;
-  const bool steal_on = STEAL && (queued || IPK_STEAL_STATIC);
+  // (the descriptor holds 16 bits of strip and 6 of frame: wider launches simply run without takeovers)
+  const bool steal_on = STEAL && (queued || IPK_STEAL_STATIC) && a.n_strips <= 0xFFFFu && (!BATCH || a.n_frames <= 64u);
   uint32_t tserial = 0;
   auto take_over = [&](uint32_t &frame, uint32_t &strip, uint32_t &r0, uint32_t &r1) -> bool {
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -2344,7 +2350,15 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
 #else
   const uint32_t gt0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 #endif
-  for (uint32_t gt = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt0);; gt = (queued && gt < n_tasks) ? draw() : 0xFFFFFFFFu) {   // whole waves enter and leave together
+  // Without a queue (a.task_ctr == null, or nothing to draw) a wave walks the tasks gt0, gt0 + n_waves, ...: with at most one task per wave that is the
+  // single task of old, and a launch that holds more tasks than waves (no queue slot for the stream and a 64-frame batch, a GPU with fewer CUs, a frame
+  // wider than 16K strips) still runs every one of them.
+  auto next_task = [&](uint32_t gt) -> uint32_t {
+    if (gt >= n_tasks) return 0xFFFFFFFFu;
+    if (queued) return draw();
+    return (n_tasks - gt > n_waves) ? gt + n_waves : 0xFFFFFFFFu;
+  };
+  for (uint32_t gt = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt0);; gt = next_task(gt)) {   // whole waves enter and leave together
     uint32_t frame = 0u, strip, r0, r1;
     if (gt < n_tasks) {
       frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gt / per_frame)) : 0u;
@@ -2390,7 +2404,11 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // (a compile-time false for the Bayer variants, so that they carry no trace of it)
     const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
     if (r0 >= r1) continue;
-    if (steal_on && lane == 0) {                            // this wave's task, for takers: the row first, then the descriptor (one wave's LDS operations run in order)
+    if (steal_on && lane == 0) {
+      // this wave's task, for takers.  Takers read the descriptor first and the row second, and swap only against the descriptor they read; so the old
+      // descriptor is withdrawn BEFORE the new task's row is published (one wave's LDS operations run in order): a taker that still holds the old
+      // descriptor can then never pair it with the new task's row -- its swap fails -- and one that reads the new descriptor reads a row of the new task.
+      __hip_atomic_store(&s_tdesc[wslot], (unsigned long long)(++tserial & 0x3FFu) << 54, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store(&s_tcur[wslot], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store(&s_tdesc[wslot], ((unsigned long long)(((++tserial & 0x3FFu) << 22) | (frame << 16) | strip) << 32) | r1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -2410,7 +2428,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     const SrcT *src = reinterpret_cast<const SrcT *>(frame_src);
     const float min0 = a.min0, range0 = a.range0, inv_range0 = a.inv_range0;
     const bool exact_norm = CMN ? false : a.exact_norm != 0;
-    const bool fast_ok = CMN ? true : a.fast_ok != 0, has_curve = CMN ? true : a.has_curve != 0, linear = CMN ? (OUT == 2) : a.linear != 0;
+    const bool fast_ok = CMN ? true : a.fast_ok != 0, has_curve = CMN ? true : a.has_curve != 0, linear = CMN ? (OUTS == 2) : a.linear != 0;
 
     // One image row is fetched in two steps so that the global loads of row r+2 are in flight while row r is
     // being computed: issue_row() only loads, finish_row() normalises (OpGoFloat) and gathers the horizontal
@@ -2484,7 +2502,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       return w;
     };
 
-    const bool store_aligned = (OUT == 0 || OUT == 3) ? true : ((OUT == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
+    const bool store_aligned = (OUTS == 0 || OUTS == 3) ? true : ((OUTS == 1) ? ((a.W & 3u) == 0) : ((a.W & 1u) == 0));
     const uint32_t Hm1 = a.H - 1, Wm1 = a.W - 1;
     const bool col_edge = lane_on && (col0 == 0 || col0 + 3 >= Wm1);
 
@@ -2657,6 +2675,10 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
 #if IPK_ABLATE >= 4
       for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
 #else
+      if (SKEL) {
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
+      } else {
       bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
 #if IPK_OPT_LDSORDER
       if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN, pv);
@@ -2669,6 +2691,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
           const PixOut e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
           if (bad) o[j] = e;
         }
+      }
       }
 #endif
       bool fNN;
@@ -2706,16 +2729,16 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         // The compiler reasons about one lane: a lane never reads back what it staged, so without these wave-scope
         // fences it treats the staging writes as dead stores / reorders them past the reads.  Wavefront-scope fences
         // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
-        OutStage<OUT>::stage(stg, lane, o);
+        OutStage<OUTS>::stage(stg, lane, o);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if IPK_ABL_STORE == 3   // timing only: every wave overwrites its own 3 KB of the frame's first 12 MB (the stores are issued, HBM sees next to nothing of them)
-        OutStage<OUT>::flush(stg, lane, frame_dst, (size_t)(blockIdx.x * 16u + (threadIdx.x >> 6)) * 256u);
+        OutStage<OUTS>::flush(stg, lane, frame_dst, (size_t)(blockIdx.x * 16u + (threadIdx.x >> 6)) * 256u);
 #else
-        OutStage<OUT>::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
+        OutStage<OUTS>::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       } else {
-        if (lane_on) OutStore<OUT>::store(frame_dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
+        if (lane_on) OutStore<OUTS>::store(frame_dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -2876,10 +2899,12 @@ bool init_task_counters() {
 }
 // `lk` is held by the caller until its kernel launch has been issued: two host threads launching on one stream must enqueue one after the other.
 // Returns false (a.task_ctr = null: static schedule) when no slot can be had.
+static bool g_ctr_disabled = false;                          // test hook (ipk_selftest_task_queue): every launch runs as if no queue slot could be had
+void selftest_task_queue(bool enabled) { std::lock_guard<std::mutex> lk(g_ctr_mu); g_ctr_disabled = !enabled; }
 static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk) {
   a.task_ctr = nullptr;
   lk = std::unique_lock<std::mutex>(g_ctr_mu);
-  if (!g_ctr_block) return false;
+  if (!g_ctr_block || g_ctr_disabled) return false;
   static thread_local char per_thread_key;
   const hipStream_t key = (s == hipStreamPerThread) ? reinterpret_cast<hipStream_t>(&per_thread_key) : s;
   StreamCtr *e = nullptr;
@@ -2889,14 +2914,23 @@ static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std:
       g_ctr_of.push_back({key, s, (uint32_t)g_ctr_of.size(), 0});
       e = &g_ctr_of.back();
     } else {
-      // reuse the least recently used slot whose stream has nothing in flight (a destroyed stream's handle answers with an error: also free)
-      StreamCtr *lru = nullptr;
-      for (auto &c : g_ctr_of) if (!lru || c.last_use < lru->last_use) lru = &c;
+      // reuse the least recently used slot whose stream has nothing in flight (a destroyed stream's handle answers with an error: also free).  Slots of
+      // per-thread streams cannot be queried from this thread and are passed over -- one of them at the head of the order used to block reuse for
+      // good -- and a busy candidate is passed over as well: the next few in age order are tried before the launch settles for the static schedule.
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (!lru || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
-      const hipError_t q = (lru->key == lru->stream) ? hipStreamQuery(lru->stream) : hipErrorNotReady;   // per-thread streams: not queryable from here
-      (void)hipGetLastError();
-      if (q == hipErrorNotReady) return false;
+      if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+      StreamCtr *lru = nullptr;
+      uint64_t older_than = 0;
+      for (int attempt = 0; attempt < 8 && !lru; ++attempt) {
+        StreamCtr *cand = nullptr;
+        for (auto &c : g_ctr_of) if (c.key == c.stream && c.last_use > older_than && (!cand || c.last_use < cand->last_use)) cand = &c;
+        if (!cand) break;
+        older_than = cand->last_use;
+        const hipError_t q = hipStreamQuery(cand->stream);
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) lru = cand;
+      }
+      if (!lru) return false;
       lru->key = key; lru->stream = s;
       e = lru;
     }
@@ -3028,6 +3062,12 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   (void)task_counters_for(s, a, queue_lock);
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks);
+  if (f.out_type == 4) {                                  // ipk_stream_probe: the skeleton of the headline variants (Bayer phase, full strips, no guards)
+    if (a.gen_cells || a.ori != 0 || a.W < 256u || a.exact_norm || std::fabs(a.min0) < 0x1p-70f || std::fabs(a.min0) > 0x1p70f) return -2;
+    if (!f.src_is_u16) hipLaunchKernelGGL((k_fused_bayer<float, true, 4, true, false, false, true>), dim3(blocks), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((k_fused_bayer<uint16_t, false, 4, true, false, false, true>), dim3(blocks), dim3(1024), 0, s, a);
+    return launch_status();
+  }
   if (!f.src_is_u16) {
     if (f.out_type == 0) launch_fused_t<float, true, 0>(a, blocks, s);
     else if (f.out_type == 1) launch_fused_t<float, true, 1>(a, blocks, s);

@@ -31,6 +31,7 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
                           int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s);
 bool init_task_counters();      // the per-stream task-queue heads of the row-walking kernels: one device block (ipk_init)
 void release_task_counters();   // (ipk_shutdown)
+void selftest_task_queue(bool enabled);   // test hook: false = every following launch runs the queue-less static schedule
 
 template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,

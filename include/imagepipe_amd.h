@@ -513,6 +513,13 @@ IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* Measurement aid, no counterpart in the reference: a plain device-to-device copy, 16 bytes per lane, as the practical HBM ceiling next to which
  * bench.py reports the kernels' achieved bandwidth (SURVEY.md 8d asks for the measured copy / triad ceiling beside the 8 TB/s spec peak). */
 IPK_API int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream);
+/* Measurement aid, no counterpart in the reference: the memory skeleton of ipk_raw_to_srgb as a launch of its own -- the same persistent launch and
+ * task walk, the same row loads, OpGoFloat normalisation (src/ops/gofloat.rs:126), demosaic::full (src/ops/demosaic.rs:67-119), LDS staging and
+ * nontemporal stores, WITHOUT OpToLab..OpGamma: dst receives the demosaiced R, G, B channels (the first three of demosaic::full's RGBE pixel) as
+ * width*height*3 f32 samples, whatever p->out_type says.  4 (u16: 2) bytes in and 12 out per pixel on the fused kernel's own access pattern:
+ * bench.py times it in the same session as the fused kernel and reports roofline.ceiling_ms / frac_of_ceiling from it.  Whole Bayer frames of at
+ * least 256 columns with levels the fast normalisation is validated for; IPK_ERR_UNSUPPORTED otherwise. */
+IPK_API int ipk_stream_probe(const ipk_fused_params *p, const void *src, void *dst, void *stream);
 /* SplineFunc::interpolate (src/ops/curves.rs:126-157) on every f32 against the form the fused kernels use for a base curve of 2 or 3 knots (lower
  * clamp and exact knot hit as arithmetic, ipk_device.hpp spline_interpolate_3a); the curve is given like ipk_basecurve's.  IPK_ERR_UNSUPPORTED when
  * the kernels would not use that form for this curve (more knots, a knot ordinate of -0.0, non-finite coefficients). */
@@ -523,6 +530,10 @@ IPK_API int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_ba
 /* the device cbrtf routines (variant 0 literal glibc port, 1 select form, 2 form for 1<x<2) on a device array;
  * callers compare with the host libm's cbrtf (src/color_conversions.rs:123 -> f32::cbrt) */
 IPK_API int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream);
+/* test hook of the row-walking kernels' launch schedule: enabled = 0 makes every following launch run as if its stream could get no task-queue slot
+ * (the queue-less static schedule: every wave walks the tasks of its index, a whole round of waves apart); 1 restores the queues.  The results
+ * are the same bits either way -- which is what tests/test_gpu_fused.py checks for launches that hold more tasks than the chip has waves. */
+IPK_API int ipk_selftest_task_queue(int enabled);
 /* host-side test hooks of the caching contract: LRU bookkeeping without device memory; SHA-256 known answers */
 IPK_API int ipk_selftest_cache_put(ipk_cache *cache, const uint8_t *key32, size_t bytes);
 IPK_API int ipk_selftest_sha256(const void *data, size_t n, uint8_t *out32);

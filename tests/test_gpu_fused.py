@@ -1166,3 +1166,72 @@ def test_fused_launch_captured_in_a_graph_replays_correctly(ipa, orc):
     out.zero_()
     plan.run(src, out); torch.cuda.synchronize()
     assert torch.equal(out.cpu().view(torch.int32), want.view(torch.int32)), "direct launch after the replays"
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: launches without a task queue that hold more tasks than the chip has waves; the stream probe
+# ---------------------------------------------------------------------------------------------
+def test_queue_less_launch_runs_every_task(ipa):
+    """No queue slot for the stream (ipk_selftest_task_queue(0) forces what a full slot table does) and more tasks than waves: a 64-frame batch
+    whose strips x frames exceed the chip's 4096 waves, and a single frame wider than 4096 strips would be -- here 70 x 72 strips.  Every wave
+    then walks the tasks of its index a whole round of waves apart; each frame must equal the same frame through a queued launch of its own."""
+    import torch
+    L = ipa.lib()
+    h, w, n = 40, 72 * 256, 64                              # 72 strips x 64 frames = 4608 one-segment tasks > 4096 waves
+    plan = ipa.FusedPlan(width=w, height=h, is_float=True, black0=util.BLACK, white0=util.WHITE, cfa="GRBG", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    g = torch.Generator(device="cuda"); g.manual_seed(12)
+    srcs = [torch.randint(0, 16384, (h * w,), device="cuda", generator=g, dtype=torch.int32).to(torch.float32) for _ in range(n)]
+    want = [plan.run(s, plan.new_output()).clone() for s in srcs]
+    torch.cuda.synchronize()
+    assert L.ipk_selftest_task_queue(0) == 0
+    try:
+        outs = [torch.zeros_like(x) for x in want]
+        ipa.FusedBatchPlan(plan, srcs, outs).run()
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert torch.equal(outs[i].view(torch.int32), want[i].view(torch.int32)), i
+        # single frames, queue-less, at sizes that would otherwise draw (144 MP) and that would not (24 MP)
+        for hh, ww in ((12000, 12000), (4000, 6000)):
+            p1 = ipa.FusedPlan(width=ww, height=hh, is_float=False, black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+            src = torch.randint(0, 16384, (hh * ww,), device="cuda", generator=g, dtype=torch.int32).to(torch.int16)
+            a = p1.run(src, p1.new_output()).clone(); torch.cuda.synchronize()
+            assert L.ipk_selftest_task_queue(1) == 0
+            b = p1.run(src, p1.new_output()); torch.cuda.synchronize()
+            assert L.ipk_selftest_task_queue(0) == 0
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (hh, ww)
+            del a, b, src
+    finally:
+        assert L.ipk_selftest_task_queue(1) == 0
+
+
+@pytest.mark.parametrize("cfa", CFAS)
+@pytest.mark.parametrize("is_float,shape", [(True, (48, 256)), (False, (37, 515)), (True, (4000, 6000))])
+def test_stream_probe_is_gofloat_plus_demosaic(ipa, orc, cfa, is_float, shape):
+    """ipk_stream_probe -- the fused kernel's memory skeleton, the launch bench.py times as the kernel's ceiling -- has a defined result: the first
+    three channels of demosaic::full(OpGoFloat(src)) (src/ops/gofloat.rs:126, src/ops/demosaic.rs:67-119).  Compared with the oracle's two stages
+    sample by sample; the fused kernels start each demosaic sum from its first tap, so an exactly-zero channel may differ in its sign."""
+    import torch
+    h, w = shape
+    if h > 1000 and cfa != "RGGB":
+        pytest.skip("full size once")
+    raw = util.noise_u16(util.SEED + 77 + h, h, w)
+    src = raw.astype(np.float32) if is_float else raw
+    plan = ipa.FusedPlan(width=w, height=h, is_float=is_float, black0=util.BLACK, white0=util.WHITE, cfa=cfa, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    dev = torch.from_numpy(src.ravel()).cuda() if is_float else ipa.upload_u16(raw)
+    out = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    plan.probe(dev, out); torch.cuda.synchronize()
+    want = orc.demosaic_full(cfa, orc.gofloat_cfa(src, 0, 0, w, h, util.BLACK, util.WHITE))[:, :, :3]
+    got = out.cpu().numpy().reshape(h, w, 3)
+    zero = (got == 0.0) & (want == 0.0)
+    assert_bits_equal(np.where(zero, np.float32(0.0), got), np.where(zero, np.float32(0.0), want), "stream probe %s %dx%d" % (cfa, w, h))
+
+
+def test_stream_probe_refuses_what_it_has_no_variant_for(ipa):
+    import torch
+    xt = "GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+    for kw in (dict(width=600, height=48, cfa=xt), dict(width=200, height=48, cfa="RGGB")):
+        plan = ipa.FusedPlan(is_float=True, black0=util.BLACK, white0=util.WHITE, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix(), **kw)
+        src = torch.zeros(kw["width"] * kw["height"], dtype=torch.float32, device="cuda")
+        with pytest.raises(ipa._lib.IpkError) as e:
+            plan.probe(src, torch.zeros(kw["width"] * kw["height"] * 3, dtype=torch.float32, device="cuda"))
+        assert e.value.code == -5, e.value.code           # IPK_ERR_UNSUPPORTED
