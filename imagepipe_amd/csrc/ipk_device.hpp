@@ -42,12 +42,6 @@ __device__ __forceinline__ LutPair lut_pair_at(const float *__restrict__ tab, ui
   const float v1 = tab[key], v2 = tab[key + 1];
   return make_float2(v1, v2 - v1);
 }
-// the read alone -- {v[i], dv} from a pair table, {v[i], v[i+1]} from a plain one -- and the step that makes it a pair, for callers that
-// want all their reads in flight before the first subtraction waits for one
-__device__ __forceinline__ LutPair lut_raw_at(const LutPair *__restrict__ tab, uint32_t key) { return tab[key]; }
-__device__ __forceinline__ LutPair lut_raw_at(const float *__restrict__ tab, uint32_t key) { return make_float2(tab[key], tab[key + 1]); }
-__device__ __forceinline__ LutPair lut_raw_to_pair(const LutPair *, LutPair r) { return r; }
-__device__ __forceinline__ LutPair lut_raw_to_pair(const float *, LutPair r) { return make_float2(r.x, r.y - r.x); }
 template <typename Tab>
 __device__ __forceinline__ float lut_interp(const Tab *__restrict__ tab, float val) {
   const float pos = val * kLutMaxF;
@@ -105,9 +99,6 @@ __device__ __forceinline__ float cbrtf_glibc_sel(float x) {
 // step and the final products scale by exact powers of two, the last constant becomes 2^(1/3)/... see below) -- one instruction fewer; and (b) the
 // polynomial's two fmas as explicit v_fma_f64: hipcc turns `fma(a, x, CONST)` into a register copy of CONST plus v_fmac_f64 (two-address form),
 // two extra v_mov_b64 per evaluation.  Proven like the form above (tests/test_gpu_selftest.py, every f32 in (1,2)).
-#ifndef IPK_OPT_CBRT_ASM
-#define IPK_OPT_CBRT_ASM 1
-#endif
 __device__ __forceinline__ double fma_f64_vvv(double a, double b, double c) {
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -119,7 +110,6 @@ __device__ __forceinline__ double fma_f64_svv(double a, double b, double c) {   
   return d;
 }
 __device__ __forceinline__ float cbrtf_glibc_1to2(float x) {
-#if IPK_OPT_CBRT_ASM
   // with dx = (double)x = 2 dxm:  c2 dxm^2 = (c2/4) dx^2, c1 dxm = (c1/2) dx  (exact scalings)
   const double dx = (double)x;
   const float u = (float)fma_f64_vvv(fma_f64_svv(-0.191502161678719066 * 0.25, dx, 0.697570460207922770 * 0.5), dx, 0.492659620528969547);
@@ -130,18 +120,6 @@ __device__ __forceinline__ float cbrtf_glibc_1to2(float x) {
   double r = __builtin_amdgcn_rcp(den2);                    // = r/2 exactly (the reciprocal unit works on the mantissa)
   r = __builtin_fma(__builtin_fma(-den2, r, 1.0), r, r);
   return (float)((num * r) * (2.0 * 1.2599210498948731647672));
-#else
-  const float xm = x * 0.5f;                             // exact
-  const double dxm = (double)xm;
-  const float u = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, dxm, 0.697570460207922770), dxm, 0.492659620528969547);
-  const float t2 = u * u * u;
-  const double du = (double)u, dt2 = (double)t2;
-  const double num = du * __builtin_fma(2.0, dxm, dt2);
-  const double den = __builtin_fma(2.0, dt2, dxm);
-  double r = __builtin_amdgcn_rcp(den);
-  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  return (float)((num * r) * 1.2599210498948731647672);
-#endif
 }
 
 // XYZ_LAB_TRANSFORM.lookup (src/color_conversions.rs:102-114 with the closure of :120-124)
@@ -263,6 +241,8 @@ constexpr int kKnotFloats = kKnotSegRec + 16;
 struct SplineDev {
   int npoints, nseg;
   float px[kSplineMaxKnots], py[kSplineMaxKnots], c1[kSplineMaxKnots], c2[kSplineMaxKnots], c3[kSplineMaxKnots];
+  // grid form of a curve with four or more knots (spline_interpolate_grid): set by the host when the curve qualifies (make_spline)
+  int grid_ok; float grid_scale, grid_xl, grid_yl;       // cells per unit of x; the last knot
 };
 __device__ __forceinline__ float spline_poly(float y, float c1, float c2, float c3, float diff) {
   // self.points[i].1 + self.c1s[i]*diff + self.c2s[i]*diff*diff + self.c3s[i]*diff*diff*diff  (:156)
@@ -320,57 +300,16 @@ __device__ __forceinline__ float spline_interpolate_lds(const float *__restrict_
   return spline_poly(py[i], c1[i], c2[i], c3[i], val - px[i]);
 }
 
-// Branch-free forms of the 2- and 3-knot cases for the fused kernel (same decisions as the literal
-// search above, applied as selects in reverse priority order); any other knot count takes the loop.
-// The 3-knot form alone (no dispatch on the knot count): for callers that know the curve has 3 knots, or 2 knots padded by
-// the host to (x0, x1, x1) / (y0, y1, y1) -- then `up` implies val >= x2, so the unused second segment is never evaluated
-// into the result and every decision is the 2-knot one.
-#ifndef IPK_OPT_SPLINE_REC
-#define IPK_OPT_SPLINE_REC 1
-#endif
-__device__ __forceinline__ float spline_interpolate_3(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
-  const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
-  const bool up = x1 < val, down = x1 > val;
-#if IPK_OPT_SPLINE_REC
-  const float *rec = lds_knots + kKnotSegRec + (up ? 8 : 0);
-  const float4 q = *reinterpret_cast<const float4 *>(rec);
-  const float bx = q.x, by = q.y, k1 = q.z, k2 = q.w, k3 = rec[4];
-#else
-  const int i = up ? 1 : 0;
-  const float bx = lds_knots[i], by = lds_knots[kSplineMaxKnots + i];
-  const float k1 = lds_knots[2 * kSplineMaxKnots + i], k2 = lds_knots[3 * kSplineMaxKnots + i], k3 = lds_knots[4 * kSplineMaxKnots + i];
-#endif
-  float r = spline_poly(by, k1, k2, k3, val - bx);
-  // (tried, round 2: these three selects behind one wave-uniform test, per pixel or per pixel pair -- 4 instructions fewer per pixel on
-  // mid-tones: noise 0.591 -> 0.596 ms, photo 0.472 -> 0.477, smooth 0.570 -> 0.576.  A test that skips this little costs more than it saves.)
-  r = (!up && !down) ? s.py[1] : r;                    // exact knot hit
-  r = !(val > x0) ? s.py[0] : r;                       // val <= first, or NaN
-  r = (val >= x2) ? s.py[2] : r;                       // val >= end
-  return r;
-}
-// The same decisions with two of the three selects turned into arithmetic (round 3; 5 instructions per pixel fewer):
+// The 3-knot curve (the raw default, curves.rs:18; or 2 knots padded by the host to (x0, x1, x1) / (y0, y1, y1)) for the common-parameter kernels, with
+// two of the literal search's three special cases turned into arithmetic:
 //   val <= x0 or NaN -> y0:  the argument is raised to x0 first (v_max_f32 returns the number when the other operand is NaN); segment 0 at a
 //     difference of exactly 0 gives y0 + c1*0 + c2*0*0 + c3*0*0*0 = y0 -- every product is a zero, and adding zeros to y0 returns y0 bit for bit
 //     unless y0 is -0.0 (which would come back as +0.0);
 //   val == x1 -> y1:  the knot itself goes to segment 1 (`>=` instead of `>`), whose difference is then exactly 0: y1 by the same argument;
 //   val >= x2 -> y2 stays a select (segment 1 at x2 is only approximately y2).
 // Needs finite coefficients (0 * inf is NaN) and knot ordinates that are not -0.0: spline3_arith_ok(), checked by the host, which otherwise
-// keeps the form above.  Equality with the literal search on EVERY f32 argument is checked on the device for the curves the tests use
+// launches the generic variants (spline_interpolate_sel).  Equality with the literal search on EVERY f32 argument is checked on the device for the curves the tests use
 // (ipk_selftest_spline3, tests/test_gpu_selftest.py).
-// the same in two halves, so that a caller can have the record reads of several pixels in flight before it needs the first of them
-struct Spline3Rec { float4 q; float k3, v1; };
-__device__ __forceinline__ Spline3Rec spline3a_fetch(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
-  Spline3Rec r;
-  r.v1 = fmaxf(val, s.px[0]);
-  const float *rec = lds_knots + kKnotSegRec + (r.v1 >= s.px[1] ? 8 : 0);
-  r.q = *reinterpret_cast<const float4 *>(rec);
-  r.k3 = rec[4];
-  return r;
-}
-__device__ __forceinline__ float spline3a_eval(const SplineDev &s, const Spline3Rec &r, float val) {
-  const float y = spline_poly(r.q.y, r.q.z, r.q.w, r.k3, r.v1 - r.q.x);
-  return (val >= s.px[2]) ? s.py[2] : y;
-}
 __device__ __forceinline__ float spline_interpolate_3a(const SplineDev &s, const float *__restrict__ lds_knots, float val) {
   const float x0 = s.px[0], x1 = s.px[1], x2 = s.px[2];
   const float v1 = fmaxf(val, x0);
@@ -403,6 +342,58 @@ __device__ __forceinline__ float spline_interpolate_sel(const SplineDev &s, cons
     return r;
   }
   return spline_interpolate_lds(lds_knots, np, s.nseg, val);
+}
+
+// ---- curves with four or more knots: the binary search as a grid lookup --------------------------------------------------
+// SplineFunc::interpolate (curves.rs:126-157) for sorted knots decides: val >= x_last -> y_last; val <= x_0 -> y_0; val == x_k -> y_k; otherwise the
+// segment i with x_i < val < x_{i+1}, y_i + c1_i d + c2_i d d + c3_i d d d with d = val - x_i.  With the argument raised to x_0 first and the knot
+// itself counted into its own segment (d = 0: every product is a zero and y_k comes back bit for bit, as in spline_interpolate_3a) that is: segment
+// i = max{k <= nseg-1 : x_k <= v1}, evaluated at d = v1 - x_i, and the x_last select.  The segment comes from a uniform grid over [x_0, x_last]:
+// cell(v) = min(u32((v - x_0) * scale), 255) is monotone in v (each f32 step is), so every knot in an earlier cell is below v1 and every knot in a
+// later one above it; the host admits a curve only when no cell holds two knots (besides x_0), which leaves ONE comparison -- against the knot in v1's
+// own cell.  Per pixel: one 8-byte LDS read by cell {record offset, that knot's x}, one compare, the segment record (b128 + b32), the polynomial --
+// where the literal search runs two to six dependent LDS probes inside a per-lane loop.  Needs what the 3-knot form needs: finite coefficients, knot
+// ordinates that are not -0.0 (spline_grid_ok); NaN arguments differ (y_0 instead of the first probe's knot) and never reach the curve in a lane
+// whose result is used: the point-wise stages flag non-finite inputs and redo them literally.  Equality with the literal search on EVERY f32 is
+// checked on the device per curve (ipk_selftest_spline3).
+constexpr int kGridCells = 256;
+constexpr int kGridFloats = 2 * kGridCells + 8 * kSplineMaxKnots;     // cells {record byte offset, knot x}, then one 8-float record per segment
+__device__ __host__ inline uint32_t spline_grid_cell(float v1, float x0, float scale) {
+  const float t = (v1 - x0) * scale;                                   // >= 0: v1 >= x0
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t c = __float2uint_rz(t);                               // saturating
+#else
+  const uint32_t c = !(t < 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)t;
+#endif
+  return c < (uint32_t)(kGridCells - 1) ? c : (uint32_t)(kGridCells - 1);
+}
+// called by the first kGridCells threads of a block (before its barrier); reads the curve from the kernel arguments
+__device__ __forceinline__ void fill_grid(float *__restrict__ g, const SplineDev &s, int t) {
+  if (t >= kGridCells) return;
+  const float x0 = s.px[0];
+  uint32_t base = 0u; float nx = __builtin_inff();
+  for (int k = 1; k < s.nseg; ++k) {
+    const uint32_t ck = spline_grid_cell(s.px[k], x0, s.grid_scale);
+    if (ck < (uint32_t)t) base = (uint32_t)k;
+    else if (ck == (uint32_t)t) nx = s.px[k];                          // at most one (host-checked)
+  }
+  g[2 * t] = __uint_as_float((2u * kGridCells + 8u * base) * 4u);
+  g[2 * t + 1] = nx;
+  if (t < s.nseg) {
+    float *r = g + 2 * kGridCells + 8 * t;
+    r[0] = s.px[t]; r[1] = s.py[t]; r[2] = s.c1[t]; r[3] = s.c2[t]; r[4] = s.c3[t]; r[5] = 0.0f; r[6] = 0.0f; r[7] = 0.0f;
+  }
+}
+__device__ __forceinline__ float spline_interpolate_grid(const SplineDev &s, const float *__restrict__ g, float val) {
+  const float x0 = s.px[0];
+  const float v1 = fmaxf(val, x0);
+  const uint32_t c = spline_grid_cell(v1, x0, s.grid_scale);
+  const float2 ce = reinterpret_cast<const float2 *>(g)[c];
+  const uint32_t off = __float_as_uint(ce.x) + (ce.y <= v1 ? 32u : 0u);
+  const float *rec = reinterpret_cast<const float *>(reinterpret_cast<const char *>(g) + off);
+  const float4 q = *reinterpret_cast<const float4 *>(rec);
+  const float r = spline_poly(q.y, q.z, q.w, rec[4], v1 - q.x);
+  return (val >= s.grid_xl) ? s.grid_yl : r;
 }
 
 // the LDS image of a curve: called by the first kKnotFloats threads of a block (before its barrier)
@@ -438,12 +429,6 @@ __device__ __forceinline__ bool cdiv_guard(float x) {
   const int e = __builtin_amdgcn_frexp_expf(x);
   return (unsigned)(e + 99) > 199u;
 }
-template <bool EXACT>
-__device__ __forceinline__ float cdiv(float x, float c, float rc) {
-  if (EXACT) return x / c;
-  return cdiv_fast(x, c, rc);
-}
-
 // ---- LDS table staging ---------------------------------------------------------------------
 __device__ __forceinline__ void load_lut_pairs(LutPair *__restrict__ lds, const LutPair *__restrict__ g) {
   // 8192 pairs = 4096 float4; all threads of the block cooperate, 16 B per lane per step

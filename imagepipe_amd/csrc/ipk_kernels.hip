@@ -17,173 +17,20 @@
 
 using namespace ipkd;
 
-// Development-only timing ablations (never defined in the product build; results are wrong by construction):
-//   1 no out-of-table Lab branch, 2 +no gamma, 3 +no curve, 4 no point-wise stage at all, 5 +no demosaic
-#ifndef IPK_ABLATE
-#define IPK_ABLATE 0
-#endif
-// development only, timing / counter studies of the complete fused kernel (wrong results): IPK_ABL_STORE 1 = the result goes through the LDS staging
-// buffer but is not stored, 2 = neither staged nor stored, 3 = stored into a cache-resident 12 MB; IPK_ABL_LOAD 1 = the row loop loads nothing (it reuses the rows its task was primed with)
-#ifndef IPK_ABL_STORE
-#define IPK_ABL_STORE 0
-#endif
-#ifndef IPK_ABL_LOAD
-#define IPK_ABL_LOAD 0
-#endif
-// Round-2 instruction-class substitutions (each measured on the same box against its =0 build, profiles/README.md):
-//   (tried, no gain: LDS table addresses by an f32 fma on denormal operands -- exact integer arithmetic at the full issue rate --
-//    instead of the half-rate v_lshl_add_u32: 0.628 vs 0.628 ms on noise, 0.499 vs 0.502 on photo-like data)
-//   IPK_OPT_NOZEROADD  the fused kernel's demosaic sums start from their first tap instead of `0.0 + tap` (see demosaic_inner_px)
-//   IPK_OPT_SPLINE_REC per-segment curve records in LDS: one address select instead of five (ipk_device.hpp)
-#ifndef IPK_OPT_NOZEROADD
-#define IPK_OPT_NOZEROADD 1
-#endif
-//   IPK_OPT_LINSKIP    lab_to_xyz's linear branches behind wave-uniform tests (see pointwise4_fast)
-#ifndef IPK_OPT_LINSKIP
-#define IPK_OPT_LINSKIP 1
-#endif
-//   IPK_OPT_LOSKIP     the Lab lookup's negative-ratio branch behind its own wave-uniform test (noise 0.600 -> 0.591 ms, photo 0.470 -> 0.473)
-#ifndef IPK_OPT_LOSKIP
-#define IPK_OPT_LOSKIP 1
-#endif
-//   IPK_OPT_LABPAIRS / IPK_OPT_GAMPAIRS   the LDS copy of a lookup table as {v[i], v[i+1]-v[i]} pairs (64 KB) instead of the plain 8193 floats
-//                      (32 KB): one ds_read_b64 per lookup -- 2 LDS cycles per wave when conflict-free, banks mod 64 -- instead of a ds_read2_b32
-//                      (4 cycles, banks mod 32), and the subtraction of color_conversions.rs:112 is done once per table entry, when the block
-//                      fills its LDS, instead of once per lookup (the same f32 subtraction on the same operands)
-#ifndef IPK_OPT_LABPAIRS
-#define IPK_OPT_LABPAIRS 1
-#endif
-//                      Measured against the plain builds on one box (tools/ab.sh): Lab pairs noise 0.5917 -> 0.5898 ms, photo 0.4748 -> 0.4686, smooth
-//                      0.5735 -> 0.5679; gamma pairs as well (u8 output) noise 0.5941 -> 0.5898, photo 0.4696 -> 0.4636.  Halving the LDS cycles
-//                      buys 1 %: the kernel is not waiting for its LDS.  Variants without the room keep a plain table: generic CFA (cell
-//                      records in LDS), and the gamma table when the output is f32 (48 KB of staging; 64 + 64 + 48 KB > 160 KB).
-#ifndef IPK_OPT_GAMPAIRS
-#define IPK_OPT_GAMPAIRS 1
-#endif
-//   IPK_OPT_PRIME4     a task's first four row loads issued together: one memory round trip per task instead of three (priming 3.1 -> 2.0 us per task in
-//                      the probe build).  No gain when first measured; with the takeovers a wave starts a few more tasks and it is worth 0.7-1 % at
-//                      100 MP (noise 0.4972 -> 0.4923 ms, photo-like 0.3880 -> 0.3853, four repetitions), nothing at 24 MP: on since then
-#ifndef IPK_OPT_PRIME4
-#define IPK_OPT_PRIME4 1
-#endif
-//   IPK_OPT_SPLINE3A   the common-parameter variants' 3-knot base curve with its lower clamp and knot hit as arithmetic (spline_interpolate_3a); the
-//                      host admits a curve to those variants only when spline3_arith_ok() holds
-#ifndef IPK_OPT_SPLINE3A
-#define IPK_OPT_SPLINE3A 1
-#endif
-//   IPK_OPT_UNROLL3    the row loop of the common-parameter Bayer variants as three copies of its body with the three-row window in rotating roles
-//                      (no 18 register copies per row, three times the code): noise 0.544 -> 0.550 ms, photo 0.435 -> 0.445 -- off
-#ifndef IPK_OPT_UNROLL3
-#define IPK_OPT_UNROLL3 0
-#endif
-//   IPK_OPT_FAIRPRIO   launches without a queue (one task per wave): issue priority that falls as a wave advances through its task (see row_step)
-#ifndef IPK_OPT_FAIRPRIO
-#define IPK_OPT_FAIRPRIO 1
-#endif
-//   IPK_OPT_W8M_XCD    config 5's scaled-demosaic kernel launched so that neighbouring output rows run on one XCD (see k_raw_scaled_demosaic_w8m)
-#ifndef IPK_OPT_W8M_XCD
-#define IPK_OPT_W8M_XCD 1
-#endif
-//   IPK_OPT_COLD       the wave-uniform tests of the rare paths marked unlikely, so that their code is laid out behind the loop and the common path
-//                      runs through not-taken branches (a taken branch makes the wave refetch its instruction buffer)
-#ifndef IPK_OPT_COLD
-#define IPK_OPT_COLD 1
-#endif
-#if IPK_OPT_COLD
+// What was measured and not kept (instruction-class substitutions, LDS read ordering, unrolled row loops, load-first pipelining, queue shapes,
+// ablation builds) lives in profiles/README.md "experiment log" with the commit that last carried each switch; this file holds the shipped form only.
+//
+// Wave-uniform tests of rare paths are marked unlikely, so that their code is laid out behind the loop and the common path runs through not-taken
+// branches (a taken branch makes the wave refetch its instruction buffer).
 #define IPK_RARE(x) __builtin_expect(!!(x), 0)
-#else
-#define IPK_RARE(x) (x)
-#endif
-//   IPK_OPT_LDSORDER   the point-wise stages' LDS reads issued as batches with independent arithmetic behind them (pointwise4_fast): the multipliers and
-//                      the matrix asked for in front of the demosaic, all twelve Lab / gamma lookups back to back with their weights behind them, the
-//                      four curve records and the output matrix together with A and B computed meanwhile -- in hipcc's own order a row has about eight
-//                      LDS round trips with nothing behind them (four reads, consume, eight reads; the curve per pixel pair).  Measured on three boxes,
-//                      five repetitions: noise 0.5141 vs 0.5148 ms, photo 0.4090 vs 0.4092 (one box: photo -1.3 %, noise +1 %): the other three waves
-//                      of the SIMD already cover those waits.  Off: it costs the last spare VGPRs (128 of 128).
-#ifndef IPK_OPT_LDSORDER
-#define IPK_OPT_LDSORDER 0
-#endif
-//   IPK_OPT_NTOUT      the fused kernels' results (f32, 8-bit, 16-bit) through nontemporal stores (OutStage<>::flush): the result is written once and not
-//                      read again by the launch, and no longer displaces the mosaic rows in the caches: 100 MP noise 0.5040 -> 0.4969 ms, photo-like
-//                      0.4004 -> 0.3904, 24 MP 0.1275 -> 0.1239, 64 x 24 MP 0.1154 -> 0.1137 per frame (same box, four repetitions)
-#ifndef IPK_OPT_NTOUT
-#define IPK_OPT_NTOUT 1
-#endif
-//   IPK_OPT_LOADFIRST  (with PRIME4) the loads of row r+3 are issued BEFORE row r's stores (right behind the wait for row r+2), and a task primes row r0+2
-//                      first, so that nothing of the priming is in flight at the loop's entry: hipcc then waits for the row with a COUNT that leaves the three
-//                      younger stores in flight (s_waitcnt vmcnt(4) / vmcnt(3) instead of vmcnt(0)).  Measured neutral (noise 0.5055 -> 0.5054 ms, photo-like
-//                      0.4012 -> 0.3988, two repetitions): the waves do not wait for their stores -- a probe build has them parked 18 (noise) / 60 (photo-like)
-//                      cycles per row at that wait, 0.2 % / 0.9 % of their time (tools/wave_timeline.py).  Keeping TWO rows of loads in flight (two register
-//                      sets in alternating roles, row loop unrolled twice) cannot be expressed: hipcc's wait for the older set is vmcnt(4) where vmcnt(9) would
-//                      do, which waits for the younger set as well.  Left off.
-#ifndef IPK_OPT_LOADFIRST
-#define IPK_OPT_LOADFIRST 0
-#endif
-//   IPK_OPT_STEAL      once the task queue is dry, a wave that has finished takes over the lower half of the rows that the wave of its BLOCK with the
-//                      most rows left has not begun (descriptors in LDS, one 64-bit compare-and-swap per takeover; see fused_bayer_body)
-#ifndef IPK_OPT_STEAL
-#define IPK_OPT_STEAL 1
-#endif
-//   IPK_OPT_CBRT_EXEC  the out-of-table patch of the Lab stage (cube root for lanes above 1, linear branch for negative ones) under the mask of the lanes that
-//                      need it instead of on all lanes with a select behind: the same instructions are issued, but on the noise frame only a tenth to a
-//                      third of the lanes switch the f64 data path.  The kernel is bound by the socket's power cap: what the idle lanes
-//                      do not burn comes back as clock -- 100 MP noise 0.4748 -> 0.4517 ms, 24 MP 0.1173 -> 0.1120; photo-like and smooth data unchanged
-//   IPK_OPT_SPAR       white-balance multipliers, camera matrix and XYZ -> RGB matrix as SCALAR operands from the kernel arguments instead of 24 broadcast reads of
-//                      their LDS copy per row into vector registers (round 1 moved them to LDS to spare scalar registers): 24 LDS instructions per row and a
-//                      vector-register read per multiply less -- 100 MP noise 0.4761 -> 0.4673 ms, photo-like 0.3928 -> 0.3835, 24 MP 0.1174 -> 0.1159 / 0.0962 -> 0.0941
-#ifndef IPK_OPT_SPAR
-#define IPK_OPT_SPAR 1
-#endif
-#ifndef IPK_OPT_CBRT_LIKELY
-#define IPK_OPT_CBRT_LIKELY 1
-#endif
-#ifndef IPK_OPT_CBRT_EXEC
-#define IPK_OPT_CBRT_EXEC 1
-#endif
-#ifndef IPK_MIN_TASK_ROWS
-#define IPK_MIN_TASK_ROWS 4
-#endif
-#ifndef IPK_OPT_SPREAD
-#define IPK_OPT_SPREAD 4
-#endif
-#ifndef IPK_STEAL_MIN
-#define IPK_STEAL_MIN 4
-#endif
-#ifndef IPK_STEAL_STATIC   // takeovers also in launches that draw nothing (one task per wave: single frames under ~130 MP)
-#define IPK_STEAL_STATIC 1
-#endif
-// Round-3 switches (each measured against its =0 build on one box, profiles/README.md):
-//   IPK_OPT_SLOTMASK   the out-of-table patch of the Lab stage with one independent compare per mask (see pointwise4_fast)
-#ifndef IPK_OPT_SLOTMASK
-#define IPK_OPT_SLOTMASK 1
-#endif
-//   (kept unconditionally: the task position is wave-uniform for the compiler -- readfirstlane -- so the row counter, the row parity and the strip
-//    parity live in scalar registers and the demosaic's role dispatch is scalar branches instead of exec-mask regions: noise 0.529 -> 0.521 ms)
+constexpr uint32_t kSpread = 4;        // static schedule: a block's waves start on groups of kSpread neighbouring tasks a round of blocks apart (fused_bayer_body)
+constexpr uint32_t kMinTaskRows = 4;   // one task per wave: at least this many rows each (fused_task_grid)
+constexpr uint32_t kStealMin = 4;      // a takeover needs at least this many rows left behind the owner's current one
 
 namespace ipk {
 
-#ifdef IPK_DEV_PROBE   // development only (tools/wave_timeline.py): per-wave time stamps of the row-walking kernels, 8 x u64 per wave
-__device__ unsigned long long g_probe[4096 * 8];
-__device__ unsigned long long g_probe2[4096 * 4];   // per wave: cycles in the wait for the next row's loads, cycles from staging to the last store's issue, spare, spare
-}  // namespace ipk
-extern "C" __attribute__((visibility("default"))) int ipk_dev_probe2_read(unsigned long long *out, size_t n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipk::g_probe2), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
-}
-extern "C" __attribute__((visibility("default"))) int ipk_dev_probe_read(unsigned long long *out, size_t n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipk::g_probe), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
-}
-namespace ipk {
-#endif
-#if IPK_OPT_LABPAIRS
 typedef LutPair LabTab;
-#else
-typedef float LabTab;
-#endif
-#if IPK_OPT_GAMPAIRS
 typedef LutPair GamTab;
-#else
-typedef float GamTab;
-#endif
 // A block's LDS copies of the two plain 8193-float tables, each in either form (all threads of the block; before its barrier).
 // With the usual 1024 threads every thread issues ALL its global loads (8 or 16 per table) before the first LDS write, so the block pays
 // the L2 latency once instead of once per loop iteration -- the prologue is a tenth of the point-wise chain's run time on a 3 MP preview.
@@ -248,33 +95,19 @@ static inline dim3 grid_rows_few(size_t width, size_t height, int bx, unsigned t
 // Table-free streaming kernels (one element or four per thread) are launched FLAT -- as many blocks as the data needs, the grid-stride loop runs
 // once -- where round 2 capped them at 16 blocks per CU: neighbouring blocks run at the same time and touch neighbouring addresses, which the
 // memory system rewards (a plain copy: 5.0-5.2 TB/s through a capped grid-stride loop, 6.3-6.45 flat; tools/copy_probe.hip).  IPK_OPT_FLATGRID.
-#ifndef IPK_OPT_FLATGRID
-#define IPK_OPT_FLATGRID 1
-#endif
-static inline unsigned flat_cap(unsigned capped) { return IPK_OPT_FLATGRID ? 0x7FFFFFFFu : capped; }
+static inline unsigned flat_cap(unsigned) { return 0x7FFFFFFFu; }
 // The staged kernels read every byte once and write every byte once: nontemporal accesses (IPK_OPT_NT) keep those streams from displacing each
 // other in the L2 / Infinity Cache (plain copy 6.0 -> 6.45 TB/s, tools/copy_probe.hip).
-#ifndef IPK_OPT_NT
-#define IPK_OPT_NT 1
-#endif
 typedef float ipk_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_stream4(const float *p) {
-#if IPK_OPT_NT
   const ipk_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ipk_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return *reinterpret_cast<const float4 *>(p);
-#endif
 }
 __device__ __forceinline__ void st_stream4(float *p, float4 v) {
-#if IPK_OPT_NT
   ipk_f4v q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w; __builtin_nontemporal_store(q, reinterpret_cast<ipk_f4v *>(p));
-#else
-  *reinterpret_cast<float4 *>(p) = v;
-#endif
 }
-__device__ __forceinline__ float ld_stream(const float *p) { return IPK_OPT_NT ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void st_stream(float *p, float v) { if (IPK_OPT_NT) __builtin_nontemporal_store(v, p); else *p = v; }
-template <typename U> __device__ __forceinline__ void st_stream_u(U *p, U v) { if (IPK_OPT_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+template <typename U> __device__ __forceinline__ void st_stream_u(U *p, U v) { __builtin_nontemporal_store(v, p); }
 static inline unsigned grid_1d(size_t n, int bx, unsigned cap) {
   size_t g = (n + bx - 1) / bx;
   if (g < 1) g = 1;
@@ -847,13 +680,10 @@ constexpr uint32_t kW8MaxCells = 144;
 // per LDS instruction, the LDS busy for 61 of the kernel's 72 us (profiles/r02_c5_pmc.json).  One float4 of padding per cell moves
 // neighbouring cells 16 bytes apart modulo 128: SQ_LDS_BANK_CONFLICT 21.6 M -> 0 cycles per launch, 0.072 -> 0.063 ms.
 constexpr uint32_t kW8CellF4 = 9;
-#ifndef IPK_W8M_WAVES
-#define IPK_W8M_WAVES 1
-#endif
 // KU = the window columns every lane of every wave has (floor(skip) + 1, capped at 5): their taps are straight-line code; further columns (a
 // window whose phase wraps, the shifted loads at the right frame edge) sit behind one wave-uniform branch.
 template <typename T, uint32_t KU>
-__global__ __launch_bounds__(256, IPK_W8M_WAVES) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
+__global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
                                                                 uint32_t pw, uint32_t ph, float *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
   __shared__ uint16_t s_bits[kW8MaxCells];                            // the same colours, 2 bits per column (select form)
@@ -1060,40 +890,26 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   if (a.skip_x_x >= 1.0f && a.skip_x_x <= 7.0f && a.skip_y_y >= 1.0f && a.skip_y_y <= 7.0f && width >= 8 &&
       (reinterpret_cast<uintptr_t>(dst4) & 15) == 0) {
     const unsigned gx = (unsigned)((nwidth + 255) / 256);
-#ifdef IPK_DEV_KNOBS
-    const unsigned total_blocks = getenv("IPK_DEV_W8_BLOCKS") ? (unsigned)atoi(getenv("IPK_DEV_W8_BLOCKS")) : 4096u;
-#else
     const unsigned total_blocks = 5376u;                                     // 21 blocks per CU = 3 full rounds of the 7 resident ones; measured flat 3584 .. 7168
-#endif
     const unsigned want = std::max(1u, total_blocks / gx);                   // ~16 blocks of 256 threads per CU in total
     const dim3 grid2(gx, (unsigned)std::min<size_t>(out_rows, want), 1);     // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
     const dim3 grid = grid2;
-#ifndef IPK_W8_SELECT
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
       const size_t lds = (size_t)pw * ph * kW8CellF4 * 4 * sizeof(float);
-#if IPK_OPT_W8M_XCD
       dim3 grid = grid2;
       a.xcd_gx = 0; a.xcd_gy = 0;
       {
         uint32_t group = 2;     // block rows per XCD in a run (sweep below)
-#ifdef IPK_DEV_KNOBS
-        if (getenv("IPK_DEV_W8_GROUP")) group = (uint32_t)atoi(getenv("IPK_DEV_W8_GROUP"));
-#endif
         if (group > 0 && grid2.y >= 8 * group) {
           a.xcd_gx = grid2.x; a.xcd_group = group; a.xcd_gy = grid2.y / (8 * group) * (8 * group);
           grid = dim3(a.xcd_gx * a.xcd_gy, 1, 1);
         }
       }
-#else
-      const dim3 grid = grid2;
-      a.xcd_gx = 0; a.xcd_gy = 0;
-#endif
       if (a.skip_x_x >= 4.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 5>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       else if (a.skip_x_x >= 2.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 3>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       else hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 2>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
       return;
     }
-#endif
     hipLaunchKernelGGL(k_raw_scaled_demosaic_w8<T>, grid, dim3(256), 0, s, src, a, cfa48_dev, dst4);
     return;
   }
@@ -1210,10 +1026,29 @@ static ToLabParams make_tolab(const float *mul4, const float *cm12) {
 }
 // spline_interpolate_3a's precondition (ipk_device.hpp): finite coefficients, knot ordinates that are not -0.0
 static bool spline3_arith_ok(const SplineDev &d) {
-  if (!IPK_OPT_SPLINE3A) return true;
   for (int i = 0; i < 3; ++i) {
     if (!std::isfinite(d.px[i]) || !std::isfinite(d.py[i]) || (d.py[i] == 0.0f && std::signbit(d.py[i]))) return false;
     if (i < 2 && !(std::isfinite(d.c1[i]) && std::isfinite(d.c2[i]) && std::isfinite(d.c3[i]))) return false;
+  }
+  return true;
+}
+// spline_interpolate_grid's preconditions (ipk_device.hpp): four or more knots, strictly increasing abscissae, finite coefficients, knot ordinates that
+// are not -0.0, and no grid cell with two knots (x_0 aside) under the very arithmetic the kernels use for the cell
+static bool spline_grid_ok(const SplineDev &d, float &scale) {
+  if (d.npoints < 4 || d.npoints > kSplineMaxKnots || d.nseg != d.npoints - 1) return false;
+  for (int i = 0; i < d.npoints; ++i) {
+    if (!std::isfinite(d.px[i]) || !std::isfinite(d.py[i]) || (d.py[i] == 0.0f && std::signbit(d.py[i]))) return false;
+    if (i > 0 && !(d.px[i] > d.px[i - 1])) return false;
+    if (i < d.nseg && !(std::isfinite(d.c1[i]) && std::isfinite(d.c2[i]) && std::isfinite(d.c3[i]))) return false;
+  }
+  const float span = d.px[d.npoints - 1] - d.px[0];
+  scale = (float)kGridCells / span;
+  if (!(span > 0.0f) || !std::isfinite(scale) || !(scale > 0.0f)) return false;
+  uint32_t prev = 0; bool have = false;
+  for (int k = 1; k < d.nseg; ++k) {
+    const uint32_t ck = spline_grid_cell(d.px[k], d.px[0], scale);
+    if (have && ck <= prev) return false;
+    prev = ck; have = true;
   }
   return true;
 }
@@ -1221,6 +1056,9 @@ static SplineDev make_spline(const SplineHost &h) {
   SplineDev d;
   d.npoints = h.npoints; d.nseg = h.nseg;
   for (int i = 0; i < kSplineMaxKnots; ++i) { d.px[i] = h.px[i]; d.py[i] = h.py[i]; d.c1[i] = h.c1[i]; d.c2[i] = h.c2[i]; d.c3[i] = h.c3[i]; }
+  d.grid_ok = 0; d.grid_scale = 0.0f; d.grid_xl = 0.0f; d.grid_yl = 0.0f;
+  float scale;
+  if (spline_grid_ok(d, scale)) { d.grid_ok = 1; d.grid_scale = scale; d.grid_xl = d.px[d.npoints - 1]; d.grid_yl = d.py[d.npoints - 1]; }
   return d;
 }
 
@@ -1598,11 +1436,7 @@ __device__ __forceinline__ float4 demosaic_gen_px(const float *__restrict__ cell
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
   #pragma unroll
   // the weights are 0 or 1, so t * w is exact and the fused form rounds the same sum once: s + t*w bit for bit, in one instruction instead of two
-#ifdef IPK_GEN_NOFMA   // development A/B only
-  for (int i = 0; i < 9; ++i) { s0 = s0 + t[i] * w[i]; s1 = s1 + t[i] * w[9 + i]; s2 = s2 + t[i] * w[18 + i]; }
-#else
   for (int i = 0; i < 9; ++i) { s0 = __builtin_fmaf(t[i], w[i], s0); s1 = __builtin_fmaf(t[i], w[9 + i], s1); s2 = __builtin_fmaf(t[i], w[18 + i], s2); }
-#endif
   return make_float4(__builtin_fmaf(s0, w[28], s0 * w[31]), __builtin_fmaf(s1, w[29], s1 * w[32]), __builtin_fmaf(s2, w[30], s2 * w[33]), 0.0f);
 }
 // The literal form (demosaic.rs:99-114) from the packed tap colours: frame-edge pixels (taps outside the image are
@@ -1642,12 +1476,6 @@ constexpr float kRcLabK = 1.0f / kLabK;
 // instructions (v_pk_mul/add/fma_f32) were tried for the pairs and measured slower than scalar code on MI355X
 // (tools/ubench.hip: v_mul/v_add 2.75 cycles per wave64 instruction, v_pk_* 4.8, v_fma 4.1), so the pair type is a
 // plain struct and the translation unit is built with -fno-slp-vectorize.
-#ifdef IPK_PACKED_PAIRS   // measured slower on MI355X (v_pk_* = 4.8 cycles vs 2 x 2.75 for mul/add, plus packing moves): off
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 F2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
-__device__ __forceinline__ f2 S2(float a) { f2 r; r.x = a; r.y = a; return r; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-#else   // pixel pairs as two scalars; the build also passes -fno-slp-vectorize (0.96 -> 0.87 ms on the 100 MP frame)
 struct f2 { float x, y; };
 __device__ __forceinline__ f2 F2(float a, float b) { return f2{a, b}; }
 __device__ __forceinline__ f2 S2(float a) { return f2{a, a}; }
@@ -1656,7 +1484,6 @@ __device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y +
 __device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
-#endif
 __device__ __forceinline__ f2 min2(f2 a, float m) { return F2(rs_min(a.x, m), rs_min(a.y, m)); }
 
 // 1/c = rc_hi + rc_lo.  q = fma(x, rc_hi, x*rc_lo) equals x/c for EVERY finite x with 2^-100 <= |x| <= 2^100 for the
@@ -1679,11 +1506,7 @@ __device__ __forceinline__ float cdiv3s1(float x, float c, float rc) {
 // XYZ_LAB_TRANSFORM.lookup's direct branch for v > 1 (color_conversions.rs:103-104,123): cbrtf; the short form when the
 // whole wave's out-of-table values are below 2
 __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
-#if IPK_OPT_CBRT_LIKELY
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(hi && v >= 2.0f) == 0, 1)) return cbrtf_glibc_1to2(v);
-#else
-  if (__builtin_amdgcn_ballot_w64(hi && v >= 2.0f) == 0) return cbrtf_glibc_1to2(v);
-#endif
   return cbrtf_glibc_sel(v);
 }
 
@@ -1704,7 +1527,6 @@ __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
 //    runs for every lane and out-of-table values (bit pattern above 1.0f; -0 is also caught and takes the linear
 //    branch, which yields table[0] bit-for-bit) are patched afterwards behind wave-uniform branches;
 //  * v.max(0).min(1) -> v_med3_f32 (proven equal on every f32 up to the sign of zero, which the lookup ignores).
-struct FastBad { bool b; };
 // `par` = LDS copy of the uniform parameters (mul[0..3], cm[4..15], rgbm[16..24]): read through the LDS they end up in
 // vector registers instead of competing with the wave's many 64-bit condition masks for scalar registers.
 // Written for the lane's FOUR pixels (two pairs) stage by stage, so that each table stage issues its 12 LDS reads
@@ -1725,19 +1547,15 @@ template <bool PXG, bool TOLAB_ONLY = false, typename LT, typename GT>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const LT *__restrict__ s_lab,
                                                 const GT *__restrict__ s_gam, const float *__restrict__ s_knots,
                                                 const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false,
-                                                const float *__restrict__ par_regs = nullptr) {
+                                                const float *__restrict__ par_regs = nullptr, const float *__restrict__ s_grid = nullptr) {
   bool bad = false;
   float v[12], f[12];
   f2 y[2];
-#if IPK_OPT_SPAR
   // the multipliers and the camera matrix as SCALAR operands straight from the kernel arguments (s_load through the constant cache, re-read where the
   // scalar registers are short) instead of sixteen broadcast reads of the LDS copy per row into vector registers
   const float spar[16] = {a.tolab.mul[0], a.tolab.mul[1], a.tolab.mul[2], a.tolab.mul[3], a.tolab.cm[0], a.tolab.cm[1], a.tolab.cm[2], a.tolab.cm[3], a.tolab.cm[4],
                           a.tolab.cm[5], a.tolab.cm[6], a.tolab.cm[7], a.tolab.cm[8], a.tolab.cm[9], a.tolab.cm[10], a.tolab.cm[11]};
   const float *const par0 = spar;
-#else
-  const float *const par0 = par_regs ? par_regs : par;       // par[0..14] already in registers (the caller read them early), or straight from LDS
-#endif
   #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
@@ -1757,28 +1575,11 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     float pos[12]; LutPair e[12];
     #pragma unroll
     for (int k = 0; k < 12; ++k) pos[k] = v[k] * kLutMaxF;
-#if IPK_OPT_LDSORDER
-    // all twelve keys first, then the twelve reads back to back with the twelve weights behind them: the first read's answer is needed some
-    // forty instructions after it was asked for (hipcc on its own issued four reads, consumed them, then the other eight)
-    uint32_t key[12]; float w[12];
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) key[k] = f32_as_u32_sat(pos[k]);
-    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) e[k] = lut_raw_at(s_lab, key[k]);
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) w[k] = __builtin_amdgcn_fractf(pos[k]);
-    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) { e[k] = lut_raw_to_pair(s_lab, e[k]); f[k] = e[k].x + w[k] * e[k].y; }
-#else
     #pragma unroll
     for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k]));
     #pragma unroll
     for (int k = 0; k < 12; ++k) f[k] = e[k].x + __builtin_amdgcn_fractf(pos[k]) * e[k].y;
-#endif
   }
-#if IPK_ABLATE < 1
   // (Tried and measured, round 1: compacting the v > 1 lanes of all 12 slots through a per-wave LDS queue -- ballot + mbcnt
   // ranks, cbrtf on dense groups of 64, results scattered back -- instead of one cbrtf per slot with most lanes idle.  On
   // uniform noise, where every slot has a few such lanes, it removes 7 % of the VALU instructions and 6 % of the time
@@ -1795,7 +1596,6 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // progressive waits let the first lerps start while the last reads are still in flight, and a wait that is already satisfied costs little.)
   // (Round 2, again without gain: ONE wave-level test -- the OR of the twelve compare masks -- in front of the per-slot tests: noise 0.591 ->
   // 0.621 ms, photo 0.473 -> 0.480, smooth 0.572 -> 0.595.)
-#if IPK_OPT_SLOTMASK
   // One slot = one table-stage value of all 64 lanes.  Per slot that stays in the table this costs a compare and a branch; a slot with lanes above
   // 1 adds one compare, the cube root and one select, and the negative / NaN lanes (their own compare: as a bit pattern they are exactly the
   // values above +inf's) the linear branch.  (Round 2 derived the third mask from the first two -- hipcc moves such a mask through a VGPR to
@@ -1812,66 +1612,21 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       // In the common-parameter variants (CMN -- `curve3`); the linear branch for negative ratios below is masked only where there are no per-pixel
       // guards (PXG == false): with the guards' registers live as well BOTH masked regions spill (X-Trans full resolution 0.295 -> 0.338 ms with 36
       // bytes of scratch), the cube root's alone does not (X-Trans noise 0.305 -> 0.288 ms).
-      if (IPK_OPT_CBRT_EXEC && curve3) { if (__builtin_amdgcn_ballot_w64(hi) != 0) { if (hi) f[k] = lab_cbrt(v[k], true); } }
+      if (curve3) { if (__builtin_amdgcn_ballot_w64(hi) != 0) { if (hi) f[k] = lab_cbrt(v[k], true); } }
       else if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
       const bool lo = __float_as_uint(v[k]) > 0x7F800000u;            // negative (or -0), or NaN: out of the table and not above 1
-      if (IPK_OPT_CBRT_EXEC && !PXG && curve3) { if (__builtin_amdgcn_ballot_w64(lo) != 0) { if (lo) { const float dv = kLabK * v[k] + 16.0f; f[k] = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); } } }
+      if (!PXG && curve3) { if (__builtin_amdgcn_ballot_w64(lo) != 0) { if (lo) { const float dv = kLabK * v[k] + 16.0f; f[k] = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); } } }
       else if (__builtin_amdgcn_ballot_w64(lo) != 0)
       { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
     }
   }
-#else
-  #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const bool oor = __float_as_uint(v[k]) > 0x3F800000u;             // v > 1, v < 0, -0 or NaN
-    if (__builtin_amdgcn_ballot_w64(oor) != 0) {
-      const bool hi = v[k] > 1.0f, lo = oor && !hi;
-      if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
-      // the linear branch for negative ratios: / 116 as the proven two-step form -- its dividend k*v + 16 is 0 or a multiple of 2^-20
-      // (a difference against 16) and at most 2^61 in magnitude.  (Round 1 evaluated it for every slot that had any out-of-table lane;
-      // ratios below zero need a sample below black AND a negative matrix row sum, so it now has its own wave-uniform test.)
-#if IPK_OPT_LOSKIP
-      if (__builtin_amdgcn_ballot_w64(lo) != 0)
-#endif
-      { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
-    }
-  }
-#endif
-#endif
   f2 rr[2], gg[2], bb[2];
   f2 Lq[2], Aq[2], Bq[2];
   // the XYZ -> sRGB matrix (par[16..24]): read where LDS_ORDER puts the curve's reads, used at the very end
   float pm[9];
-#if IPK_OPT_LDSORDER
-  constexpr bool kSplit = IPK_OPT_SPLINE3A && !TOLAB_ONLY;
-  if (kSplit && has_curve && curve3 && IPK_ABLATE < 3) {
-    // L of all four pixels first; their four curve-record reads and the nine matrix reads go out together; A and B are computed while those are
-    // in flight; then the four polynomials.  (Per pixel pair, as below, every pair paid the LDS round trip again.)
-    #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const f2 fy = F2(f[6 * g + 2], f[6 * g + 3]);
-      Lq[g] = cdiv2s(S2(116.0f) * fy - S2(16.0f), rc_hi(100.0f), rc_lo(100.0f));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    Spline3Rec rec[4];
-    #pragma unroll
-    for (int g = 0; g < 2; ++g) { rec[2 * g] = spline3a_fetch(a.spline, s_knots, Lq[g].x); rec[2 * g + 1] = spline3a_fetch(a.spline, s_knots, Lq[g].y); }
-    #pragma unroll
-    for (int i = 0; i < 9; ++i) pm[i] = par[16 + i];
-    #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
-      Aq[g] = cdiv2s(S2(500.0f) * (fx - fy) + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-      Bq[g] = cdiv2s(S2(200.0f) * (fy - fz) + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-    for (int g = 0; g < 2; ++g) Lq[g] = F2(spline3a_eval(a.spline, rec[2 * g], Lq[g].x), spline3a_eval(a.spline, rec[2 * g + 1], Lq[g].y));
-  } else
-#endif
   {
     #pragma unroll
-    for (int i = 0; i < 9; ++i) pm[i] = TOLAB_ONLY ? 0.0f : (IPK_OPT_SPAR ? a.rgbm.m[i] : par[16 + i]);
+    for (int i = 0; i < 9; ++i) pm[i] = TOLAB_ONLY ? 0.0f : a.rgbm.m[i];
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
@@ -1881,9 +1636,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       f2 L = cdiv2s(l, rc_hi(100.0f), rc_lo(100.0f));
       Aq[g] = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
       Bq[g] = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
-      if (!TOLAB_ONLY && has_curve && IPK_ABLATE < 3) {
-        if (curve3) L = IPK_OPT_SPLINE3A ? F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y))
-                                         : F2(spline_interpolate_3(a.spline, s_knots, L.x), spline_interpolate_3(a.spline, s_knots, L.y));
+      if (!TOLAB_ONLY && has_curve) {
+        if (curve3) L = F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y));
+        else if (s_grid != nullptr && a.spline.grid_ok) L = F2(spline_interpolate_grid(a.spline, s_grid, L.x), spline_interpolate_grid(a.spline, s_grid, L.y));
         else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
       }
       Lq[g] = L;
@@ -1903,7 +1658,6 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const f2 gx = cdiv2s(ca, rc_hi(500.0f), rc_lo(500.0f)) + gy;
     const f2 gz = gy - cdiv2s(cb, rc_hi(200.0f), rc_lo(200.0f));
     const f2 gx3 = gx * gx * gx, gy3 = gy * gy * gy, gz3 = gz * gz * gz;
-#if IPK_OPT_LINSKIP
     // lab_to_xyz's linear branches (color_conversions.rs:183-187: f^3 <= e, L* <= k*e -- only the darkest tones) are evaluated for a
     // channel only when some lane of the wave takes one in this pixel pair: 6 + 9 + 6 instructions per pixel (a tenth of the kernel's
     // arithmetic) that bright and mid-tone frames never need.  NaN compares false and lands in the branch, as in the literal form.
@@ -1926,24 +1680,13 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
       zq = F2(zb0 ? gz3.x : lz.x, zb1 ? gz3.y : lz.y);
     }
-#else
-    const f2 lx = cdiv3s(S2(116.0f) * gx - S2(16.0f), kLabK, kRcLabK);
-    const f2 lz = cdiv3s(S2(116.0f) * gz - S2(16.0f), kLabK, kRcLabK);
-    const float ly0 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.x, kLabK, kRcLabK), kLabK, cl.x);
-    const float ly1 = __builtin_amdgcn_div_fixupf(cdiv3s1(cl.y, kLabK, kRcLabK), kLabK, cl.y);
-    const bool yb0 = cl.x > kLabK * kLabE, yb1 = cl.y > kLabK * kLabE;
-    if (has_curve) bad |= (!yb0 & cdiv_guard(cl.x)) | (!yb1 & cdiv_guard(cl.y));
-    const f2 xq = F2(gx3.x > kLabE ? gx3.x : lx.x, gx3.y > kLabE ? gx3.y : lx.y);
-    const f2 yq = F2(yb0 ? gy3.x : ly0, yb1 ? gy3.y : ly1);
-    const f2 zq = F2(gz3.x > kLabE ? gz3.x : lz.x, gz3.y > kLabE ? gz3.y : lz.y);
-#endif
     const f2 X = xq * S2(kWhiteX), Y = yq, Z = zq * S2(kWhiteZ);
     rr[g] = X * S2(pm[0]) + Y * S2(pm[1]) + Z * S2(pm[2]);
     gg[g] = X * S2(pm[3]) + Y * S2(pm[4]) + Z * S2(pm[5]);
     bb[g] = X * S2(pm[6]) + Y * S2(pm[7]) + Z * S2(pm[8]);
   }
   if (TOLAB_ONLY) return bad;
-  if (!linear && IPK_ABLATE < 2) {
+  if (!linear) {
     float pos[12]; LutPair e[12];
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -1952,31 +1695,13 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       #pragma unroll
       for (int k = 0; k < 6; ++k) pos[6 * g + k] = c[k] * kLutMaxF;
     }
-#if IPK_OPT_LDSORDER
-    uint32_t key[12]; float wq[12];
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) key[k] = f32_as_u32_sat(pos[k]);
-    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) e[k] = lut_raw_at(s_gam, key[k]);
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) wq[k] = __builtin_amdgcn_fractf(pos[k]);
-    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-    for (int k = 0; k < 12; ++k) e[k] = lut_raw_to_pair(s_gam, e[k]);
-#else
     #pragma unroll
     for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_gam, f32_as_u32_sat(pos[k]));
-#endif
     #pragma unroll
     for (int g = 0; g < 2; ++g) {
       float w[6];
       #pragma unroll
-#if IPK_OPT_LDSORDER
-      for (int k = 0; k < 6; ++k) w[k] = wq[6 * g + k];
-#else
       for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_fractf(pos[6 * g + k]);
-#endif
       const LutPair *p = e + 6 * g;
       rr[g] = F2(p[0].x, p[1].x) + F2(w[0], w[1]) * F2(p[0].y, p[1].y);
       gg[g] = F2(p[2].x, p[3].x) + F2(w[2], w[3]) * F2(p[2].y, p[3].y);
@@ -1997,10 +1722,10 @@ __device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const LT *
                                                   const float *__restrict__ s_knots, const float4 &p) {
   float l, ca, cb;
   camera_to_lab(s_lab, a.tolab, p.x, p.y, p.z, p.w, l, ca, cb);
-  if (a.has_curve && IPK_ABLATE < 3) l = spline_interpolate_lds(s_knots, a.spline.npoints, a.spline.nseg, l);
+  if (a.has_curve) l = spline_interpolate_lds(s_knots, a.spline.npoints, a.spline.nseg, l);
   PixOut o;
   lab_to_rgb(a.rgbm, l, ca, cb, o.r, o.g, o.b);
-  if (!a.linear && IPK_ABLATE < 2) { o.r = gamma_sample_plain(s_gam, o.r); o.g = gamma_sample_plain(s_gam, o.g); o.b = gamma_sample_plain(s_gam, o.b); }
+  if (!a.linear) { o.r = gamma_sample_plain(s_gam, o.r); o.g = gamma_sample_plain(s_gam, o.g); o.b = gamma_sample_plain(s_gam, o.b); }
   return o;
 }
 
@@ -2098,50 +1823,30 @@ template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 store
     f4u *g = reinterpret_cast<f4u *>(reinterpret_cast<float *>(dst) + pix * 3);          // element-aligned 16-byte stores
     const float4 *s = reinterpret_cast<const float4 *>(stg);
     const float4 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
-#if IPK_OPT_NTOUT
     // the result is written once and not read again by this launch: nontemporal stores keep it from displacing the mosaic rows in the caches
     // (element-aligned 16-byte stores, as below)
     typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
     f4a *gn = reinterpret_cast<f4a *>(reinterpret_cast<float *>(dst) + pix * 3);
     f4a v0, v1, v2;
     v0.x = q0.x; v0.y = q0.y; v0.z = q0.z; v0.w = q0.w; v1.x = q1.x; v1.y = q1.y; v1.z = q1.z; v1.w = q1.w; v2.x = q2.x; v2.y = q2.y; v2.z = q2.z; v2.w = q2.w;
-#if IPK_ABL_STORE == 1
-    if (q0.x == 123.456f && q1.y == 654.321f && q2.z == 1.5f)
-#endif
     { __builtin_nontemporal_store(v0, gn + lane); __builtin_nontemporal_store(v1, gn + 64 + lane); __builtin_nontemporal_store(v2, gn + 128 + lane); }
     (void)g;
-#else
-    g[lane] = f4u{q0.x, q0.y, q0.z, q0.w}; g[64 + lane] = f4u{q1.x, q1.y, q1.z, q1.w}; g[128 + lane] = f4u{q2.x, q2.y, q2.z, q2.w};
-#endif
   }
 };
 template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
   static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
     uint32_t *p = stg + 3 * lane;
-#ifdef IPK_Q8_LITERAL
-    uint32_t q[12];
-    #pragma unroll
-    for (int j = 0; j < 4; ++j) { q[3 * j] = output8bit(o[j].r); q[3 * j + 1] = output8bit(o[j].g); q[3 * j + 2] = output8bit(o[j].b); }
-    p[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-    p[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-    p[2] = q[8] | (q[9] << 8) | (q[10] << 16) | (q[11] << 24);
-#else
     p[0] = output8bit_x4(o[0].r, o[0].g, o[0].b, o[1].r);
     p[1] = output8bit_x4(o[1].g, o[1].b, o[2].r, o[2].g);
     p[2] = output8bit_x4(o[2].b, o[3].r, o[3].g, o[3].b);
-#endif
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
     u32u *g = reinterpret_cast<u32u *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);        // byte-aligned dword stores
     const uint32_t q0 = stg[lane], q1 = stg[64 + lane], q2 = stg[128 + lane];
-#if IPK_OPT_NTOUT
     typedef uint32_t u32a __attribute__((aligned(1)));
     u32a *gn = reinterpret_cast<u32a *>(reinterpret_cast<uint8_t *>(dst) + pix * 3);
     __builtin_nontemporal_store(q0, gn + lane); __builtin_nontemporal_store(q1, gn + 64 + lane); __builtin_nontemporal_store(q2, gn + 128 + lane);
     (void)g;
-#else
-    g[lane].v = q0; g[64 + lane].v = q1; g[128 + lane].v = q2;
-#endif
   }
 };
 template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
@@ -2158,15 +1863,11 @@ template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
     u64u *g = reinterpret_cast<u64u *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);      // 2-byte-aligned 8-byte stores
     const uint2 *s = reinterpret_cast<const uint2 *>(stg);
     const uint2 q0 = s[lane], q1 = s[64 + lane], q2 = s[128 + lane];
-#if IPK_OPT_NTOUT
     typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(2)));
     u2a *gn = reinterpret_cast<u2a *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);
     u2a v0, v1, v2; v0.x = q0.x; v0.y = q0.y; v1.x = q1.x; v1.y = q1.y; v2.x = q2.x; v2.y = q2.y;
     __builtin_nontemporal_store(v0, gn + lane); __builtin_nontemporal_store(v1, gn + 64 + lane); __builtin_nontemporal_store(v2, gn + 128 + lane);
     (void)g;
-#else
-    g[lane] = u64u{q0.x, q0.y}; g[64 + lane] = u64u{q1.x, q1.y}; g[128 + lane] = u64u{q2.x, q2.y};
-#endif
   }
 };
 
@@ -2219,7 +1920,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // 4 (2) bytes in and 12 out per pixel on the fused kernel's own access pattern: the ceiling its time is compared with (bench.py roofline.ceiling_ms).
   constexpr bool SKEL = OUT == 4;
   constexpr int OUTS = SKEL ? 0 : OUT;                   // the output layout (OutStage / OutStore) the variant writes
-  constexpr bool ZA = DEMO || !IPK_OPT_NOZEROADD;        // literal `0.0 + tap` sums where the demosaic result itself is the output
+  constexpr bool ZA = DEMO;                                    // literal `0.0 + tap` sums where the demosaic result itself is the output
   constexpr bool GUARD_NORM = sizeof(SrcT) == 4 && !DEMO;
   // LDS: Lab table as {v,dv} pairs (64 KB), gamma table plain (32 KB; pairs when the output is 8/16-bit), curve knots, and one staging
   // buffer per wave (3 KB for f32) that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
@@ -2239,6 +1940,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
+  // the grid form of a curve with four or more knots (the common-parameter variants are compiled for three)
+  __shared__ __attribute__((aligned(16))) float s_grid[(CMN || DEMO || SKEL) ? 4 : kGridFloats];
+  if (!(CMN || DEMO || SKEL) && a.spline.grid_ok) fill_grid(s_grid, a.spline, (int)threadIdx.x);
   // what the block's waves are working on, for takeovers once the queue is dry (IPK_OPT_STEAL): per wave slot one 64-bit descriptor -- low word: the
   // row its task ends in front of; high word: serial << 22 | frame << 16 | strip -- and the row it is at
   __shared__ unsigned long long s_tdesc[16];
@@ -2283,23 +1987,12 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // waves that remain in the tail simply run faster, so the tail wastes about 5 %, and twice the tasks cost that much in draws and priming.
   // Units of 4 rows numbered strip after strip (chunks of vertically adjacent units) were worse still: a block's sixteen waves then read sixteen 1 KB
   // pieces 1.4 MB apart instead of 16 KB of one row, rows ran 6-10 % slower.  Kept from all of it: the self-resetting queue.)
-#ifdef IPK_DEV_PROBE
-  unsigned long long pb_t0 = __builtin_readcyclecounter(), pb_draw = 0, pb_tasks = 0, pb_atomics = 0, pb_rows = 0, pb_prime = 0, pb_vm = 0, pb_st = 0;
-  const unsigned long long pb_w0 = wall_clock64();
-#endif
   auto draw = [&]() -> uint32_t {
     uint32_t t = 0xFFFFFFFFu;
-#ifdef IPK_DEV_PROBE
-    const unsigned long long d0 = __builtin_readcyclecounter();
-    pb_atomics += 1;
-#endif
     if ((threadIdx.x & 63u) == 0) {
       t = n_waves + atomicAdd(a.task_ctr, 1u);
     }
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-#ifdef IPK_DEV_PROBE
-    pb_draw += __builtin_readcyclecounter() - d0;
-#endif
     return t;
   };
   const bool queued = a.task_ctr != nullptr && n_tasks > n_waves;
@@ -2311,10 +2004,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // descriptor the taker looked at (same task, same end), so two takers cannot both get the same rows, and a descriptor that has moved on is simply looked
   // at again.  An owner that was already past the new end when it moved computes those rows too: the same values written twice.  Costs a wave two LDS
   // operations per row; nothing is drawn, staged or primed that was not before, except the priming of the taken-over half.
-  constexpr bool STEAL = IPK_OPT_STEAL && !IPK_OPT_UNROLL3;
   const uint32_t wslot = threadIdx.x >> 6, nwb = blockDim.x >> 6;
   // (the descriptor holds 16 bits of strip and 6 of frame: wider launches simply run without takeovers)
-  const bool steal_on = STEAL && (queued || IPK_STEAL_STATIC) && a.n_strips <= 0xFFFFu && (!BATCH || a.n_frames <= 64u);
+  const bool steal_on = a.n_strips <= 0xFFFFu && (!BATCH || a.n_frames <= 64u);
   uint32_t tserial = 0;
   auto take_over = [&](uint32_t &frame, uint32_t &strip, uint32_t &r0, uint32_t &r1) -> bool {
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -2327,7 +2019,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       const uint32_t rem = e > c + 1u ? e - c - 1u : 0u;   // rows behind the one the owner is at
       uint32_t best = 0u, bl = 0u;
       for (uint32_t i = 0; i < 16u; ++i) { const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)rem, (int)i); if (x > best) { best = x; bl = i; } }
-      if (best < (uint32_t)IPK_STEAL_MIN) return false;
+      if (best < kStealMin) return false;
       const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, (int)bl), dhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d >> 32), (int)bl);
       const uint32_t mid = dlo - best / 2u;
       const unsigned long long dv = ((unsigned long long)dhi << 32) | dlo, nv = ((unsigned long long)dhi << 32) | mid;
@@ -2339,17 +2031,13 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   };
   // (everything that decides the control flow here is made wave-uniform FOR THE COMPILER -- readfirstlane -- or the row counter, the row parity and the
   // addresses of the task loop below end up in vector registers behind exec-mask loops: the first form of the takeovers cost 6.6 M integer instructions)
-#if IPK_OPT_SPREAD
   // Static schedule (IPK_OPT_SPREAD = G): a block's sixteen waves start on 16 / G groups of G neighbouring tasks, the groups a whole round of blocks
   // apart, so that every block's share is a sample of the whole frame -- takeovers only even out what is inside a block -- while neighbouring strips
   // still share a block (their halo columns, the rows they read at the same time).  24 MP photo-like frame (saturated patches): G = 16 (none) / 8 / 4 / 2 / 1
   // 0.102 / 0.099 / 0.093 / 0.095 / 0.098 ms, noise 0.1215 / 0.1185 / 0.1221 / 0.1193 / 0.1225; 48 MP photo-like 0.193 / 0.192 / 0.184 / 0.187 / 0.189
   // (G = 1 on noise: 0.231 -> 0.247: every strip's neighbours on other XCDs).  G = 4.
   const uint32_t gt0 = queued ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)
-                              : (((threadIdx.x >> 6) / IPK_OPT_SPREAD) * gridDim.x + blockIdx.x) * IPK_OPT_SPREAD + ((threadIdx.x >> 6) % IPK_OPT_SPREAD);
-#else
-  const uint32_t gt0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-#endif
+                              : (((threadIdx.x >> 6) / kSpread) * gridDim.x + blockIdx.x) * kSpread + ((threadIdx.x >> 6) % kSpread);
   // Without a queue (a.task_ctr == null, or nothing to draw) a wave walks the tasks gt0, gt0 + n_waves, ...: with at most one task per wave that is the
   // single task of old, and a launch that holds more tasks than waves (no queue slot for the stream and a 64-frame batch, a GPU with fewer CUs, a frame
   // wider than 16K strips) still runs every one of them.
@@ -2412,10 +2100,6 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       __hip_atomic_store(&s_tcur[wslot], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store(&s_tdesc[wslot], ((unsigned long long)(((++tserial & 0x3FFu) << 22) | (frame << 16) | strip) << 32) | r1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#ifdef IPK_DEV_PROBE
-    pb_tasks += 1;
-    const unsigned long long pb_p0 = __builtin_readcyclecounter();
-#endif
 
     // halo columns of the strip: lane 0 fetches column 4*lc0-1, the last lane column 4*(lc0+nl); every other lane
     // (and a halo that would fall outside the frame) re-reads its own first sample so the load needs no predicate
@@ -2506,54 +2190,32 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     const uint32_t Hm1 = a.H - 1, Wm1 = a.W - 1;
     const bool col_edge = lane_on && (col0 == 0 || col0 + 3 >= Wm1);
 
-    const RawRowT zero_raw = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     RowWin P = {0, 0, 0, 0, 0, 0}, C, N = {0, 0, 0, 0, 0, 0};
     bool fP = false, fC = false, fN = false;
     // A chunk starts with the loads of its first four rows in flight together and awaits them in turn: one memory round trip instead of three
     // (4.7 us per chunk, tools/wave_timeline.py).  The row above the frame's first row does not exist: row 0 is loaded in its place, for a
     // window every pixel of which takes the edge path.
-#if IPK_OPT_PRIME4
     RawRowT raw_next;
     {
-#if IPK_OPT_LOADFIRST
-      // row r0+2 FIRST: the wait for the youngest of the four (row r0+1) then leaves nothing of this task's priming in flight at the loop's entry, and
-      // the loop's own wait can be a count that excludes the stores (see row_step)
-      raw_next = issue_row(min(r0 + 2, Hm1));
-      const RawRowT rp = issue_row(r0 > 0 ? r0 - 1 : 0u), rc = issue_row(r0), rn = issue_row(min(r0 + 1, Hm1));
-#else
       const RawRowT rp = issue_row(r0 > 0 ? r0 - 1 : 0u), rc = issue_row(r0), rn = issue_row(min(r0 + 1, Hm1));
       raw_next = issue_row(min(r0 + 2, Hm1));
-#endif
       P = finish_row(rp, fP); C = finish_row(rc, fC); N = finish_row(rn, fN);
     }
-#else
-    if (r0 > 0) P = finish_row(issue_row(r0 - 1), fP);
-    C = finish_row(issue_row(r0), fC);
-#endif
     uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
     // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
     // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
-    (void)zero_raw;
     // Software pipeline: while row r is computed its window (P, C, N = rows r-1, r, r+1) is already in registers; row r+2
     // is *finished* (the wait for its loads) after the arithmetic of row r and BEFORE that row's stores are issued, and row
     // r+3 is *issued* after them.  gfx9 counts loads and stores in one vmcnt and the compiler must assume they complete
     // out of order, so a wait for loads with younger stores in flight becomes vmcnt(0) and exposes the full store latency
     // every iteration (it was 24 % of the wave's time); here the only stores older than the awaited loads are a whole
     // iteration old.
-#if !IPK_OPT_PRIME4
-    N = finish_row(issue_row(min(r0 + 1, Hm1)), fN);
-    RawRowT raw_next = issue_row(min(r0 + 2, Hm1));
-#endif
-#ifdef IPK_DEV_PROBE
-    pb_prime += __builtin_readcyclecounter() - pb_p0;
-#endif
     // (the ~20 register moves that rotate the row window per iteration would vanish in a 3x unrolled loop; the compiler refuses
     // `#pragma unroll 3` here -- wave-level ballots and barriers in the body -- and a hand-unrolled body triples the code for ~1 %)
     // One row: demosaic + point-wise stages + store of row r from the window (P, C, N) = rows r-1, r, r+1; then row r+2 is finished INTO P's
     // registers (P is dead by then) and row r+3 issued.  The caller passes the three windows in rotating roles -- (P, C, N), (C, N, P), (N, P, C) --
     // so the window never moves between registers (IPK_OPT_UNROLL3; the rolling form copies 18 registers per row).
     auto row_step = [&](RowWin &P, RowWin &C, RowWin &N, bool &fP, bool &fC, bool &fN, const uint32_t r) {
-#if IPK_OPT_FAIRPRIO
       // The four waves of a SIMD are served oldest first: left alone, the same 23 rows take one wave 83 us and another 164 (24 MP frame, one task per
       // wave, tools/wave_timeline.py) and the launch ends on a quarter of its waves.  Where nothing is drawn from a queue a wave's issue priority
       // therefore falls as it advances through its task, row by row in a cycle of four: whichever of a SIMD's waves is a row behind outranks the
@@ -2566,17 +2228,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         case 2: __builtin_amdgcn_s_setprio(1); break;
         default: __builtin_amdgcn_s_setprio(0); break;
       }
-#endif
       const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
-#if IPK_OPT_LDSORDER
-      // the white-balance multipliers and the camera matrix come from the block's LDS copy (kept out of the scarce scalar registers): asked for
-      // here, in front of the demosaic's arithmetic, instead of where they are first used (a full LDS round trip in front of every row's first multiply)
-      float pv[16];
-      if (!DEMO) {
-        #pragma unroll
-        for (int i = 0; i < 15; ++i) pv[i] = s_par[i];
-      }
-#endif
       const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
       const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
       const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
@@ -2669,22 +2321,12 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         return;
       }
       PixOut o[4];
-#if IPK_ABLATE >= 5
-      for (int j = 0; j < 4; ++j) px[j] = make_float4(cw[j + 1], pw[j + 1], nw[j + 1], 0.0f);
-#endif
-#if IPK_ABLATE >= 4
-      for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
-#else
       if (SKEL) {
         #pragma unroll
         for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
       } else {
       bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
-#if IPK_OPT_LDSORDER
-      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN, pv);
-#else
-      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN);
-#endif
+      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN, nullptr, (CMN || DEMO || SKEL) ? nullptr : s_grid);
       if (IPK_RARE(__builtin_amdgcn_ballot_w64(bad) != 0)) {          // rare: an input outside the fast form's proven zone
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2693,34 +2335,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         }
       }
       }
-#endif
       bool fNN;
-#ifdef IPK_DEV_PROBE
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long pb_v0 = __builtin_readcyclecounter();
-      __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);   // vmcnt(0) alone (expcnt, lgkmcnt left at their maxima)
-      const unsigned long long pb_v1 = __builtin_readcyclecounter();
-      pb_vm += pb_v1 - pb_v0;
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       const RowWin NN = finish_row(raw_next, fNN);         // row r+2: the wait for its loads sits before this row's stores
       __builtin_amdgcn_sched_barrier(0);
-#ifdef IPK_DEV_PROBE
-      const unsigned long long pb_s0 = __builtin_readcyclecounter();
-#endif
-#if IPK_OPT_LOADFIRST && !IPK_ABL_LOAD
-      raw_next = issue_row(min(r + 3, Hm1));
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-#if IPK_ABLATE == 6      // timing only: same bytes, lane-contiguous 16-byte stores (wrong pixel order)
-      if (OUT == 0 && FULL) {
-        float *rowp = reinterpret_cast<float *>(frame_dst) + ((size_t)(r - a.out_r0) * a.W + pc0) * 3;
-        f4u q0{o[0].r, o[0].g, o[0].b, o[1].r}, q1{o[1].g, o[1].b, o[2].r, o[2].g}, q2{o[2].b, o[3].r, o[3].g, o[3].b};
-        reinterpret_cast<f4u *>(rowp)[lane] = q0; reinterpret_cast<f4u *>(rowp)[64 + lane] = q1; reinterpret_cast<f4u *>(rowp)[128 + lane] = q2;
-      }
-#elif IPK_ABLATE == 7 || IPK_ABL_STORE == 2   // timing only: no stores
-      if (o[0].r == 123.456f && o[0].g == 3.25f && o[2].g == 7.5f) reinterpret_cast<float *>(frame_dst)[lane] = o[1].g + o[2].b + o[3].r + o[0].b + o[1].r + o[1].b + o[2].r + o[3].g + o[3].b;
-#else
       if (FULL) {
         // Lane-blocked -> lane-interleaved through the wave's LDS staging buffer, then three stores per lane whose
         // addresses are contiguous across the wave (whole cache lines per instruction; a 48-byte lane stride would
@@ -2731,38 +2348,16 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
         OutStage<OUTS>::stage(stg, lane, o);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if IPK_ABL_STORE == 3   // timing only: every wave overwrites its own 3 KB of the frame's first 12 MB (the stores are issued, HBM sees next to nothing of them)
-        OutStage<OUTS>::flush(stg, lane, frame_dst, (size_t)(blockIdx.x * 16u + (threadIdx.x >> 6)) * 256u);
-#else
         OutStage<OUTS>::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
-#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       } else {
         if (lane_on) OutStore<OUTS>::store(frame_dst, (size_t)(r - a.out_r0) * a.W + col0, nvalid, o, store_aligned);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
-#ifdef IPK_DEV_PROBE
-      pb_st += __builtin_readcyclecounter() - pb_s0;
-#endif
-#if IPK_OPT_LOADFIRST && !IPK_ABL_LOAD
-#elif !IPK_ABL_LOAD
       raw_next = issue_row(min(r + 3, Hm1));
-#else
-      asm volatile("" : "+v"(raw_next.v0), "+v"(raw_next.v1), "+v"(raw_next.v2), "+v"(raw_next.v3), "+v"(raw_next.h));   // opaque: nothing of finish_row is hoisted
-#endif
       P = NN; fP = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
     };
-#if IPK_OPT_UNROLL3
-    if (!GEN && !ROT && CMN) {                             // the headline variants only: three copies of the row body
-      for (uint32_t r = r0;;) {
-        row_step(P, C, N, fP, fC, fN, r); if (++r >= r1) break;
-        row_step(C, N, P, fC, fN, fP, r); if (++r >= r1) break;
-        row_step(N, P, C, fN, fP, fC, r); if (++r >= r1) break;
-      }
-    } else
-#endif
     for (uint32_t r = r0, r1d = r1; r < r1d; ++r) {
       uint32_t e_now = r1;
       if (steal_on) {                                       // where this wave is, and where its task ends by now (asked for here, looked at behind the row)
@@ -2770,9 +2365,6 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         e_now = (uint32_t)__hip_atomic_load(reinterpret_cast<uint32_t *>(&s_tdesc[wslot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       row_step(P, C, N, fP, fC, fN, r);
-#ifdef IPK_DEV_PROBE
-      pb_rows += 1;
-#endif
       { const RowWin t = P; P = C; C = N; N = t; const bool ft = fP; fP = fC; fC = fN; fN = ft; }   // back to rolling order
       if (steal_on) r1d = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_now);
     }
@@ -2785,18 +2377,6 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-#ifdef IPK_DEV_PROBE
-  if ((threadIdx.x & 63u) == 0) {
-    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (w < 4096u) {
-      unsigned long long *q = g_probe + 8 * w;
-      q[0] = pb_t0; q[1] = __builtin_readcyclecounter(); q[2] = pb_draw | (pb_atomics << 48); q[3] = pb_tasks; q[4] = pb_prime; q[5] = pb_rows;
-      q[6] = pb_w0; q[7] = wall_clock64();
-      unsigned long long *q2 = g_probe2 + 4 * w;
-      q2[0] = pb_vm; q2[1] = pb_st; q2[2] = 0; q2[3] = 0;
-    }
-  }
-#endif
 }
 template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
 __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer_body<SrcT, VEC, OUT, FULL, GEN, PXG, CMN, ROT, false>(a, nullptr); }
@@ -2837,11 +2417,7 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
 
 template <typename SrcT, bool VEC, int OUT>
 static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
-#ifdef IPK_DEV_KNOBS
-  const unsigned tpb = getenv("IPK_DEV_TPB") ? atoi(getenv("IPK_DEV_TPB")) : 1024;
-#else
   const unsigned tpb = 1024;
-#endif
   const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && spline3_arith_ok(a.spline) && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
                       std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
   if (a.ori != 0) {                                      // rotated space: the common parameter set only (launch_fused_bayer checked)
@@ -2966,13 +2542,7 @@ void release_task_counters() {
 //   wave would be thousands of rows of one frame (64 x 24 MP: 7.31 ms drawn, 8.81 static).
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
   const uint32_t waves_per_block = 16;
-#ifdef IPK_DEV_KNOBS
-  static const uint32_t uni = getenv("IPK_DEV_TASK_ROWS") ? (uint32_t)atoi(getenv("IPK_DEV_TASK_ROWS")) : 32u;
-  static const uint32_t share_min_env = getenv("IPK_DEV_SHARE_MIN") ? (uint32_t)atoi(getenv("IPK_DEV_SHARE_MIN")) : 0u;
-  const uint32_t share_min = share_min_env ? share_min_env : (frames == 1 ? 128u : 64u);
-#else
   const uint32_t uni = 32u, share_min = frames == 1 ? 128u : 64u;
-#endif
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;
   const uint32_t w4 = (a.W + 3) / 4;
@@ -2983,7 +2553,7 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_
   if (share >= share_min && a.task_ctr != nullptr) a.n_segs = std::max(1u, nrows / uni);
   else {
     // one task per wave, at least IPK_MIN_TASK_ROWS rows each
-    const uint32_t min_rows = IPK_MIN_TASK_ROWS;
+    const uint32_t min_rows = kMinTaskRows;
     a.n_segs = std::min(nrows, std::min(std::max(1u, (uint32_t)(total_waves / ((uint64_t)a.n_strips * frames))), std::max(1u, nrows / min_rows)));
   }
   const uint64_t tasks = (uint64_t)a.n_strips * a.n_segs * frames;
@@ -2991,7 +2561,7 @@ static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_
   // SIMDs four deep (a 3 MP preview: 1620 tasks on 102 of 256 CUs, 0.045 ms); the spread static round (IPK_OPT_SPREAD) deals groups of four tasks to as
   // many blocks as there are groups, so such a launch now fills all CUs with one or two groups each, and waves without a task take over halves.
   const bool drawn = share >= share_min && a.task_ctr != nullptr;
-  const uint64_t per_block = (IPK_OPT_SPREAD && !drawn) ? (uint64_t)IPK_OPT_SPREAD : waves_per_block;
+  const uint64_t per_block = !drawn ? (uint64_t)kSpread : waves_per_block;
   blocks = (unsigned)std::min<uint64_t>(grid, (tasks + per_block - 1) / per_block);
 }
 
@@ -3007,7 +2577,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.tolab = make_tolab(f.mul4, f.cm12);
   for (int i = 0; i < 9; ++i) a.rgbm.m[i] = f.rgbm9[i];
   a.has_curve = f.has_curve; a.linear = f.linear;
-  if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
+  if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; a.spline.grid_ok = 0; }
   if (f.has_curve && a.spline.npoints == 2) {             // 2 knots padded to (x0, x1, x1): same decisions through the 3-knot form (ipk_device.hpp)
     a.spline.npoints = 3; a.spline.nseg = 2;
     a.spline.px[2] = a.spline.px[1]; a.spline.py[2] = a.spline.py[1];
@@ -3105,6 +2675,8 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
+  __shared__ __attribute__((aligned(16))) float s_grid[TOLAB_ONLY ? 4 : kGridFloats];
+  if (!TOLAB_ONLY && a.spline.grid_ok) fill_grid(s_grid, a.spline, (int)threadIdx.x);
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -3127,7 +2699,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
     bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
     if (a.fast_ok) {
-      bad |= pointwise4_fast<true, TOLAB_ONLY>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0);
+      bad |= pointwise4_fast<true, TOLAB_ONLY>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, false, nullptr, TOLAB_ONLY ? nullptr : s_grid);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
@@ -3202,6 +2774,8 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
+  __shared__ __attribute__((aligned(16))) float s_grid[kGridFloats];
+  if (a.spline.grid_ok) fill_grid(s_grid, a.spline, (int)threadIdx.x);
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -3229,7 +2803,7 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
     }
     PixOut o[4];
     bool bad = a.fast_ok == 0;
-    if (a.fast_ok) bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0);
+    if (a.fast_ok) bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, false, nullptr, s_grid);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -3334,14 +2908,18 @@ void launch_copy_probe(const void *src, void *dst, size_t bytes, int, hipStream_
 // every f32 argument through the arithmetic 3-knot form against the literal search (curves.rs:126-157)
 __global__ void k_selftest_spline3(SplineDev sp, SelftestOut *out) {
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
+  __shared__ __attribute__((aligned(16))) float s_grid[kGridFloats];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, sp, (int)threadIdx.x);
+  if (sp.grid_ok) fill_grid(s_grid, sp, (int)threadIdx.x);
   __syncthreads();
   unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
   const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const float v = __uint_as_float((unsigned)i);
-    const float want = spline_interpolate_lds(s_knots, sp.npoints, sp.nseg, v), got = spline_interpolate_3a(sp, s_knots, v);
-    const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);
+    const float want = spline_interpolate_lds(s_knots, sp.npoints, sp.nseg, v), got = sp.grid_ok ? spline_interpolate_grid(sp, s_grid, v) : spline_interpolate_3a(sp, s_knots, v);
+    // (the grid form answers a NaN argument with y_0, the literal search with its first probe's knot: no NaN reaches the curve in a lane whose result is
+    //  used -- see spline_interpolate_grid -- so NaN arguments are left out of this comparison for grid curves)
+    const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got) || (sp.grid_ok && v != v);
     if (!same) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
   }
   if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
@@ -3383,7 +2961,7 @@ int launch_selftest_spline3(const SplineHost &h, void *out_dev, hipStream_t s) {
     d.npoints = 3; d.nseg = 2; d.px[2] = d.px[1]; d.py[2] = d.py[1];
     d.c1[1] = d.c1[0]; d.c2[1] = d.c2[0]; d.c3[1] = d.c3[0]; d.c1[2] = d.c1[1];
   }
-  if (d.npoints != 3 || !spline3_arith_ok(d)) return -2;
+  if (!d.grid_ok && (d.npoints != 3 || !spline3_arith_ok(d))) return -2;
   hipLaunchKernelGGL(k_selftest_spline3, dim3(256 * 8), dim3(256), 0, s, d, reinterpret_cast<SelftestOut *>(out_dev));
   return 0;
 }
