@@ -28,11 +28,12 @@ class FusedParams(C.Structure):
         ("src_type", C.c_int), ("owidth", _sz),
         ("x", _sz), ("y", _sz), ("width", _sz), ("height", _sz),
         ("black0", C.c_float), ("white0", C.c_float),
-        ("cfa", C.c_char * 160), ("cfa_width", C.c_int), ("cfa_height", C.c_int),
+        ("cfa", C.c_char * 160),
         ("wb_coeffs", C.c_float * 4), ("cam_to_xyz_normalized", C.c_float * 12),
         ("exposure", C.c_float), ("npoints", C.c_int), ("points", C.c_float * 128),
         ("linear", C.c_int), ("out_type", C.c_int),
         ("band_src_row0", _sz), ("band_src_rows", _sz), ("band_out_row0", _sz), ("band_out_rows", _sz),
+        ("cfa_width", C.c_int), ("cfa_height", C.c_int),           # later additions are appended, never inserted
     ]
 
 
@@ -40,7 +41,7 @@ class PipelineDesc(C.Structure):
     """ipk_pipeline_desc"""
     _fields_ = [
         ("src_type", C.c_int), ("width", _sz), ("height", _sz),
-        ("cpp", C.c_int), ("is_cfa", C.c_int), ("cfa", C.c_char * 160), ("cfa_width", C.c_int), ("cfa_height", C.c_int),
+        ("cpp", C.c_int), ("is_cfa", C.c_int), ("cfa", C.c_char * 160),
         ("crop_top", _sz), ("crop_right", _sz), ("crop_bottom", _sz), ("crop_left", _sz),
         ("blacklevels", C.c_float * 4), ("whitelevels", C.c_float * 4),
         ("rotatecrop", C.c_float * 5),
@@ -49,6 +50,7 @@ class PipelineDesc(C.Structure):
         ("rotation", C.c_int), ("fliph", C.c_int), ("flipv", C.c_int),
         ("maxwidth", _sz), ("maxheight", _sz),
         ("linear", C.c_int), ("allow_fused", C.c_int), ("use_fastpath", C.c_int),
+        ("cfa_width", C.c_int), ("cfa_height", C.c_int),
     ]
 
 
@@ -151,6 +153,7 @@ SIGNATURES = {
     "ipk_selftest_cdiv": (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_lut_weight": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_clamp01": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "ipk_abi_sizeof": (_sz, [C.c_int]),
     "ipk_copy_probe": (C.c_int, [_vp, _vp, _sz, _vp]),
     "ipk_stream_probe": (C.c_int, [C.POINTER(FusedParams), _vp, _vp, _vp]),
     "ipk_selftest_spline3": (C.c_int, [C.c_float, _fp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -88,29 +89,33 @@ int cfa_fail(const char *pat) {
     return fail(IPK_ERR_UNSUPPORTED, "16-letter CFA pattern \"%s\": state the tile's shape (\"8x2:...\" / \"2x8:...\", or cfa_width / cfa_height); it is not guessed", pat);
   return fail(IPK_ERR_INVALID, "invalid CFA pattern \"%s\"", pat ? pat : "(null)");
 }
-// A descriptor's pattern with the shape its cfa_width / cfa_height fields state folded into the string (the notation every other entry point
-// takes); the fields are zeroed.  False: the fields contradict a prefix already in the string, or do not fit the buffer.
+// A descriptor's pattern in its CANONICAL spelling, with the shape its cfa_width / cfa_height fields state folded in (the fields are zeroed): plain
+// letters when the tile's shape is the one the letter count implies (4 -> 2x2, 36 -> 6x6, 144 -> 12x12), "WxH:letters" otherwise.  A caller that
+// fills the fields from its CFA object, one that writes a redundant "2x2:" prefix and one that passes the plain pattern therefore reach the same
+// device tables and -- through hash_chain -- the same ipk_pipeline_hashes / cache keys, which stay the hash of the reference's plain pattern string
+// (src/ops/demosaic.rs:13).  False: the fields contradict a prefix already in the string, or the result does not fit the buffer.
 #define IPK_FOLD_CFA(T, d) \
   T d##_folded; \
-  if ((d) && ((d)->cfa_width != 0 || (d)->cfa_height != 0)) { \
+  if (d) { \
     d##_folded = *(d); \
     if (!fold_cfa_shape(d##_folded)) return fail(IPK_ERR_INVALID, "cfa_width / cfa_height do not fit the pattern string"); \
     (d) = &d##_folded; \
   }
 template <typename Desc>
 static bool fold_cfa_shape(Desc &d) {
-  if (d.cfa_width == 0 && d.cfa_height == 0) return true;
-  if (d.cfa_width < 1 || d.cfa_height < 1 || d.cfa_width > 48 || d.cfa_height > 48) return false;
   d.cfa[sizeof(d.cfa) - 1] = 0;
+  if (d.cfa_width == 0 && d.cfa_height == 0 && !std::strchr(d.cfa, ':')) return true;      // plain letters, nothing stated: canonical already
+  if ((d.cfa_width != 0 || d.cfa_height != 0) && (d.cfa_width < 1 || d.cfa_height < 1 || d.cfa_width > 48 || d.cfa_height > 48)) return false;
   int w = 0, h = 0; const char *letters = d.cfa;
   if (!ipk::Cfa::split_dims(d.cfa, w, h, letters)) return false;
-  if (w != 0 && (w != d.cfa_width || h != d.cfa_height)) return false;
-  if (w == 0) {
-    char buf[sizeof(d.cfa) + 16];
-    const int n = std::snprintf(buf, sizeof(buf), "%dx%d:%s", d.cfa_width, d.cfa_height, letters);
-    if (n < 0 || (size_t)n >= sizeof(d.cfa)) return false;
-    std::memcpy(d.cfa, buf, (size_t)n + 1);
-  }
+  if (w != 0 && d.cfa_width != 0 && (w != d.cfa_width || h != d.cfa_height)) return false;
+  if (w == 0) { w = d.cfa_width; h = d.cfa_height; }
+  const size_t len = std::strlen(letters);
+  const bool inferred = w == h && ((w == 2 && len == 4) || (w == 6 && len == 36) || (w == 12 && len == 144));
+  char buf[sizeof(d.cfa) + 16];
+  const int n = inferred ? std::snprintf(buf, sizeof(buf), "%s", letters) : std::snprintf(buf, sizeof(buf), "%dx%d:%s", w, h, letters);
+  if (n < 0 || (size_t)n >= sizeof(d.cfa)) return false;
+  std::memcpy(d.cfa, buf, (size_t)n + 1);
   d.cfa_width = 0; d.cfa_height = 0;
   return true;
 }
@@ -389,6 +394,20 @@ void ipk_shutdown(void) {
   g.ready = false; g.device = -1; g.num_cus = 0;
 }
 int ipk_is_initialized(void) { return g.ready ? 1 : 0; }
+// the layout this library was built with, for bindings to check theirs against (no GPU needed)
+size_t ipk_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(ipk_fused_params);
+    case 1: return sizeof(ipk_pipeline_desc);
+    case 2: return sizeof(ipk_band);
+    case 3: return sizeof(ipk_stage_time);
+    case 16: return offsetof(ipk_fused_params, cfa_width);
+    case 17: return offsetof(ipk_pipeline_desc, cfa_width);
+    case 18: return offsetof(ipk_fused_params, band_src_row0);
+    case 19: return offsetof(ipk_pipeline_desc, use_fastpath);
+    default: return 0;
+  }
+}
 const char *ipk_last_error(void) { return g_err; }
 int ipk_device_cus(void) { return g.num_cus; }
 

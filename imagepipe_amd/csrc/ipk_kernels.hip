@@ -1546,8 +1546,10 @@ __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
 template <bool PXG, bool TOLAB_ONLY = false, typename LT, typename GT>
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const LT *__restrict__ s_lab,
                                                 const GT *__restrict__ s_gam, const float *__restrict__ s_knots,
-                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const bool curve3 = false,
+                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const int cm = 0,
                                                 const float *__restrict__ par_regs = nullptr, const float *__restrict__ s_grid = nullptr) {
+  // cm: 0 = the caller's flags are runtime values (generic variants, the chains); 1 / 2 = a common-parameter variant (fused_bayer_body's CM) whose curve is
+  // the 3-knot arithmetic form / the grid form
   bool bad = false;
   float v[12], f[12];
   f2 y[2];
@@ -1609,13 +1611,13 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       const bool hi = v[k] > 1.0f;
       // the cube root under the lanes' own mask: the same instructions are issued, but only the lanes above 1 -- a tenth to a third of them on
       // the noise frame -- switch the f64 data path.  The kernel is bound by the socket's power cap, so what the idle lanes do not burn comes back as clock.
-      // In the common-parameter variants (CMN -- `curve3`); the linear branch for negative ratios below is masked only where there are no per-pixel
+      // In the common-parameter variants (cm != 0); the linear branch for negative ratios below is masked only where there are no per-pixel
       // guards (PXG == false): with the guards' registers live as well BOTH masked regions spill (X-Trans full resolution 0.295 -> 0.338 ms with 36
       // bytes of scratch), the cube root's alone does not (X-Trans noise 0.305 -> 0.288 ms).
-      if (curve3) { if (__builtin_amdgcn_ballot_w64(hi) != 0) { if (hi) f[k] = lab_cbrt(v[k], true); } }
+      if (cm != 0) { if (__builtin_amdgcn_ballot_w64(hi) != 0) { if (hi) f[k] = lab_cbrt(v[k], true); } }
       else if (__builtin_amdgcn_ballot_w64(hi) != 0) { const float c = lab_cbrt(v[k], hi); f[k] = hi ? c : f[k]; }
       const bool lo = __float_as_uint(v[k]) > 0x7F800000u;            // negative (or -0), or NaN: out of the table and not above 1
-      if (!PXG && curve3) { if (__builtin_amdgcn_ballot_w64(lo) != 0) { if (lo) { const float dv = kLabK * v[k] + 16.0f; f[k] = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); } } }
+      if (!PXG && cm != 0) { if (__builtin_amdgcn_ballot_w64(lo) != 0) { if (lo) { const float dv = kLabK * v[k] + 16.0f; f[k] = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); } } }
       else if (__builtin_amdgcn_ballot_w64(lo) != 0)
       { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
     }
@@ -1637,8 +1639,8 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       Aq[g] = cdiv2s(a0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
       Bq[g] = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
       if (!TOLAB_ONLY && has_curve) {
-        if (curve3) L = F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y));
-        else if (s_grid != nullptr && a.spline.grid_ok) L = F2(spline_interpolate_grid(a.spline, s_grid, L.x), spline_interpolate_grid(a.spline, s_grid, L.y));
+        if (cm == 1) L = F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y));
+        else if (s_grid != nullptr && (cm == 2 || a.spline.grid_ok)) L = F2(spline_interpolate_grid(a.spline, s_grid, L.x), spline_interpolate_grid(a.spline, s_grid, L.y));
         else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
       }
       Lq[g] = L;
@@ -1910,8 +1912,9 @@ struct RgbeStage {
 // the frames of a batch launch: up to kBatchMax per launch, passed by value as the second kernel argument (1 KB of kernarg)
 constexpr int kBatchMax = 64;
 struct BatchPtrs { const void *src[kBatchMax]; void *dst[kBatchMax]; };
-template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG, bool CMN, bool ROT, bool BATCH>
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG, int CM, bool ROT, bool BATCH>
 __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const BatchPtrs *bp) {
+  constexpr bool CMN = CM != 0;                          // 1: common parameters with the 3-knot curve compiled in; 2: with the grid form (four or more knots)
   // f32 sources can hold denormal/huge samples: guard the normalisation's dividends.  u16 samples minus a
   // host-validated black level cannot leave the proven zone.
   constexpr bool DEMO = OUT == 3;                        // demosaic only (staged OpDemosaic)
@@ -1941,8 +1944,9 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
   // the grid form of a curve with four or more knots (the common-parameter variants are compiled for three)
-  __shared__ __attribute__((aligned(16))) float s_grid[(CMN || DEMO || SKEL) ? 4 : kGridFloats];
-  if (!(CMN || DEMO || SKEL) && a.spline.grid_ok) fill_grid(s_grid, a.spline, (int)threadIdx.x);
+  constexpr bool HAS_GRID = CM != 1 && !DEMO && !SKEL;
+  __shared__ __attribute__((aligned(16))) float s_grid[HAS_GRID ? kGridFloats : 4];
+  if (HAS_GRID && (CM == 2 || a.spline.grid_ok)) fill_grid(s_grid, a.spline, (int)threadIdx.x);
   // what the block's waves are working on, for takeovers once the queue is dry (IPK_OPT_STEAL): per wave slot one 64-bit descriptor -- low word: the
   // row its task ends in front of; high word: serial << 22 | frame << 16 | strip -- and the row it is at
   __shared__ unsigned long long s_tdesc[16];
@@ -2326,7 +2330,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         for (int j = 0; j < 4; ++j) { o[j].r = px[j].x; o[j].g = px[j].y; o[j].b = px[j].z; }
       } else {
       bool bad = !fast_ok || (!PXG && sizeof(SrcT) == 4 && (fP | fC | fN));   // f32 without per-pixel guards: a flagged row in the window
-      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CMN, nullptr, (CMN || DEMO || SKEL) ? nullptr : s_grid);
+      if (fast_ok) bad |= pointwise4_fast<PXG>(a, s_par, s_lab, s_gam, s_knots, px, o, has_curve, linear, CM, nullptr, HAS_GRID ? s_grid : nullptr);
       if (IPK_RARE(__builtin_amdgcn_ballot_w64(bad) != 0)) {          // rare: an input outside the fast form's proven zone
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2378,11 +2382,11 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     }
   }
 }
-template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, bool CMN = false, bool ROT = false>
-__global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer_body<SrcT, VEC, OUT, FULL, GEN, PXG, CMN, ROT, false>(a, nullptr); }
+template <typename SrcT, bool VEC, int OUT, bool FULL, bool GEN, bool PXG = true, int CM = 0, bool ROT = false>
+__global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer_body<SrcT, VEC, OUT, FULL, GEN, PXG, CM, ROT, false>(a, nullptr); }
 // the persistent batch form; instantiated for the common parameter set only (launch_fused_bayer_batch)
 template <typename SrcT, bool VEC, int OUT, bool PXG>
-__global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, true, false, true>(a, &bp); }
+__global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, 1, false, true>(a, &bp); }
 
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1);
 static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk);
@@ -2418,8 +2422,11 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
 template <typename SrcT, bool VEC, int OUT>
 static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
   const unsigned tpb = 1024;
-  const bool common = a.fast_ok && a.has_curve && a.spline.npoints == 3 && spline3_arith_ok(a.spline) && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
-                      std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
+  const bool common_but_curve = a.fast_ok && a.has_curve && !a.exact_norm && (a.linear != 0) == (OUT == 2) && a.W >= 256u &&
+                                std::fabs(a.min0) >= 0x1p-70f && std::fabs(a.min0) <= 0x1p70f;
+  const bool common = common_but_curve && a.spline.npoints == 3 && spline3_arith_ok(a.spline);
+  // the same parameter set with a curve of four or more knots that qualifies for the grid form (a user's edited base curve): the Bayer variants only
+  const bool common_grid = common_but_curve && a.spline.grid_ok != 0 && a.ori == 0 && !a.gen_cells;
   if (a.ori != 0) {                                      // rotated space: the common parameter set only (launch_fused_bayer checked)
     if (a.gen_cells) { hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, true, true, true, true>), dim3(grid), dim3(tpb), 0, s, a); return; }
     if (a.px_guard == 0) hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, false, true, true>), dim3(grid), dim3(tpb), 0, s, a);
@@ -2436,7 +2443,16 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
   // u16 sources with ordinary levels and parameters (the common case for real sensors): no per-pixel input guards
   if constexpr (sizeof(SrcT) == 2) if (a.px_guard == 0 && a.W >= 256u) {
     if (common) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, true>), dim3(grid), dim3(tpb), 0, s, a);
+    else if (common_grid) hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, 2>), dim3(grid), dim3(tpb), 0, s, a);
     else hipLaunchKernelGGL((k_fused_bayer<SrcT, false, OUT, true, false, false, false>), dim3(grid), dim3(tpb), 0, s, a);
+    return;
+  }
+  if (common_grid) {
+    if constexpr (sizeof(SrcT) == 4) if (a.px_guard == 0) {
+      hipLaunchKernelGGL((k_fused_bayer<SrcT, true, OUT, true, false, false, 2>), dim3(grid), dim3(tpb), 0, s, a);
+      return;
+    }
+    hipLaunchKernelGGL((k_fused_bayer<SrcT, sizeof(SrcT) == 4, OUT, true, false, true, 2>), dim3(grid), dim3(tpb), 0, s, a);
     return;
   }
   if (common) {
@@ -2699,7 +2715,7 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
     bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
     if (a.fast_ok) {
-      bad |= pointwise4_fast<true, TOLAB_ONLY>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, false, nullptr, TOLAB_ONLY ? nullptr : s_grid);
+      bad |= pointwise4_fast<true, TOLAB_ONLY>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, 0, nullptr, TOLAB_ONLY ? nullptr : s_grid);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
@@ -2803,7 +2819,7 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
     }
     PixOut o[4];
     bool bad = a.fast_ok == 0;
-    if (a.fast_ok) bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, false, nullptr, s_grid);
+    if (a.fast_ok) bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, 0, nullptr, s_grid);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -71,6 +71,10 @@ typedef enum { IPK_OUT_F32 = 0, IPK_OUT_U8 = 1, IPK_OUT_U16 = 2 } ipk_out_type;
 IPK_API int ipk_init(int device);
 IPK_API void ipk_shutdown(void);
 IPK_API int ipk_is_initialized(void);
+/* sizeof / offsetof of the descriptor structs as this library was built, so that a binding can check its own layout before the first call:
+ * which = 0 ipk_fused_params, 1 ipk_pipeline_desc, 2 ipk_band, 3 ipk_stage_time; 16 / 17 offsetof(cfa_width) in the first two (the appended
+ * fields), 18 offsetof(ipk_fused_params, band_src_row0), 19 offsetof(ipk_pipeline_desc, use_fastpath); anything else 0.  No GPU needed. */
+IPK_API size_t ipk_abi_sizeof(int which);
 /* Human-readable description of the last failure on this thread (never NULL). */
 IPK_API const char *ipk_last_error(void);
 /* 1 when this host's libm cbrtf equals the device's cube-root routine (a port of glibc 2.35's, src/color_conversions.rs:103-104,123 call
@@ -258,8 +262,6 @@ typedef struct {
   size_t x, y, width, height;      /* OpGoFloat::size_image result */
   float black0, white0;            /* blacklevels[0], whitelevels[0] (gofloat.rs:126) */
   char cfa[160];                   /* cropped CFA pattern (OpDemosaic.cfa): letters, or "WxH:letters" (see ipk_cfa_shift) */
-  int cfa_width, cfa_height;       /* the tile's shape as the caller's CFA object has it (cfa.width / cfa.height, src/ops/demosaic.rs:33); 0, 0 = take
-                                      it from the string (a "WxH:" prefix, or the letter count 4 / 36 / 144).  16 letters need one of the two. */
   float wb_coeffs[4];              /* OpToLab.wb_coeffs (normalised again inside, colorspaces.rs:100) */
   float cam_to_xyz_normalized[12]; /* OpToLab.cam_to_xyz_normalized, [[f32;4];3] row-major */
   float exposure;                  /* OpBaseCurve.exposure */
@@ -271,6 +273,10 @@ typedef struct {
    * image row band_src_row0 (in cropped coordinates, i.e. row y+band_src_row0 of the sensor), and
    * only output rows [band_out_row0, band_out_row0+band_out_rows) are produced into dst. */
   size_t band_src_row0, band_src_rows, band_out_row0, band_out_rows;
+  /* Fields added after the struct was first published are APPENDED here, never inserted (a caller built against the older layout zero-fills them by
+   * value-initialising the struct, and every earlier field keeps its offset). */
+  int cfa_width, cfa_height;       /* the tile's shape as the caller's CFA object has it (cfa.width / cfa.height, src/ops/demosaic.rs:33); 0, 0 = take
+                                      it from the string (a "WxH:" prefix, or the letter count 4 / 36 / 144).  16 letters need one of the two. */
 } ipk_fused_params;
 
 /* src: device pointer to the sensor data (element (0,0) of the uncropped frame, or of the band's
@@ -323,7 +329,6 @@ typedef struct {
   int cpp;                         /* RawImage.cpp (1 or 3); ignored for RGB8/RGB16 */
   int is_cfa;                      /* OpGoFloat.is_cfa */
   char cfa[160];                   /* OpDemosaic.cfa = cropped_cfa() ("" for Other): letters, or "WxH:letters" */
-  int cfa_width, cfa_height;       /* as in ipk_fused_params: the tile's shape from the caller's CFA object, 0, 0 = from the string */
   size_t crop_top, crop_right, crop_bottom, crop_left;   /* OpGoFloat crops */
   float blacklevels[4], whitelevels[4];
   float rotatecrop[5];             /* OpRotateCrop: crop_top, crop_right, crop_bottom, crop_left, rotation */
@@ -335,6 +340,8 @@ typedef struct {
   int linear;
   int allow_fused;                 /* 1: use ipk_raw_to_srgb when legal (cache==None); 0: always staged */
   int use_fastpath;                /* PipelineSettings.use_fastpath (pipeline.rs:117; the reference defaults it to true) */
+  /* later additions are appended (see ipk_fused_params) */
+  int cfa_width, cfa_height;       /* as in ipk_fused_params: the tile's shape from the caller's CFA object, 0, 0 = from the string */
 } ipk_pipeline_desc;
 
 /* Size negotiation of Pipeline::run (src/pipeline.rs:314-338): demosaic_{w,h} as stored in the

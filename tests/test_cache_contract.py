@@ -98,6 +98,35 @@ def test_hash_settings_feed_every_hash(L):
     assert L.ipk_pipeline_hashes(C.byref(_desc(width=5)), 0, 0, C.create_string_buffer(256)) == -2
 
 
+def test_hashes_do_not_depend_on_how_the_cfa_shape_is_spelled(L):
+    """A caller that fills cfa_width / cfa_height from its CFA object, one that writes the redundant "2x2:" prefix and one that passes the plain
+    pattern describe the same pipeline: same hash chain (= the hash of the reference's plain pattern string, src/ops/demosaic.rs:13), same cache
+    keys.  A shape the letter count does not imply stays in the string, whichever way it was stated."""
+    xt = b"GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG"
+    plain = _hashes(L, _desc())
+    assert _hashes(L, _desc(cfa_width=2, cfa_height=2)) == plain
+    assert _hashes(L, _desc(cfa=b"2x2:RGGB")) == plain
+    assert _hashes(L, _desc(cfa=b"2x2:RGGB", cfa_width=2, cfa_height=2)) == plain
+    assert _hashes(L, _desc(cfa=xt, cfa_width=6, cfa_height=6)) == _hashes(L, _desc(cfa=xt)) == _hashes(L, _desc(cfa=b"6x6:" + xt))
+    wide = b"RGGBGRBGRGGBGRBG"                                       # 16 letters: the shape must be stated, and it is part of the identity
+    a, b = _hashes(L, _desc(cfa=wide, cfa_width=8, cfa_height=2)), _hashes(L, _desc(cfa=b"8x2:" + wide))
+    assert a == b and a != _hashes(L, _desc(cfa=b"2x8:" + wide))
+    out = C.create_string_buffer(256)
+    assert L.ipk_pipeline_hashes(C.byref(_desc(cfa=b"2x2:RGGB", cfa_width=6, cfa_height=6)), 0, 0, out) == -2      # the two statements contradict each other
+
+
+def test_descriptor_layouts_match_the_library(L):
+    """the ctypes mirrors of ipk_fused_params / ipk_pipeline_desc / ipk_band / ipk_stage_time against the layout the library was compiled with
+    (ipk_abi_sizeof); fields added later sit at the END of the structs, so every earlier field keeps its offset"""
+    from imagepipe_amd import _lib
+    for which, st in ((0, _lib.FusedParams), (1, _lib.PipelineDesc), (2, _lib.Band), (3, _lib.StageTime)):
+        assert L.ipk_abi_sizeof(which) == C.sizeof(st), (which, L.ipk_abi_sizeof(which), C.sizeof(st))
+    assert L.ipk_abi_sizeof(16) == _lib.FusedParams.cfa_width.offset and L.ipk_abi_sizeof(18) == _lib.FusedParams.band_src_row0.offset
+    assert L.ipk_abi_sizeof(17) == _lib.PipelineDesc.cfa_width.offset and L.ipk_abi_sizeof(19) == _lib.PipelineDesc.use_fastpath.offset
+    assert _lib.FusedParams.cfa_width.offset > _lib.FusedParams.band_out_rows.offset                 # appended, not inserted
+    assert _lib.PipelineDesc.cfa_width.offset > _lib.PipelineDesc.use_fastpath.offset
+
+
 def test_lru_byte_budget(L):
     h = C.c_void_p()
     assert L.ipk_cache_new(1000, C.byref(h)) == 0

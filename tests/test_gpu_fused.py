@@ -1235,3 +1235,55 @@ def test_stream_probe_refuses_what_it_has_no_variant_for(ipa):
         with pytest.raises(ipa._lib.IpkError) as e:
             plan.probe(src, torch.zeros(kw["width"] * kw["height"] * 3, dtype=torch.float32, device="cuda"))
         assert e.value.code == -5, e.value.code           # IPK_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: every fused variant a caller can reach, at the BASELINE frame sizes, against the oracle (drawn tasks and takeovers in play)
+# ---------------------------------------------------------------------------------------------
+USER5 = [(0.1, 0.07), (0.3, 0.27), (0.5, 0.6), (0.7, 0.82), (0.9, 0.95)]
+VARIANTS = [                                   # (id, points, exposure, linear)
+    ("user5", USER5, 0.0, False),             # 7 knots: the grid form of the curve in the common-parameter variant (CM = 2)
+    ("nocurve", [], 0.0, False),              # OpBaseCurve returns its input (curves.rs:34-36): the generic variant, no curve
+    ("exposure_linear", [], 0.5, True),       # 2 knots scaled by exp2(exposure), no OpGamma (gamma.rs:17): generic variant, runtime flags
+    ("user5_linear", USER5, -0.4, True),      # grid curve in the generic variant
+    ("unsorted", [(0.6, 0.5), (0.4, 0.3), (0.8, 0.9)], 0.0, False),   # knots out of order: the reference's search as it is (literal form)
+]
+
+
+@pytest.mark.parametrize("vid,points,exposure,linear", VARIANTS, ids=[v[0] for v in VARIANTS])
+@pytest.mark.parametrize("is_float", [True, False], ids=["f32", "u16"])
+@pytest.mark.parametrize("H,W", [(4000, 6000), (10000, 10000)], ids=["24MP", "100MP"])
+def test_fused_variants_full_size_vs_oracle(ipa, orc, H, W, is_float, vid, points, exposure, linear):
+    """Pipeline::run at BASELINE.json's frame sizes for the parameter sets that do NOT take the headline instantiation: user curves of more knots
+    (src/ops/curves.rs:12-49), no curve, exposure, linear (src/ops/gamma.rs:16-26), f32 and u16 sources; every output sample against the oracle.
+    The 100 MP u16 cases skip the costliest combinations to keep the suite's run time bounded (the oracle needs ~10 s per 100 MP frame)."""
+    import torch
+    if H == 10000 and not is_float and vid in ("exposure_linear", "unsorted"):
+        pytest.skip("covered at 24 MP and, at 100 MP, from the f32 source")
+    raw = util.noise_u16(util.SEED + 900 + H + len(points), H, W)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "RGGB", is_float=is_float))
+    pipe.ops.basecurve.points = points; pipe.ops.basecurve.exposure = exposure
+    pipe.globals.settings.linear = linear
+    got = pipe.run()
+    assert pipe.last_used_fused
+    want = torch.from_numpy(orc.pipeline_run(_oracle_desc(orc, src, "RGGB", points=points, exposure=exposure, linear=linear)).reshape(-1))
+    if not torch.equal(got.data.cpu().view(torch.int32), want.view(torch.int32)):
+        assert_bits_equal(got.numpy(), want.numpy().reshape(H, W, 3), "variant %s %s %dx%d" % (vid, "f32" if is_float else "u16", W, H))
+
+
+@pytest.mark.parametrize("vid,points,exposure", [("user5", USER5, 0.0), ("nocurve", [], 0.0), ("exposure", [(0.5, 0.6)], 0.8)], ids=["user5", "nocurve", "exposure"])
+@pytest.mark.parametrize("is_float", [True, False], ids=["f32", "u16"])
+def test_fused_variants_quantised_outputs_24mp_vs_oracle(ipa, orc, is_float, vid, points, exposure):
+    """output_8bit / output_16bit (src/pipeline.rs:404-421, :451-468: linear forced off / on) for the same parameter sets at 24 MP, every sample"""
+    H, W = 4000, 6000
+    raw = util.noise_u16(util.SEED + 950 + len(points), H, W)
+    src = raw.astype(np.float32) if is_float else raw
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, src, "RGGB", is_float=is_float))
+    pipe.ops.basecurve.points = points; pipe.ops.basecurve.exposure = exposure
+    desc = _oracle_desc(orc, src, "RGGB", points=points, exposure=exposure)
+    w, h, o8 = pipe.output_8bit()
+    assert pipe.last_used_fused
+    assert np.array_equal(o8.cpu().numpy().reshape(h, w, 3), orc.pipeline_output_8bit(desc))
+    w, h, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(h, w, 3), orc.pipeline_output_16bit(desc))

@@ -122,6 +122,33 @@ def test_base_curve_arithmetic_form_equals_the_literal_search_on_every_f32(L, ex
     assert n.value == 0, (n.value, hex(first.value))
 
 
+USER5 = [(0.1, 0.07), (0.3, 0.27), (0.5, 0.6), (0.7, 0.82), (0.9, 0.95)]
+
+
+@pytest.mark.parametrize("exposure,points", [(0.0, USER5), (0.6, USER5), (0.0, [(0.2, 0.1), (0.4, 0.5), (0.6, 0.55), (0.8, 0.9)]),
+                                             (0.0, [(0.2, 0.9), (0.4, 0.1), (0.6, 0.95), (0.8, 0.05)]), (0.0, [(0.3, 0.2), (0.6, 0.8)]),
+                                             (0.0, [((i + 1) / 65.0, ((i + 1) / 65.0) ** 0.8) for i in range(64)]),           # 66 knots, the most the library takes
+                                             (0.0, [(0.25, 0.25), (0.2501, 0.26), (0.75, 0.8)]),                            # two knots 1e-4 apart: still one per cell
+                                             (-0.5, [(0.0, 0.1), (0.5, 0.4), (1.0, 0.9)])])                                   # user points on the ends: no auto-added knots
+def test_base_curve_grid_form_equals_the_literal_search_on_every_f32(L, exposure, points):
+    """SplineFunc::interpolate (curves.rs:126-157) against the grid form the kernels use for curves of four or more knots (ipk_device.hpp
+    spline_interpolate_grid: segment from a 256-cell grid plus one comparison, lower clamp and knot hits as arithmetic): all 2^32 arguments
+    (NaN arguments excepted, which never reach the curve of a lane whose result is used)"""
+    flat = (C.c_float * (2 * len(points)))(*[c for p in points for c in p])
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_spline3(C.c_float(exposure), flat, len(points), C.byref(n), C.byref(first)) == 0
+    assert n.value == 0, (n.value, hex(first.value))
+
+
+@pytest.mark.parametrize("points", [[(0.3, 0.2), (0.3004, 0.21), (0.3008, 0.22), (0.7, 0.8)],       # three knots inside one grid cell (1/256 wide)
+                                    [(0.6, 0.5), (0.4, 0.3), (0.8, 0.9)],                            # not sorted: the reference searches it as it is
+                                    [(0.2, 0.1), (0.4, -0.0), (0.6, 0.55), (0.8, 0.9)]])            # a knot ordinate of -0.0
+def test_base_curve_grid_form_is_refused_where_it_would_not_hold(L, points):
+    flat = (C.c_float * (2 * len(points)))(*[c for p in points for c in p])
+    n = C.c_uint64(); first = C.c_uint32()
+    assert L.ipk_selftest_spline3(C.c_float(0.0), flat, len(points), C.byref(n), C.byref(first)) == -5    # IPK_ERR_UNSUPPORTED: the literal search stays
+
+
 def test_base_curve_arithmetic_form_is_refused_for_a_negative_zero_ordinate(L):
     flat = (C.c_float * 2)(0.5, -0.0)
     n = C.c_uint64(); first = C.c_uint32()
