@@ -128,7 +128,7 @@ USER5 = [(0.1, 0.07), (0.3, 0.27), (0.5, 0.6), (0.7, 0.82), (0.9, 0.95)]
 @pytest.mark.parametrize("exposure,points", [(0.0, USER5), (0.6, USER5), (0.0, [(0.2, 0.1), (0.4, 0.5), (0.6, 0.55), (0.8, 0.9)]),
                                              (0.0, [(0.2, 0.9), (0.4, 0.1), (0.6, 0.95), (0.8, 0.05)]), (0.0, [(0.3, 0.2), (0.6, 0.8)]),
                                              (0.0, [((i + 1) / 65.0, ((i + 1) / 65.0) ** 0.8) for i in range(64)]),           # 66 knots, the most the library takes
-                                             (0.0, [(0.25, 0.25), (0.2501, 0.26), (0.75, 0.8)]),                            # two knots 1e-4 apart: still one per cell
+                                             (0.0, [(0.25, 0.25), (0.2541, 0.26), (0.75, 0.8)]),                            # two knots in neighbouring grid cells (64 and 65)
                                              (-0.5, [(0.0, 0.1), (0.5, 0.4), (1.0, 0.9)])])                                   # user points on the ends: no auto-added knots
 def test_base_curve_grid_form_equals_the_literal_search_on_every_f32(L, exposure, points):
     """SplineFunc::interpolate (curves.rs:126-157) against the grid form the kernels use for curves of four or more knots (ipk_device.hpp
