@@ -890,16 +890,20 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
   if (a.skip_x_x >= 1.0f && a.skip_x_x <= 7.0f && a.skip_y_y >= 1.0f && a.skip_y_y <= 7.0f && width >= 8 &&
       (reinterpret_cast<uintptr_t>(dst4) & 15) == 0) {
     const unsigned gx = (unsigned)((nwidth + 255) / 256);
-    const unsigned total_blocks = 5376u;                                     // 21 blocks per CU = 3 full rounds of the 7 resident ones; measured flat 3584 .. 7168
-    const unsigned want = std::max(1u, total_blocks / gx);                   // ~16 blocks of 256 threads per CU in total
-    const dim3 grid2(gx, (unsigned)std::min<size_t>(out_rows, want), 1);     // (equal row counts per block, 3 or 4 instead of 3.2 on average: measured, no gain)
+    // 21 blocks per CU = 3 full rounds of the 7 resident ones.  Round 4 sweep (50 MP X-Trans -> 2160x1440, one box, ms): 1620 / 1792 / 2688 / 3584 / 5376 /
+    // 7168 blocks 0.064 / 0.059 / 0.058 / 0.0565 / 0.0563 / 0.0565 with the plain grid, 0.064 / 0.061 / 0.060 / 0.057 / 0.059 / 0.058 with runs of two
+    // block rows per XCD; equal row counts per block (every block the same 3, 4, 6 or 8 rows) 0.064 / 0.064 / 0.061 / 0.058 / 0.057 / 0.059: fewer, longer-lived
+    // blocks lose although they run the per-block set-up less often -- the kernel is not bound by its instruction count alone.
+    const unsigned total_blocks = 5376u;
+    const unsigned want = std::max(1u, total_blocks / gx);
+    const dim3 grid2(gx, (unsigned)std::min<size_t>(out_rows, want), 1);
     const dim3 grid = grid2;
     if (pw > 0 && ph > 0 && (uint32_t)(pw * ph) <= kW8MaxCells && 48 % pw == 0 && 48 % ph == 0) {
       const size_t lds = (size_t)pw * ph * kW8CellF4 * 4 * sizeof(float);
       dim3 grid = grid2;
       a.xcd_gx = 0; a.xcd_gy = 0;
       {
-        uint32_t group = 2;     // block rows per XCD in a run (sweep below)
+        uint32_t group = 2;     // block rows per XCD in a run
         if (group > 0 && grid2.y >= 8 * group) {
           a.xcd_gx = grid2.x; a.xcd_group = group; a.xcd_gy = grid2.y / (8 * group) * (8 * group);
           grid = dim3(a.xcd_gx * a.xcd_gy, 1, 1);
@@ -968,18 +972,26 @@ __global__ __launch_bounds__(1024) void k_gamma(const float *__restrict__ src, s
   __syncthreads();
   // four samples per thread (16-byte accesses) while whole groups remain, then the tail one by one
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 ? n / 4 : 0;
-  // two groups per thread and iteration, both loads issued before the first lookup: 0.467 -> 0.458 ms at 100 MP (5.1 -> 5.2 TB/s; the random table
-  // gathers in LDS, not the loads, are what keeps it under the 6.2-6.5 TB/s the box copies at)
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + stride < n4; i += 2 * stride) {
-    const float4 v = ld_stream4(src + 4 * i), w = ld_stream4(src + 4 * (i + stride));
-    st_stream4(dst + 4 * i, make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w)));
-    st_stream4(dst + 4 * (i + stride), make_float4(gamma_sample(s_gam, w.x), gamma_sample(s_gam, w.y), gamma_sample(s_gam, w.z), gamma_sample(s_gam, w.w)));
+  // Four 16-byte groups per thread and iteration, all four loads issued before the first lookup, and the four ADJACENT: a block covers 64 KB of
+  // contiguous input per step, blocks side by side, and the launch holds sixteen blocks per CU slot so that the dispatcher keeps the chip on one
+  // compact, advancing window of the buffer (4096 blocks at 100 MP).  Measured at 100 MP on one box: round 3's form (two groups a grid width apart,
+  // 512 blocks) 0.470 ms = 5.1 TB/s; four groups a grid width apart 0.446-0.470 whatever the grid; adjacent groups 0.403 with 512 blocks, 0.383 with
+  // 4096-8192 (6.3 TB/s, what a plain copy reaches), 0.446 with 32768: the table fill of a short-lived block starts to show.  The groups are finished
+  // one after the other (scheduling barriers): with all sixteen lookups interleaved the kernel needs 68 registers, and two blocks per CU want 64.
+  auto one = [&](size_t k, const float4 &v) {
+    st_stream4(dst + 4 * k, make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w)));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const size_t bs = 4 * (size_t)blockDim.x, gs = bs * gridDim.x;
+  size_t j = (size_t)blockIdx.x * bs + threadIdx.x;
+  for (; j + 3 * blockDim.x < n4; j += gs) {
+    const float4 v0 = ld_stream4(src + 4 * j), v1 = ld_stream4(src + 4 * (j + blockDim.x)), v2 = ld_stream4(src + 4 * (j + 2 * blockDim.x)), v3 = ld_stream4(src + 4 * (j + 3 * blockDim.x));
+    __builtin_amdgcn_sched_barrier(0);
+    one(j, v0); one(j + blockDim.x, v1); one(j + 2 * blockDim.x, v2); one(j + 3 * blockDim.x, v3);
   }
-  for (; i < n4; i += stride) {
-    const float4 v = ld_stream4(src + 4 * i);
-    st_stream4(dst + 4 * i, make_float4(gamma_sample(s_gam, v.x), gamma_sample(s_gam, v.y), gamma_sample(s_gam, v.z), gamma_sample(s_gam, v.w)));
+  if (j < n4) {                                            // the block whose span holds the end of the buffer
+    #pragma unroll
+    for (int u = 0; u < 4; ++u) if (j + u * blockDim.x < n4) one(j + u * blockDim.x, ld_stream4(src + 4 * (j + u * blockDim.x)));
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = gamma_sample(s_gam, src[i]);
@@ -1078,7 +1090,8 @@ void launch_fromlab(const float *src3, size_t npix, const float *m9, float *dst3
                      reinterpret_cast<const f3 *>(src3), npix, m, reinterpret_cast<f3 *>(dst3));
 }
 void launch_gamma(const float *src, size_t n, const void *gam_pairs, float *dst, int num_cus, hipStream_t s) {
-  hipLaunchKernelGGL(k_gamma, dim3(grid_1d(n, 1024, (unsigned)num_cus * 2)), dim3(1024), 0, s, src, n,
+  // sixteen blocks per CU slot (two are resident at a time), each walking 64 KB-wide steps: see k_gamma
+  hipLaunchKernelGGL(k_gamma, dim3(grid_1d((n / 4 + 3) / 4, 1024, (unsigned)num_cus * 16)), dim3(1024), 0, s, src, n,
                      reinterpret_cast<const LutPair *>(gam_pairs), dst);
 }
 // The transposing orientations (Rotate90/270, Transpose, Transverse: |y_step| == 1, |x_step| == source pitch): consecutive
@@ -1543,23 +1556,23 @@ __device__ __forceinline__ float lab_cbrt(float v, bool hi) {
 // |black| >= range/64 makes a nonzero v - black at least |black| * 2^-25 >= range * 2^-31, and finish_row's single
 // comparison flags a row with a dividend below -2^20 * range; a row window holding a flagged row takes the literal form.
 // TOLAB_ONLY: stop behind OpToLab and hand back the Lab pixels (L, A, B in r, g, b) -- the staged ipk_tolab on the same arithmetic.
-template <bool PXG, bool TOLAB_ONLY = false, typename LT, typename GT>
+template <bool PXG, bool TOLAB_ONLY = false, int NP = 2, typename LT, typename GT>   // NP pixel pairs per lane (2: four pixels)
 __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float *__restrict__ par, const LT *__restrict__ s_lab,
                                                 const GT *__restrict__ s_gam, const float *__restrict__ s_knots,
-                                                const float4 px[4], PixOut o[4], const bool has_curve, const bool linear, const int cm = 0,
+                                                const float4 px[2 * NP], PixOut o[2 * NP], const bool has_curve, const bool linear, const int cm = 0,
                                                 const float *__restrict__ par_regs = nullptr, const float *__restrict__ s_grid = nullptr) {
   // cm: 0 = the caller's flags are runtime values (generic variants, the chains); 1 / 2 = a common-parameter variant (fused_bayer_body's CM) whose curve is
   // the 3-knot arithmetic form / the grid form
   bool bad = false;
-  float v[12], f[12];
-  f2 y[2];
+  float v[6 * NP], f[6 * NP];
+  f2 y[NP];
   // the multipliers and the camera matrix as SCALAR operands straight from the kernel arguments (s_load through the constant cache, re-read where the
   // scalar registers are short) instead of sixteen broadcast reads of the LDS copy per row into vector registers
   const float spar[16] = {a.tolab.mul[0], a.tolab.mul[1], a.tolab.mul[2], a.tolab.mul[3], a.tolab.cm[0], a.tolab.cm[1], a.tolab.cm[2], a.tolab.cm[3], a.tolab.cm[4],
                           a.tolab.cm[5], a.tolab.cm[6], a.tolab.cm[7], a.tolab.cm[8], a.tolab.cm[9], a.tolab.cm[10], a.tolab.cm[11]};
   const float *const par0 = spar;
   #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NP; ++g) {
     const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
     if (PXG) bad |= !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
     const f2 r = min2(F2(pa.x, pb.x) * S2(par0[0]), 1.0f);
@@ -1574,13 +1587,13 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     v[6 * g] = xr.x; v[6 * g + 1] = xr.y; v[6 * g + 2] = y[g].x; v[6 * g + 3] = y[g].y; v[6 * g + 4] = zr.x; v[6 * g + 5] = zr.y;
   }
   {
-    float pos[12]; LutPair e[12];
+    float pos[6 * NP]; LutPair e[6 * NP];
     #pragma unroll
-    for (int k = 0; k < 12; ++k) pos[k] = v[k] * kLutMaxF;
+    for (int k = 0; k < 6 * NP; ++k) pos[k] = v[k] * kLutMaxF;
     #pragma unroll
-    for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k]));
+    for (int k = 0; k < 6 * NP; ++k) e[k] = lut_pair_at(s_lab, f32_as_u32_sat(pos[k]));
     #pragma unroll
-    for (int k = 0; k < 12; ++k) f[k] = e[k].x + __builtin_amdgcn_fractf(pos[k]) * e[k].y;
+    for (int k = 0; k < 6 * NP; ++k) f[k] = e[k].x + __builtin_amdgcn_fractf(pos[k]) * e[k].y;
   }
   // (Tried and measured, round 1: compacting the v > 1 lanes of all 12 slots through a per-wave LDS queue -- ballot + mbcnt
   // ranks, cbrtf on dense groups of 64, results scattered back -- instead of one cbrtf per slot with most lanes idle.  On
@@ -1606,7 +1619,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   // side, two independent f64 chains in flight, noise 0.494 -> 0.533 ms, photo-like 0.388 -> 0.383 (a pair is evaluated whenever either slot needs
   // it); with the slots evaluated one by one inside the pair's branch noise 0.511 -> 0.521, photo-like 0.400 -> 0.395, smooth 0.446 -> 0.450.  Not kept.)
   #pragma unroll
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < 6 * NP; ++k) {
     if (IPK_RARE(__builtin_amdgcn_ballot_w64(__float_as_uint(v[k]) > 0x3F800000u) != 0)) {   // some lane has v > 1, v < 0, -0 or NaN
       const bool hi = v[k] > 1.0f;
       // the cube root under the lanes' own mask: the same instructions are issued, but only the lanes above 1 -- a tenth to a third of them on
@@ -1622,15 +1635,15 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       { const float dv = kLabK * v[k] + 16.0f; const float t = __builtin_fmaf(dv, rc_hi(116.0f), dv * rc_lo(116.0f)); f[k] = lo ? t : f[k]; }
     }
   }
-  f2 rr[2], gg[2], bb[2];
-  f2 Lq[2], Aq[2], Bq[2];
+  f2 rr[NP], gg[NP], bb[NP];
+  f2 Lq[NP], Aq[NP], Bq[NP];
   // the XYZ -> sRGB matrix (par[16..24]): read where LDS_ORDER puts the curve's reads, used at the very end
   float pm[9];
   {
     #pragma unroll
     for (int i = 0; i < 9; ++i) pm[i] = TOLAB_ONLY ? 0.0f : a.rgbm.m[i];
     #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NP; ++g) {
       const f2 fx = F2(f[6 * g], f[6 * g + 1]), fy = F2(f[6 * g + 2], f[6 * g + 3]), fz = F2(f[6 * g + 4], f[6 * g + 5]);
       const f2 l = S2(116.0f) * fy - S2(16.0f);
       const f2 a0 = S2(500.0f) * (fx - fy);
@@ -1647,7 +1660,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     }
   }
   #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NP; ++g) {
     const f2 L = Lq[g], A = Aq[g], B = Bq[g];
     if (TOLAB_ONLY) {
       o[2 * g].r = L.x; o[2 * g].g = A.x; o[2 * g].b = B.x; o[2 * g + 1].r = L.y; o[2 * g + 1].g = A.y; o[2 * g + 1].b = B.y;
@@ -1689,18 +1702,18 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
   }
   if (TOLAB_ONLY) return bad;
   if (!linear) {
-    float pos[12]; LutPair e[12];
+    float pos[6 * NP]; LutPair e[6 * NP];
     #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NP; ++g) {
       const float c[6] = {__builtin_amdgcn_fmed3f(rr[g].x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(rr[g].y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gg[g].x, 0.0f, 1.0f),
                           __builtin_amdgcn_fmed3f(gg[g].y, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb[g].x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(bb[g].y, 0.0f, 1.0f)};
       #pragma unroll
       for (int k = 0; k < 6; ++k) pos[6 * g + k] = c[k] * kLutMaxF;
     }
     #pragma unroll
-    for (int k = 0; k < 12; ++k) e[k] = lut_pair_at(s_gam, f32_as_u32_sat(pos[k]));
+    for (int k = 0; k < 6 * NP; ++k) e[k] = lut_pair_at(s_gam, f32_as_u32_sat(pos[k]));
     #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NP; ++g) {
       float w[6];
       #pragma unroll
       for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_fractf(pos[6 * g + k]);
@@ -1711,7 +1724,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     }
   }
   #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NP; ++g) {
     o[2 * g].r = rr[g].x; o[2 * g].g = gg[g].x; o[2 * g].b = bb[g].x;
     o[2 * g + 1].r = rr[g].y; o[2 * g + 1].g = gg[g].y; o[2 * g + 1].b = bb[g].y;
   }
@@ -2388,7 +2401,7 @@ __global__ __launch_bounds__(1024) void k_fused_bayer(FusedArgs a) { fused_bayer
 template <typename SrcT, bool VEC, int OUT, bool PXG>
 __global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, 1, false, true>(a, &bp); }
 
-static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1);
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1, uint32_t waves_per_block = 16);
 static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk);
 // after hipLaunchKernelGGL: an enqueue error becomes the launcher's return value (-4); nothing is left to undo, the heads were not touched
 static int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -4; }
@@ -2407,7 +2420,9 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
   unsigned blocks;
   std::unique_lock<std::mutex> queue_lock;
   (void)task_counters_for(s, a, queue_lock);
-  // the demosaic-only Bayer variant is memory-bound and small (58 VGPRs, 67 KB of LDS): two persistent blocks per CU, 8 waves per SIMD in flight
+  // the demosaic-only variants are memory-bound and small (78 VGPRs, 67 KB of LDS): two blocks per CU are launched, of which one is resident at a time
+  // (round 4: blocks of eight waves, three resident per CU -- six waves per SIMD instead of four -- measured slower, 402 -> 416 us at 100 MP)
+  // (1 / 2 / 3 / 4 / 6 blocks per CU launched: 0.416 / 0.415 / 0.422 / 0.417 / 0.426 ms at 100 MP)
   fused_task_grid(a, gen_cells ? num_cus : 2 * (num_cus > 0 ? num_cus : 256), blocks);
   if (gen_cells) {
     if (a.W >= 256u) hipLaunchKernelGGL((k_fused_bayer<float, true, 3, true, true>), dim3(blocks), dim3(1024), 0, s, a);
@@ -2556,8 +2571,7 @@ void release_task_counters() {
 //   frame and the static schedule needs no queue for ONE frame up to a share of ~128 rows: 72 MP static 0.349 / 0.277 ms against drawn 0.353 / 0.285,
 //   100 MP 0.479 / 0.382 against 0.487 / 0.384, 196 MP 0.928 / 0.730 against 0.929 / 0.714.  A batch keeps the queue from a share of 64 rows: one task per
 //   wave would be thousands of rows of one frame (64 x 24 MP: 7.31 ms drawn, 8.81 static).
-static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames) {
-  const uint32_t waves_per_block = 16;
+static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames, uint32_t waves_per_block) {
   const uint32_t uni = 32u, share_min = frames == 1 ? 128u : 64u;
   const uint32_t grid = (uint32_t)(num_cus > 0 ? num_cus : 256);
   const uint32_t total_waves = grid * waves_per_block;
@@ -2680,8 +2694,12 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // TOLAB_ONLY: OpToLab alone (the staged ipk_tolab, for callers that memoise the Lab buffer): same loads, same fast form with the literal
 // redo behind a wave-uniform branch, stops behind xyz_to_lab; only the Lab table lives in LDS (32 KB: several blocks per CU).
+// TOLAB_ONLY takes TWO pixels per lane (128-pixel chunks): with half the live values the compiler keeps the kernel to 64 vector registers, so that two
+// blocks (66 KB of LDS each) share a CU -- eight waves per SIMD instead of four cover the load latency this kernel otherwise sits in.
 template <bool TOLAB_ONLY>
-__global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) {
+__device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_t npix) {
+  constexpr int NP = TOLAB_ONLY ? 1 : 2, PPL = 2 * NP;                  // pixel pairs / pixels per lane
+  constexpr uint64_t CH = 64u * PPL;                                   // pixels per wave step
   __shared__ LabTab s_lab[kLutPairs + 4];
   __shared__ GamTab s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
@@ -2697,29 +2715,30 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  const uint64_t nchunks = (npix + 255) / 256;
+  const uint64_t nchunks = (npix + CH - 1) / CH;
   const float4 *src = reinterpret_cast<const float4 *>(a.src);
   f3 *dst = reinterpret_cast<f3 *>(a.dst);
-  // (Round 3: the loads of a wave's NEXT chunk issued before the current one is computed -- 16 more registers -- made the staged ipk_tolab slower,
-  // 0.527 -> 0.551 ms at 100 MP: the kernel is not waiting for its loads)
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const uint64_t base = chunk * 256 + lane;
-    float4 px[4];
+    const uint64_t base = chunk * CH + lane;
+    float4 px[PPL];
     #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PPL; ++j) {
       const uint64_t i = base + 64u * j;
       px[j] = ld_stream4(reinterpret_cast<const float *>(src + (i < npix ? i : npix - 1)));   // clamped, unpredicated: the tail lanes recompute the last pixel
     }
-    PixOut o[4];
+    PixOut o[PPL];
     // the fast form drops the E term (e * cm[i][3]): legal while the fourth channel is +0.0, as every producer on this
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
-    bool bad = a.fast_ok == 0 || (__float_as_uint(px[0].w) | __float_as_uint(px[1].w) | __float_as_uint(px[2].w) | __float_as_uint(px[3].w)) != 0u;
+    uint32_t wbits = 0u;
+    #pragma unroll
+    for (int j = 0; j < PPL; ++j) wbits |= __float_as_uint(px[j].w);
+    bool bad = a.fast_ok == 0 || wbits != 0u;
     if (a.fast_ok) {
-      bad |= pointwise4_fast<true, TOLAB_ONLY>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, 0, nullptr, TOLAB_ONLY ? nullptr : s_grid);
+      bad |= pointwise4_fast<true, TOLAB_ONLY, NP>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, 0, nullptr, TOLAB_ONLY ? nullptr : s_grid);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < PPL; ++j) {
         PixOut e;
         if (TOLAB_ONLY) camera_to_lab(s_lab, a.tolab, px[j].x, px[j].y, px[j].z, px[j].w, e.r, e.g, e.b);
         else e = pointwise_exact(a, s_lab, s_gam, s_knots, px[j]);
@@ -2727,12 +2746,14 @@ __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t 
       }
     }
     #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PPL; ++j) {
       const uint64_t i = base + 64u * j;
       if (i < npix) { float *po = reinterpret_cast<float *>(dst + i); st_stream(po, o[j].r); st_stream(po + 1, o[j].g); st_stream(po + 2, o[j].b); }
     }
   }
 }
+template <bool TOLAB_ONLY>
+__global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) { pointwise_chain_body<TOLAB_ONLY>(a, npix); }
 static FusedArgs chain_args(const FusedLaunch &f) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -2749,7 +2770,7 @@ static FusedArgs chain_args(const FusedLaunch &f) {
 int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
   FusedArgs a = chain_args(f);
   const size_t chunks = (npix + 255) / 256;
-  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);                      // (more blocks measured: 1 / 2 / 4 / 8 / 16 per CU 0.663 / 0.665 / 0.677 / 0.673 / 0.704 ms at 100 MP)
   const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
   hipLaunchKernelGGL(k_pointwise_chain<false>, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
   return 0;
@@ -2757,8 +2778,10 @@ int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
 // OpToLab::run on the fast form (the staged op): f.fast_ok / f.mul4 / f.cm12 / f.lab_table as for the chain
 int launch_tolab_fast(const FusedLaunch &f, size_t npix, hipStream_t s) {
   FusedArgs a = chain_args(f);
-  const size_t chunks = (npix + 255) / 256;
-  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256) * 2u;                 // two 1024-thread blocks per CU fit (66 KB of LDS each)
+  const size_t chunks = (npix + 127) / 128;                                               // two pixels per lane (pointwise_chain_body)
+  // two 1024-thread blocks per CU are resident (66 KB of LDS, 63 registers each); sixteen per CU slot are launched, so that the chip works on one
+  // compact, advancing window of the buffer: 1 / 2 / 4 / 8 / 16 / 32 / 64 per CU 0.555 / 0.525 / 0.516 / 0.499 / 0.497 / 0.506 / 0.539 ms at 100 MP
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256) * 16u;
   const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);
   hipLaunchKernelGGL(k_pointwise_chain<true>, dim3(blocks ? blocks : 1), dim3(1024), 0, s, a, (uint64_t)npix);
   return 0;
