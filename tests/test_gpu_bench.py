@@ -85,6 +85,15 @@ def test_bench_default_control_flow_with_extras(nproc):
         # the library's own gather (host transport here: the ranks share the GPU) must have moved the frames, f32 and 8-bit
         assert g["ipk_f32"]["ok"] and g["ipk_u8"]["ok"] and g["ipk_f32"]["every_rank_holds_the_same_frames"], g
         assert g["ipk_u8"]["gathered_bytes_per_rank_per_step"] * 4 == g["ipk_f32"]["gathered_bytes_per_rank_per_step"]
+        # the multi-GPU claim, first-class in the line: the batch on N GPUs against the same batch on one, per delivery of the results, each with
+        # the xGMI arithmetic beside the measurement
+        sc = d["scale"]
+        assert sc["n_gpus"] == 2 and sc["n1_batch_ms"] > 0 and "compute_only" in sc["claim"]
+        assert sc["compute_only"]["ms"] > 0 and sc["compute_only"]["expected_speedup"] == 2.0 and sc["compute_only"]["speedup"] > 0
+        for k in ("gather_to_root_u8", "gather_to_root_u8_overlapped", "all_gather_f32", "all_gather_f32_overlapped"):
+            assert sc[k]["ms"] > 0 and sc[k]["expected_ms"] > 0 and sc[k]["link_ms"] > 0 and sc[k]["speedup"] > 0, (k, sc[k])
+        assert sc["all_gather_f32"]["link_ms"] == pytest.approx(4 * sc["gather_to_root_u8"]["link_ms"], rel=0.02)
+        assert g["ipk_u8_to_root"]["root"] == 0 and g["ipk_f32_overlapped"]["overlapped"] is True
         # the banded single-frame leg runs in child processes on the RCCL transport: with two ranks on ONE GPU RCCL refuses the communicator,
         # and the leg must say so loudly (ok false, named in failed_legs) instead of costing the line or passing silently
         assert d["band_mode"]["ok"] is False and "band_mode" in d["failed_legs"], d.get("band_mode")
@@ -119,6 +128,7 @@ def test_bench_batch_two_ranks():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 6 and d["scaling"] == "strong" and d["value"] > 0
     assert d["with_gather"]["ipk_f32"]["ok"] and d["with_gather"]["ipk_u8"]["ok"]        # the library's gather; torch's over gloo may refuse device tensors
+    assert d["scale"]["compute_only"]["speedup"] > 0 and d["scale"]["all_gather_f32_overlapped"]["ms"] > 0
 
 
 @pytest.mark.parametrize("cfa,H,W,nproc", [("RGGB", 150, 600, 2), ("GBRG", 301, 258, 3), ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 180, 300, 4)])
