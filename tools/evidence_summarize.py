@@ -1,14 +1,16 @@
 #!/usr/bin/env python
-"""Turns gpurun_out/evid_<TAG> (tools/evidence_r03.sh, run on the GPU box) into the tracked evidence under profiles/:
+"""Turns gpurun_out/evid_<TAG> (tools/evidence.sh, run on the GPU box) into the tracked evidence under profiles/:
    <TAG>_kernel_stats.csv, <TAG>_c4/_c2/_c5_kernel_stats.csv   rocprofv3 --kernel-trace --stats summaries
    <TAG>_counters.json      HBM traffic per launch (FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE; separate passes), headline and configs
    <TAG>_valu_model.json    the VALU-issue account of k_fused_bayer: instruction counts by class, priced two ways, the wave-cycle ratio and the stall split
    <TAG>_ubench2.txt        the micro-benchmark figures the prices come from
+   <TAG>_variants.csv       one rocprofv3 line per fused variant (curve x linear x source x output) with its HBM and per-pixel figures
+   <TAG>_staged_kernels.csv the staged 100 MP pipeline's kernels (the cache path), each with its algorithmic bytes and fraction of the HBM peak
 """
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "evid_" + tag)
 dst = os.path.join(root, "profiles")
@@ -78,6 +80,70 @@ for c, needle, alg, what in (("c4", "k_fused_bayer_batch", 64 * 16 * 6000 * 4000
         e["bench_line_roofline"] = bl.get("roofline")
         e["bench_ms_per_step"] = bl.get("ms_per_step")
     out[c] = e
+# ---- the stream probe (the fused kernel's memory skeleton) under the kernel trace ------------------------------------------------------------
+f = find("stats_probe", "*kernel_stats.csv")
+if f:
+    for r in csv.DictReader(open(f)):
+        if "k_fused_bayer<float, true, 4," in r.get("Name", ""):
+            out["stream_probe"] = {"kernel": r["Name"][:100], "calls": int(r["Calls"]), "average_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                   "algorithmic_bytes_per_launch": 16e8, "frac_of_8TBps": round(16e8 / (float(r["AverageNs"]) * 1e-9) / 8e12, 4),
+                                   "command": "python bench.py --no-cpu-baseline --no-check --steps 20 (its ceiling leg: ipk_stream_probe on the headline frame)"}
+    bl = bench_line(os.path.join(src, "bench_probe.log"))
+    if bl:
+        out["stream_probe_bench_roofline"] = bl.get("roofline")
+
+# ---- every fused variant -----------------------------------------------------------------------------------------------------------------------
+rows = []
+for aj in sorted(glob.glob(os.path.join(src, "variants", "v*.args")), key=lambda p: int(os.path.basename(p)[1:-5])):
+    vdir = aj[:-5]
+    bl = bench_line(vdir + ".json")
+    ks = None
+    g = glob.glob(os.path.join(vdir, "**", "*kernel_stats.csv"), recursive=True)
+    if g:
+        best = None
+        for r in csv.DictReader(open(g[0])):
+            if "k_fused_bayer<" in r.get("Name", "") and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                best = r
+        ks = best
+    if not (bl and ks):
+        continue
+    c = bl["config"]
+    bpp = {"f32": 4, "u16": 2}[c["src"]] + {"f32": 12, "u8": 3, "u16": 6}[c["out"]]
+    avg = float(ks["AverageNs"]) / 1e3
+    rows.append({"src": c["src"], "out": c["out"], "curve": c["curve"], "linear": int(bool(c["linear"])), "exposure": c["exposure"],
+                 "kernel": ks["Name"].replace("void ipk::", "").split("(")[0], "calls": int(ks["Calls"]), "avg_us": round(avg, 1), "min_us": round(float(ks["MinNs"]) / 1e3, 1),
+                 "stddev_us": round(float(ks.get("StdDev", 0) or 0) / 1e3, 1), "alg_bytes_per_px": bpp, "achieved_GBps": round(bpp * 1e8 / (avg * 1e-6) / 1e9, 1),
+                 "frac_of_8TBps": round(bpp * 1e8 / (avg * 1e-6) / 8e12, 4), "px_per_ns": round(1e8 / (avg * 1e3), 3), "bench_kernel_ms": bl["roofline"]["kernel_ms"]})
+if rows:
+    base = {(r["src"], r["out"]): r["avg_us"] for r in rows if r["curve"] == "default" and r["linear"] == (1 if r["out"] == "u16" else 0)}
+    for r in rows:
+        b = base.get((r["src"], r["out"]))
+        r["time_vs_common_variant"] = round(r["avg_us"] / b, 3) if b else ""
+    with open(os.path.join(dst, tag + "_variants.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+    out["variants"] = {"file": tag + "_variants.csv", "n": len(rows), "worst_time_vs_common": max((r["time_vs_common_variant"] or 0) for r in rows),
+                       "note": "100 MP frame, noise; one rocprofv3 --kernel-trace --stats run per variant; the u8 / u16 outputs are the output_8bit / output_16bit "
+                               "boundary (5-7 / 8-10 B per pixel): bound by VALU issue, not HBM -- px_per_ns is the comparable figure across outputs"}
+
+# ---- the staged kernels of the 100 MP pipeline (the cache path) -----------------------------------------------------------------------------
+f = find("stats_staged", "*kernel_stats.csv")
+if f:
+    alg = [("k_gofloat_cfa", 8e8, "OpGoFloat 4+4 B/px"), ("k_fused_bayer<float, true, 3,", 20e8, "OpDemosaic (row walker, demosaic only) 4+16"), ("k_pointwise_chain<true>", 28e8, "OpToLab 16+12"),
+           ("k_basecurve", 24e8, "OpBaseCurve 12+12"), ("k_fromlab", 24e8, "OpFromLab 12+12"), ("k_gamma", 24e8, "OpGamma 12+12"), ("k_output8", 15e8, "output8bit 12+3"),
+           ("k_output16", 18e8, "output16bit 12+6")]
+    srows = []
+    for r in csv.DictReader(open(f)):
+        for needle, b, what in alg:
+            if needle in r.get("Name", ""):
+                avg = float(r["AverageNs"]) / 1e3
+                srows.append({"stage": what, "kernel": r["Name"].replace("void ipk::", "").replace("ipk::", "").split("(")[0], "calls": int(r["Calls"]), "avg_us": round(avg, 1),
+                              "min_us": round(float(r["MinNs"]) / 1e3, 1), "alg_bytes": int(b), "achieved_GBps": round(b / (avg * 1e-6) / 1e9, 1), "frac_of_8TBps": round(b / (avg * 1e-6) / 8e12, 4)})
+    if srows:
+        with open(os.path.join(dst, tag + "_staged_kernels.csv"), "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(srows[0].keys())); w.writeheader(); w.writerows(srows)
+        out["staged"] = {"file": tag + "_staged_kernels.csv", "command": "ONLY=C3 python tools/bench_configs.py (100 MP RGGB f32, staged pipeline) under rocprofv3 --kernel-trace --stats",
+                         "frac_of_8TBps": {r["kernel"]: r["frac_of_8TBps"] for r in srows}}
+
 bl = bench_line(os.path.join(src, "bench_plain.json"))
 if bl:
     out["bench_line"] = bl
