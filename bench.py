@@ -361,20 +361,29 @@ def ceiling_leg(ctx, wl, steps, warmup):
 
 
 def launch_stats(ctx, wl, n):
-    """n single launches, an event pair around each (the marker costs the queue a few microseconds, so these run a little slower than the
-    back-to-back mean): min / median / p95 / max / stddev of the launch duration in ms"""
+    """n single launches, an event pair around each, in the steady state: 60 untimed launches run straight in front of them with no synchronisation in
+    between (the events are created beforehand).  min / median / p95 / max / stddev of the launch duration in ms -- and, beside it, what an idle gap costs:
+    after a synchronise + 50 ms of sleep the shader clock has dropped and takes ~20 launches (~12 ms) to come back, which is what the 0.6 ms outliers of
+    earlier rounds were (tools/outlier_probe.py: one run of 19 consecutive slow launches behind the pause, none elsewhere in 3000)."""
     torch = ctx.torch
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    for _ in range(8):
+    idle = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for _ in range(60):
         wl.step()
     for a, b in evs:
         a.record(); wl.step(); b.record()
     torch.cuda.synchronize()
+    time.sleep(0.05)
+    for a, b in idle:
+        a.record(); wl.step(); b.record()
+    torch.cuda.synchronize()
     per = sorted(a.elapsed_time(b) / wl.launches_per_step for a, b in evs)
+    after_idle = [a.elapsed_time(b) / wl.launches_per_step for a, b in idle]
     mean = sum(per) / n
     sd = (sum((x - mean) ** 2 for x in per) / n) ** 0.5
     return {"launches": n, "min_ms": round(per[0], 4), "median_ms": round(per[n // 2], 4), "p95_ms": round(per[min(n - 1, int(0.95 * n))], 4), "max_ms": round(per[-1], 4),
-            "mean_ms": round(mean, 4), "stddev_ms": round(sd, 4), "stddev_frac": round(sd / mean, 4), "over_1p2x_median": sum(1 for x in per if x > 1.2 * per[n // 2])}
+            "mean_ms": round(mean, 4), "stddev_ms": round(sd, 4), "stddev_frac": round(sd / mean, 4), "over_1p2x_median": sum(1 for x in per if x > 1.2 * per[n // 2]),
+            "after_50ms_idle": {"first_ms": round(after_idle[0], 4), "max_ms": round(max(after_idle), 4), "mean_of_20_ms": round(sum(after_idle) / 20, 4)}}
 
 
 def valu_model(kernel_ms, data):

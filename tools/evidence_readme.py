@@ -53,8 +53,11 @@ def glance():
                 r["ceiling_ms"], r["ceiling_frac_of_peak"], r["frac_of_ceiling"], r.get("copy_ceiling_GBps", float("nan")), r.get("frac_of_copy_ceiling", float("nan")))))
         if "launch_stats" in r:
             ls = r["launch_stats"]
-            rows.append(("launch-to-launch spread (%d single launches)" % ls["launches"], "min %.4f / median %.4f / p95 %.4f / max %.4f ms, stddev %.1f %%, %d above 1.2× median" % (
-                ls["min_ms"], ls["median_ms"], ls["p95_ms"], ls["max_ms"], 100 * ls["stddev_frac"], ls["over_1p2x_median"])))
+            t = "min %.4f / median %.4f / p95 %.4f / max %.4f ms, stddev %.1f %%, %d above 1.2× median" % (
+                ls["min_ms"], ls["median_ms"], ls["p95_ms"], ls["max_ms"], 100 * ls["stddev_frac"], ls["over_1p2x_median"])
+            if "after_50ms_idle" in ls:
+                t += "; the 20 launches behind a 50 ms idle gap: first %.4f, max %.4f, mean %.4f ms (clock ramp)" % (ls["after_50ms_idle"]["first_ms"], ls["after_50ms_idle"]["max_ms"], ls["after_50ms_idle"]["mean_of_20_ms"])
+            rows.append(("launch-to-launch spread, steady state (%d single launches)" % ls["launches"], t))
         if "other_data" in b:
             o = b["other_data"]
             rows.append(("other data kinds", ", ".join("%s %.4f ms (%.3f)" % (k, o[k]["kernel_ms"], o[k]["frac"]) for k in sorted(o))))
