@@ -386,6 +386,42 @@ def launch_stats(ctx, wl, n):
             "after_50ms_idle": {"first_ms": round(after_idle[0], 4), "max_ms": round(max(after_idle), 4), "mean_of_20_ms": round(sum(after_idle) / 20, 4)}}
 
 
+def live_traffic(timeout_s=240):
+    """HBM bytes per launch of the headline kernel, measured NOW: two child runs of this same script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
+    and `... WRITE_SIZE` (separate passes, kernel trace only -- MI355X_MICROARCH.md's recipe), a few steps each; FETCH_SIZE doubled per the guide's
+    gfx950 note (units of 1 KiB).  Returns (bytes per launch, detail) or (None, reason) -- the committed figure then stays in the line, labelled as such."""
+    import csv as _csv, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ipk_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu-baseline", "--no-check", "--no-extras", "--steps", "5", "--warmup", "1", "--prewarm-ms", "0"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None, "%s pass failed (rc %s)" % (ctr, r.returncode)
+            got = [float(row["Counter_Value"]) for row in _csv.DictReader(open(fs[0]))
+                   if "k_fused_bayer<" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr]
+            if not got:
+                return None, "%s: no rows for the kernel" % ctr
+            vals[ctr] = sum(got) / len(got)
+        except Exception as e:
+            return None, "%s pass: %r" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = vals["FETCH_SIZE"] * 2048.0 + vals["WRITE_SIZE"] * 1024.0
+    return total, {"fetch_bytes": round(vals["FETCH_SIZE"] * 2048.0), "write_bytes": round(vals["WRITE_SIZE"] * 1024.0),
+                   "method": "two child runs of this script under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                             "per-launch mean; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note"}
+
+
 def valu_model(kernel_ms, data):
     """The VALU-issue account of the fused kernel from the tracked file profiles/r*_valu_model.json (tools/evidence_r03.sh):
     dynamic instruction counts per launch by class (rocprofv3 PMC), priced two ways with tools/ubench2.hip's figures -- `interleaved`: at the cost
@@ -510,6 +546,16 @@ def main():
         vm = valu_model(kernel_ms, args.data)
         if vm:
             result["roofline_valu"] = vm
+        if extras and world == 1 and os.environ.get("IPK_BENCH_NO_LIVE_PMC") != "1":
+            # measured in THIS run when rocprofv3 is there (it is on the GPU boxes); the committed figure above stays only if the passes fail
+            tb, det = live_traffic()
+            if tb is not None:
+                result["roofline"]["traffic"] = round(tb)
+                result["roofline"]["traffic_source"] = "measured in this run"
+                result["roofline"]["traffic_detail"] = det
+                result["roofline"]["traffic_over_algorithmic"] = round(tb / alg_bytes, 4)
+            else:
+                result["roofline"]["traffic_live_failed"] = det
 
     if args.kernel_stats > 0 or extras:
         result["roofline"]["launch_stats"] = launch_stats(ctx, wl, args.kernel_stats if args.kernel_stats > 0 else (40 if dev_small else 500))

@@ -41,7 +41,7 @@ for src in f32 u16; do
   vrun --src $src --out f32 --curve none --exposure 0.5 --linear
 done
 # 4c. the stream probe (the fused kernel's memory skeleton) under the kernel trace, and the staged kernels of the 100 MP pipeline
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_probe -o s -- python bench.py --no-cpu-baseline --no-check --steps 20 > $OUT/bench_probe.log 2>&1
+IPK_BENCH_NO_LIVE_PMC=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_probe -o s -- python bench.py --no-cpu-baseline --no-check --steps 20 > $OUT/bench_probe.log 2>&1
 ONLY=C3 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_staged -o s -- python tools/bench_configs.py > $OUT/bench_staged.log 2>&1
 # 5. the plain default run, exactly as the driver issues it
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
