@@ -338,8 +338,26 @@ def copy_ceiling(ctx, nbytes):
         rc = L.ipk_copy_probe(a.data_ptr(), b.data_ptr(), nbytes, st)
         assert rc == 0, rc
     own, tch = run(probe), run(lambda: b.copy_(a))
-    del a, b
-    return own, tch
+    del b
+    # the fused path's own read : write mix (4 B in, 12 B out per pixel) as a flat, contiguous, nontemporal kernel without arithmetic (ipk_mix_probe):
+    # what the memory system gives ANY kernel that writes three f32 per sample read
+    n_in = (nbytes // 4) // 16 * 16
+    c = torch.empty(n_in * 3 // 4, dtype=torch.float32, device="cuda")
+
+    def mix():
+        rc = L.ipk_mix_probe(a.data_ptr(), c.data_ptr(), n_in, st)
+        assert rc == 0, rc
+    for _ in range(5):
+        mix()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        mix()
+    e1.record(); torch.cuda.synchronize()
+    mixed = 4.0 * n_in / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+    del a, c
+    return own, tch, mixed
 
 
 def ceiling_leg(ctx, wl, steps, warmup):
@@ -571,11 +589,14 @@ def main():
             result["roofline"]["frac_of_ceiling"] = round(ce[0] / kernel_ms, 4)
             result["roofline"]["ceiling_kernel"] = "ipk_stream_probe = k_fused_bayer<..., 4, ...>: the fused kernel's launch, loads, OpGoFloat, demosaic, staging and stores without OpToLab..OpGamma"
     if extras:
-        own, tch = copy_ceiling(ctx, (12 if dev_small else 1200) * 1000 * 1000)     # every rank (keeps the ranks in step)
+        own, tch, mixed = copy_ceiling(ctx, (12 if dev_small else 1200) * 1000 * 1000)     # every rank (keeps the ranks in step)
         result["roofline"]["copy_ceiling_GBps"] = round(max(own, tch), 1)
         result["roofline"]["copy_ceiling_detail"] = {"ipk_copy_probe_GBps": round(own, 1), "torch_copy_GBps": round(tch, 1),
                                                      "guide_float4_copy_GBps": 6290.0, "bytes": (12 if dev_small else 1200) * 1000 * 1000}
         result["roofline"]["frac_of_copy_ceiling"] = round(achieved / result["roofline"]["copy_ceiling_GBps"], 4)
+        result["roofline"]["mix_ceiling_GBps"] = round(mixed, 1)          # a flat kernel with the fused path's 1 : 3 read : write mix and no arithmetic (ipk_mix_probe)
+        result["roofline"]["mix_ceiling_frac_of_peak"] = round(mixed / HBM_PEAK_GBS, 4)
+        result["roofline"]["frac_of_mix_ceiling"] = round(achieved / mixed, 4)
         other = {}
         for kind in ("smooth", "photo"):
             w2 = FusedBatch(ctx, ipa, util, W, H, world, cfa, args.src, args.out, kind, util.SEED + 2)

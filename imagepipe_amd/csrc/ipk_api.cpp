@@ -1058,6 +1058,12 @@ int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream) {
   ipk::launch_copy_probe(src, dst, bytes, g.num_cus, S(stream)); HIPCHK(hipGetLastError());
   return IPK_OK;
 }
+int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream) {
+  REQUIRE_INIT();
+  if (!src || !dst || (src_bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(IPK_ERR_INVALID, "ipk_mix_probe wants 16-byte aligned buffers and a multiple of 16 bytes");
+  ipk::launch_mix_probe(src, dst, src_bytes, S(stream)); HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
 int ipk_selftest_task_queue(int enabled) { REQUIRE_INIT(); ipk::selftest_task_queue(enabled != 0); return IPK_OK; }
 int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint64_t *n_bad, uint32_t *first_bad_bits) {
   REQUIRE_INIT();

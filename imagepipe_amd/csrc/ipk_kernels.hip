@@ -2940,6 +2940,26 @@ __global__ __launch_bounds__(256) void k_copy_probe(const ipk_f4v *__restrict__ 
   #pragma unroll
   for (int u = 0; u < 4; ++u) if (base + u * 256 < n16) __builtin_nontemporal_store(v[u], dst + base + u * 256);
 }
+// The same for the fused kernel's READ : WRITE MIX -- 16 bytes read, 48 written per lane (4 : 12 bytes per pixel), flat launch, contiguous, nontemporal -- with
+// no arithmetic at all: what the memory system gives ANY kernel that turns a 1-channel f32 mosaic into 3-channel f32 pixels (bench.py's mix_ceiling).
+constexpr int kMixU = 1;     // one group per lane: 100 MP 0.273 ms = 5.86 TB/s; two 0.291; four 0.297 (same box)
+__global__ __launch_bounds__(256) void k_mix_probe(const ipk_f4v *__restrict__ src, ipk_f4v *__restrict__ dst, size_t n16) {
+  constexpr int U = kMixU;                                  // 16-byte groups read per lane
+  const size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+  ipk_f4v v[U];
+  #pragma unroll
+  for (int u = 0; u < U; ++u) if (base + u * 256 < n16) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+  #pragma unroll
+  for (int u = 0; u < U; ++u) if (base + u * 256 < n16) {
+    // the block's 256 U input groups become 768 U contiguous output groups, written as lane-contiguous sweeps of 256
+    ipk_f4v *o = dst + (size_t)blockIdx.x * (768 * U) + u * 768 + threadIdx.x;
+    __builtin_nontemporal_store(v[u], o); __builtin_nontemporal_store(v[u], o + 256); __builtin_nontemporal_store(v[u], o + 512);
+  }
+}
+void launch_mix_probe(const void *src, void *dst, size_t src_bytes, hipStream_t s) {
+  const size_t n16 = src_bytes / 16, per = 256 * kMixU;
+  hipLaunchKernelGGL(k_mix_probe, dim3((unsigned)std::max<size_t>(1, (n16 + per - 1) / per)), dim3(256), 0, s, reinterpret_cast<const ipk_f4v *>(src), reinterpret_cast<ipk_f4v *>(dst), n16);
+}
 void launch_copy_probe(const void *src, void *dst, size_t bytes, int, hipStream_t s) {
   const size_t n16 = bytes / 16;
   hipLaunchKernelGGL(k_copy_probe, dim3((unsigned)std::max<size_t>(1, (n16 + 1023) / 1024)), dim3(256), 0, s, reinterpret_cast<const ipk_f4v *>(src), reinterpret_cast<ipk_f4v *>(dst), n16);

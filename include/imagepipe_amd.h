@@ -520,6 +520,9 @@ IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* Measurement aid, no counterpart in the reference: a plain device-to-device copy, 16 bytes per lane, as the practical HBM ceiling next to which
  * bench.py reports the kernels' achieved bandwidth (SURVEY.md 8d asks for the measured copy / triad ceiling beside the 8 TB/s spec peak). */
 IPK_API int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream);
+/* The same for the fused path's read : write mix: src_bytes read, 3 * src_bytes written (4 : 12 bytes per pixel, f32 mosaic -> f32 RGB), flat launch,
+ * contiguous, nontemporal, no arithmetic: the ceiling of ANY kernel with that traffic (bench.py roofline.mix_ceiling_GBps).  dst holds 3 * src_bytes. */
+IPK_API int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream);
 /* Measurement aid, no counterpart in the reference: the memory skeleton of ipk_raw_to_srgb as a launch of its own -- the same persistent launch and
  * task walk, the same row loads, OpGoFloat normalisation (src/ops/gofloat.rs:126), demosaic::full (src/ops/demosaic.rs:67-119), LDS staging and
  * nontemporal stores, WITHOUT OpToLab..OpGamma: dst receives the demosaiced R, G, B channels (the first three of demosaic::full's RGBE pixel) as
