@@ -51,6 +51,9 @@ def glance():
         if "ceiling_ms" in r:
             rows.append(("measured ceiling: the kernel's memory skeleton (`ipk_stream_probe`)", "ceiling_ms %.4f = %.3f of peak; **frac_of_ceiling %.3f**; 1:1 copy ceiling %.0f GB/s (frac_of_copy_ceiling %.3f)" % (
                 r["ceiling_ms"], r["ceiling_frac_of_peak"], r["frac_of_ceiling"], r.get("copy_ceiling_GBps", float("nan")), r.get("frac_of_copy_ceiling", float("nan")))))
+        if "mix_ceiling_GBps" in r:
+            rows.append(("the traffic mix's own ceiling (`ipk_mix_probe`: 4 B read : 12 B written per pixel, flat, no arithmetic)", "%.0f GB/s = **%.3f of peak**; the fused kernel is at %.3f of it" % (
+                r["mix_ceiling_GBps"], r["mix_ceiling_frac_of_peak"], r["frac_of_mix_ceiling"])))
         if "launch_stats" in r:
             ls = r["launch_stats"]
             t = "min %.4f / median %.4f / p95 %.4f / max %.4f ms, stddev %.1f %%, %d above 1.2× median" % (
