@@ -341,7 +341,7 @@ def copy_ceiling(ctx, nbytes):
     del b
     # the fused path's own read : write mix (4 B in, 12 B out per pixel) as a flat, contiguous, nontemporal kernel without arithmetic (ipk_mix_probe):
     # what the memory system gives ANY kernel that writes three f32 per sample read
-    n_in = (nbytes // 4) // 16 * 16
+    n_in = (nbytes // 4) // 4096 * 4096                      # source BYTES of the probe (a quarter of the copy's: the mix writes three times what it reads)
     c = torch.empty(n_in * 3 // 4, dtype=torch.float32, device="cuda")
 
     def mix():

@@ -1060,7 +1060,7 @@ int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream) {
 }
 int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream) {
   REQUIRE_INIT();
-  if (!src || !dst || (src_bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(IPK_ERR_INVALID, "ipk_mix_probe wants 16-byte aligned buffers and a multiple of 16 bytes");
+  if (!src || !dst || (src_bytes & 4095) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(IPK_ERR_INVALID, "ipk_mix_probe wants 16-byte aligned buffers and a multiple of 4096 source bytes (whole blocks)");
   ipk::launch_mix_probe(src, dst, src_bytes, S(stream)); HIPCHK(hipGetLastError());
   return IPK_OK;
 }

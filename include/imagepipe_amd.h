@@ -521,7 +521,8 @@ IPK_API int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits);
  * bench.py reports the kernels' achieved bandwidth (SURVEY.md 8d asks for the measured copy / triad ceiling beside the 8 TB/s spec peak). */
 IPK_API int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream);
 /* The same for the fused path's read : write mix: src_bytes read, 3 * src_bytes written (4 : 12 bytes per pixel, f32 mosaic -> f32 RGB), flat launch,
- * contiguous, nontemporal, no arithmetic: the ceiling of ANY kernel with that traffic (bench.py roofline.mix_ceiling_GBps).  dst holds 3 * src_bytes. */
+ * contiguous, nontemporal, no arithmetic: the ceiling of ANY kernel with that traffic (bench.py roofline.mix_ceiling_GBps).  dst holds 3 * src_bytes;
+ * src_bytes a multiple of 4096 (whole blocks of 256 lanes x 16 bytes), both pointers 16-byte aligned. */
 IPK_API int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream);
 /* Measurement aid, no counterpart in the reference: the memory skeleton of ipk_raw_to_srgb as a launch of its own -- the same persistent launch and
  * task walk, the same row loads, OpGoFloat normalisation (src/ops/gofloat.rs:126), demosaic::full (src/ops/demosaic.rs:67-119), LDS staging and

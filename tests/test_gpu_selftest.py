@@ -194,14 +194,16 @@ def test_mix_probe_moves_the_bytes_it_claims(L):
     """ipk_mix_probe (bench.py's mix_ceiling: 16 bytes read, 48 written per lane) really reads every input group and writes three output groups for it:
     block b's 256 input groups land three times in its 768 output groups, as lane-contiguous sweeps"""
     import torch
-    n16 = 256 * 37 + 100                                   # a ragged last block
+    n16 = 256 * 37                                         # whole blocks only: the probe refuses anything else
     src = torch.arange(n16 * 4, dtype=torch.float32, device="cuda")
     dst = torch.full((n16 * 12,), -1.0, dtype=torch.float32, device="cuda")
     assert L.ipk_mix_probe(src.data_ptr(), dst.data_ptr(), n16 * 16, None) == 0
     torch.cuda.synchronize()
     s = src.cpu().numpy().reshape(n16, 4); d = dst.cpu().numpy().reshape(n16 * 3, 4)
-    for g in (0, 1, 255, 256, 257, 256 * 36 + 255, 256 * 37, n16 - 1):
+    for g in (0, 1, 255, 256, 257, 256 * 36 + 255, n16 - 1):
         b, t = divmod(g, 256)
         for k in range(3):
             assert (d[b * 768 + k * 256 + t] == s[g]).all(), (g, k)
+    assert (dst.cpu().numpy() >= 0).all()                   # every output group written
     assert L.ipk_mix_probe(src.data_ptr() + 4, dst.data_ptr(), n16 * 16, None) == -2       # misaligned source
+    assert L.ipk_mix_probe(src.data_ptr(), dst.data_ptr(), n16 * 16 - 1600, None) == -2     # not whole blocks

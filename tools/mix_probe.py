@@ -14,7 +14,7 @@ def t(fn):
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / 20
 for mp in (24, 100, 400):
-    n = mp * 1000 * 1000 * 4
+    n = mp * 1000 * 1000 * 4 // 4096 * 4096
     a = torch.ones(n // 4, device="cuda"); c = torch.empty(3 * n // 4, device="cuda")
     ms = t(lambda: L.ipk_mix_probe(a.data_ptr(), c.data_ptr(), n, st))
     b = torch.empty(4 * n // 4 // 2 * 2, device="cuda")[: n // 4 * 2]
