@@ -1,3 +1,5 @@
+#!/bin/bash
+# The round-end check on the GPU box (through gpurun): the whole -m gpu suite, smoke(), then the evidence collection for tools/evidence_summarize.py.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 ( time python -m pytest tests -m gpu -q ) > gpurun_out/final/pytest.log 2>&1
