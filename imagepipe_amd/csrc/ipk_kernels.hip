@@ -682,22 +682,24 @@ constexpr uint32_t kW8MaxCells = 144;
 constexpr uint32_t kW8CellF4 = 9;
 // KU = the window columns every lane of every wave has (floor(skip) + 1, capped at 5): their taps are straight-line code; further columns (a
 // window whose phase wraps, the shifted loads at the right frame edge) sit behind one wave-uniform branch.
-template <typename T, uint32_t KU>
-__global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
+// C4 = the filter has a fourth colour (RGBE ...): three-colour filters (Bayer, X-Trans) skip its two accumulations per tap -- as a runtime flag they
+// were two fused multiply-adds and two selects per tap, a quarter of the tap's arithmetic.
+template <typename T, uint32_t KU, bool C4>
+// (seven blocks per CU asked for: with the two register sets of the unrolled row loop hipcc otherwise takes 73 VGPRs -- six waves per SIMD, 3 % slower)
+__global__ __launch_bounds__(256, 7) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
                                                                 uint32_t pw, uint32_t ph, float *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
-  __shared__ uint16_t s_bits[kW8MaxCells];                            // the same colours, 2 bits per column (select form)
-  for (uint32_t i = threadIdx.x; i < pw * ph; i += blockDim.x) {
-    const uint32_t y = i / pw, x = i % pw;
-    uint32_t bits = 0;
-    #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) {
-      const uint32_t c = cfa48[y * 48 + (x + k) % 48] & 3u;
-      bits |= c << (2 * k);
-      #pragma unroll
-      for (uint32_t cc = 0; cc < 4; ++cc) s_m[(i * kW8CellF4 + k) * 4 + cc] = (c == cc) ? 1.0f : 0.0f;
-    }
-    s_bits[i] = (uint16_t)bits;
+  // one (cell, column) pair per thread and step: a block lives for two or three output rows, and eight dependent byte loads per cell in front of its
+  // barrier were a sixth of its life
+  // (no division either: thread t takes column k = t & 7 of pattern cell x = (t >> 3) & 15 in the rows t >> 7, t >> 7 + 2, ...; pw <= 12 by the launcher's
+  // pw * ph <= kW8MaxCells with pw, ph dividing 48, and x + k < 48 needs no wrap)
+  {
+    const uint32_t k = threadIdx.x & 7u, x = (threadIdx.x >> 3) & 15u;
+    if (x < pw)
+      for (uint32_t y = threadIdx.x >> 7; y < ph; y += blockDim.x >> 7) {
+        const uint32_t c = cfa48[y * 48 + x + k] & 3u;
+        reinterpret_cast<float4 *>(s_m)[(y * pw + x) * kW8CellF4 + k] = make_float4(c == 0u ? 1.0f : 0.0f, c == 1u ? 1.0f : 0.0f, c == 2u ? 1.0f : 0.0f, c == 3u ? 1.0f : 0.0f);
+      }
   }
   __syncthreads();
   // Which block takes which columns and rows.  Output row r reads the source rows floor(skip r) .. floor(skip (r + 1)), so rows r and r + 1 share
@@ -728,10 +730,16 @@ __global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__r
   const uint32_t lx = min(from_x, a.width - 8);
   const uint32_t kshift = from_x - lx;
   float axm[8];                                          // 1 - dx*dx of sample lx + k, -inf outside the lane's window
-  #pragma unroll
-  for (uint32_t k = 0; k < 8; ++k) {
-    const float delta_x = tb_div((float)(lx + k) - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
-    axm[k] = ((k - kshift) < nx) ? 1.0f - (delta_x * delta_x) : -__builtin_inff();
+  {
+    // (x - center_x) / skip_x_x (scaling.rs:104).  As for the rows below: tl = (0, 0) and 1 <= skip <= 7 (launcher), so the sample's column and the centre
+    // are sums of terms that are zero or at least 2^-25 in magnitude, a nonzero difference is at least 2^-49 and at most the frame width -- inside the
+    // multiply-fma division's proven zone without tb_div's exponent test (round 4: eight divergent tests per block; a block lives for two or three rows)
+    #pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+      const float dx = (float)(lx + k) - center_x;
+      const float delta_x = a.fast_x ? cdiv_fast(dx, a.skip_x_x, a.inv_skip_x_x) : dx / a.skip_x_x;
+      axm[k] = ((k - kshift) < nx) ? 1.0f - (delta_x * delta_x) : -__builtin_inff();
+    }
   }
   const uint32_t xm = lx % pw;
   uint32_t kend = 0;
@@ -768,7 +776,9 @@ __global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__r
   typename Row8<T>::Raw nxt = Row8<T>::issue(rowptr(c1.y));
   float center_y = centre(c0.row);
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
-  for (;;) {
+  // one window row: `cur` holds its samples, `nxt` the next row's (in flight); the row after next is then loaded INTO `cur`.  The loop below calls it
+  // with the two register sets in alternating roles, so the rows never move between registers (the rolling form copied ten registers per window row).
+  auto window_row = [&](typename Row8<T>::Raw &cur, typename Row8<T>::Raw &nxt) -> bool {
     const uint32_t y = c0.y;
     {
       // (y - center_y) / skip_y_y (scaling.rs:105).  This kernel only runs for tl = (0, 0) and 1 <= skip <= 7 (launcher): y and the
@@ -814,7 +824,7 @@ __global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__r
           s0 = __builtin_fmaf(t, mk.x, s0); n0 = __builtin_fmaf(factor, mk.x, n0);
           s1 = __builtin_fmaf(t, mk.y, s1); n1 = __builtin_fmaf(factor, mk.y, n1);
           s2 = __builtin_fmaf(t, mk.z, s2); n2 = __builtin_fmaf(factor, mk.z, n2);
-          if (a.components > 3) { s3 = __builtin_fmaf(t, mk.w, s3); n3 = __builtin_fmaf(factor, mk.w, n3); }
+          if (C4) { s3 = __builtin_fmaf(t, mk.w, s3); n3 = __builtin_fmaf(factor, mk.w, n3); }
         };
         #pragma unroll
         for (uint32_t k = 0; k < KU; ++k) tap(k);          // every lane's window has these columns (or weight 0 for them)
@@ -824,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__r
             if (k < kend) tap(k);
         }
       } else {
-        const uint32_t bits = s_bits[cell];
+        const float4 *m = reinterpret_cast<const float4 *>(s_m) + cell * kW8CellF4;
         #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
           if (k < kend) {
@@ -835,11 +845,11 @@ __global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__r
             factor = in ? factor : 0.0f;
             float t = rs_min(q, 1.0f) * factor;
             t = in ? t : 0.0f;
-            const uint32_t c = (bits >> (2 * k)) & 3u;
-            s0 += (c == 0) ? t : 0.0f; n0 += (c == 0) ? factor : 0.0f;
-            s1 += (c == 1) ? t : 0.0f; n1 += (c == 1) ? factor : 0.0f;
-            s2 += (c == 2) ? t : 0.0f; n2 += (c == 2) ? factor : 0.0f;
-            if (a.components > 3) { s3 += (c == 3) ? t : 0.0f; n3 += (c == 3) ? factor : 0.0f; }
+            const float4 mk = m[k];                       // the column's colour, read back from its one-hot record
+            s0 += (mk.x != 0.0f) ? t : 0.0f; n0 += (mk.x != 0.0f) ? factor : 0.0f;
+            s1 += (mk.y != 0.0f) ? t : 0.0f; n1 += (mk.y != 0.0f) ? factor : 0.0f;
+            s2 += (mk.z != 0.0f) ? t : 0.0f; n2 += (mk.z != 0.0f) ? factor : 0.0f;
+            if (C4) { s3 += (mk.w != 0.0f) ? t : 0.0f; n3 += (mk.w != 0.0f) ? factor : 0.0f; }
           }
         }
       }
@@ -856,11 +866,16 @@ __global__ __launch_bounds__(256, 1) void k_raw_scaled_demosaic_w8m(const T *__r
       s0 = s1 = s2 = s3 = n0 = n1 = n2 = n3 = 0.0f;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!c1.valid) break;
+    if (!c1.valid) return false;
     const Cur c2 = next_of(c1);
-    const typename Row8<T>::Raw n2r = Row8<T>::issue(rowptr(c2.y));
+    cur = Row8<T>::issue(rowptr(c2.y));
     if (row_end) center_y = centre(c1.row);
-    c0 = c1; c1 = c2; cur = nxt; nxt = n2r;
+    c0 = c1; c1 = c2;
+    return true;
+  };
+  for (;;) {
+    if (!window_row(cur, nxt)) break;
+    if (!window_row(nxt, cur)) break;
   }
 }
 template <typename T>
@@ -894,6 +909,7 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
     // 7168 blocks 0.064 / 0.059 / 0.058 / 0.0565 / 0.0563 / 0.0565 with the plain grid, 0.064 / 0.061 / 0.060 / 0.057 / 0.059 / 0.058 with runs of two
     // block rows per XCD; equal row counts per block (every block the same 3, 4, 6 or 8 rows) 0.064 / 0.064 / 0.061 / 0.058 / 0.057 / 0.059: fewer, longer-lived
     // blocks lose although they run the per-block set-up less often -- the kernel is not bound by its instruction count alone.
+    // (round 5, after the kernel lost a quarter of its instructions: 3584 / 4096 / 5376 / 6144 / 8192 blocks and 7 or 8 resident per CU all within 2 %)
     const unsigned total_blocks = 5376u;
     const unsigned want = std::max(1u, total_blocks / gx);
     const dim3 grid2(gx, (unsigned)std::min<size_t>(out_rows, want), 1);
@@ -903,15 +919,21 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
       dim3 grid = grid2;
       a.xcd_gx = 0; a.xcd_gy = 0;
       {
-        uint32_t group = 2;     // block rows per XCD in a run
+        uint32_t group = 4;     // block rows per XCD in a run (round 5: 2 / 4 / 8 the same time, 16 slower; 4 takes the HBM traffic from 1.11x to 1.06x)
         if (group > 0 && grid2.y >= 8 * group) {
           a.xcd_gx = grid2.x; a.xcd_group = group; a.xcd_gy = grid2.y / (8 * group) * (8 * group);
           grid = dim3(a.xcd_gx * a.xcd_gy, 1, 1);
         }
       }
-      if (a.skip_x_x >= 4.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 5>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
-      else if (a.skip_x_x >= 2.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 3>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
-      else hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 2>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      if (has_fourth_colour) {
+        if (a.skip_x_x >= 4.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 5, true>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+        else if (a.skip_x_x >= 2.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 3, true>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+        else hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 2, true>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      } else {
+        if (a.skip_x_x >= 4.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 5, false>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+        else if (a.skip_x_x >= 2.0f) hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 3, false>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+        else hipLaunchKernelGGL((k_raw_scaled_demosaic_w8m<T, 2, false>), grid, dim3(256), lds, s, src, a, cfa48_dev, (uint32_t)pw, (uint32_t)ph, dst4);
+      }
       return;
     }
     hipLaunchKernelGGL(k_raw_scaled_demosaic_w8<T>, grid, dim3(256), 0, s, src, a, cfa48_dev, dst4);
