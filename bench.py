@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="keep the committed PMC traffic figure instead of measuring it in two short child runs under rocprofv3 (at most 45 s each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (cold clock, copy ceiling, other data kinds, 64-frame batch)")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed launches before the W warmup steps, to bring the shader clock to its loaded steady state (0 = off); "
@@ -404,7 +405,7 @@ def launch_stats(ctx, wl, n):
             "after_50ms_idle": {"first_ms": round(after_idle[0], 4), "max_ms": round(max(after_idle), 4), "mean_of_20_ms": round(sum(after_idle) / 20, 4)}}
 
 
-def live_traffic(timeout_s=90):
+def live_traffic(timeout_s=45):
     """HBM bytes per launch of the headline kernel, measured NOW: two child runs of this same script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
     and `... WRITE_SIZE` (separate passes, kernel trace only -- MI355X_MICROARCH.md's recipe), a few steps each; FETCH_SIZE doubled per the guide's
     gfx950 note (units of 1 KiB).  Returns (bytes per launch, detail) or (None, reason) -- the committed figure then stays in the line, labelled as such."""
@@ -543,6 +544,17 @@ def main():
                      "kernel": "k_fused_bayer", "kernel_ms": round(kernel_ms, 4), "kernel_ms_median": round(median_ms / wl.launches_per_step, 4),
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    if world > 1:
+        # what a reader of an N > 1 line must not miss: `value` is weak scaling of independent frames (one frame per GPU per step, nothing exchanged), so it
+        # grows ~N x by construction and proves nothing about a node; the judgeable object is `scale` (BASELINE.json configs[3]: the SAME 64 x 24 MP batch on
+        # N GPUs against one GPU, compute-only and with the results gathered, each beside its xGMI expectation)
+        result["scale_is_the_claim"] = True
+        result["value_basis"] = (("WEAK scaling, no data-path collective: every rank runs its own %dx%d frame per step, value = N frames' pixels / wall time of the K timed "
+                                  "steps (barrier + synchronize on both sides, max over ranks) -- ~N x the one-GPU value by construction.  " % (W, H) if weak else
+                                  "STRONG scaling of %d independent %dx%d frames per step, frame i on rank i mod N, nothing exchanged: value = their pixels / wall time of the K "
+                                  "timed steps (barrier + synchronize on both sides, max over ranks), results left on the GPUs that computed them.  " % (B, W, H)) +
+                                 "The multi-GPU claim is the `scale` object (one fixed batch: compute_only / gather_to_root_u8 / all_gather_f32, each measured against one GPU "
+                                 "in this run and beside expected_ms from the xGMI link arithmetic), not this number")
     if cold_ms is not None:
         result["config"]["cold_ms"] = round(cold_ms / wl.launches_per_step, 4)
     if checked:
@@ -564,12 +576,12 @@ def main():
         vm = valu_model(kernel_ms, args.data)
         if vm:
             result["roofline_valu"] = vm
-        if extras and world == 1 and os.environ.get("IPK_BENCH_NO_LIVE_PMC") != "1":
+        if extras and world == 1 and not args.no_live_traffic and os.environ.get("IPK_BENCH_NO_LIVE_PMC") != "1":
             # measured in THIS run when rocprofv3 is there (it is on the GPU boxes); the committed figure above stays only if the passes fail
             tb, det = live_traffic()
             if tb is not None:
                 result["roofline"]["traffic"] = round(tb)
-                result["roofline"]["traffic_source"] = "measured in this run"
+                result["roofline"]["traffic_source"] = "two child runs of this command under rocprofv3 (5 steps, 1 warm-up, no clock pre-warm), started by this run"
                 result["roofline"]["traffic_detail"] = det
                 result["roofline"]["traffic_over_algorithmic"] = round(tb / alg_bytes, 4)
             else:

@@ -666,6 +666,9 @@ class FusedPlan:
     def probe(self, src: torch.Tensor, out_f32: torch.Tensor, stream=None):
         """ipk_stream_probe: the fused kernel's memory skeleton (loads, OpGoFloat, demosaic, staging, stores) without the point-wise stages;
         out_f32 receives the demosaiced R, G, B as rows*width*3 f32"""
+        # the probe always writes rows*width*3 f32, whatever the plan's out_type: a u8 / u16 buffer from new_output() would be overrun
+        assert out_f32.is_cuda and out_f32.is_contiguous() and out_f32.dtype == torch.float32 and out_f32.numel() >= self.rows * self.width * 3, \
+            "probe() needs a contiguous cuda float32 buffer of at least rows*width*3 elements"
         rc = lib().ipk_stream_probe(self._ref, src.data_ptr(), out_f32.data_ptr(), stream if stream is not None else torch.cuda.current_stream().cuda_stream)
         if rc < 0:
             _lib.check(rc, "ipk_stream_probe")

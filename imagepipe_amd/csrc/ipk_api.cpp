@@ -98,7 +98,9 @@ int cfa_fail(const char *pat) {
   T d##_folded; \
   if (d) { \
     d##_folded = *(d); \
-    if (!fold_cfa_shape(d##_folded)) return fail(IPK_ERR_INVALID, "cfa_width / cfa_height do not fit the pattern string"); \
+    if (!fold_cfa_shape(d##_folded)) \
+      return (d##_folded.cfa_width == 0 && d##_folded.cfa_height == 0) ? fail(IPK_ERR_INVALID, "invalid CFA shape prefix (expected \"WxH:letters\" with W*H letters)") \
+                                                                        : fail(IPK_ERR_INVALID, "cfa_width / cfa_height do not fit the pattern string"); \
     (d) = &d##_folded; \
   }
 template <typename Desc>

@@ -1675,7 +1675,12 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       Bq[g] = cdiv2s(b0 + S2(127.0f), rc_hi(255.0f), rc_lo(255.0f));
       if (!TOLAB_ONLY && has_curve) {
         if (cm == 1) L = F2(spline_interpolate_3a(a.spline, s_knots, L.x), spline_interpolate_3a(a.spline, s_knots, L.y));
-        else if (s_grid != nullptr && (cm == 2 || a.spline.grid_ok)) L = F2(spline_interpolate_grid(a.spline, s_grid, L.x), spline_interpolate_grid(a.spline, s_grid, L.y));
+        else if (s_grid != nullptr && (cm == 2 || a.spline.grid_ok)) {
+          // a NaN argument is the one input on which the grid form and the literal search differ (y_0 against the first probe's knot, curves.rs:144-149):
+          // such a lane is flagged and redone literally, so bit-equality does not rest on L never being NaN in a lane whose result is kept
+          bad |= (L.x != L.x) | (L.y != L.y);
+          L = F2(spline_interpolate_grid(a.spline, s_grid, L.x), spline_interpolate_grid(a.spline, s_grid, L.y));
+        }
         else L = F2(spline_interpolate_sel(a.spline, s_knots, L.x), spline_interpolate_sel(a.spline, s_knots, L.y));
       }
       Lq[g] = L;

@@ -273,8 +273,11 @@ typedef struct {
    * image row band_src_row0 (in cropped coordinates, i.e. row y+band_src_row0 of the sensor), and
    * only output rows [band_out_row0, band_out_row0+band_out_rows) are produced into dst. */
   size_t band_src_row0, band_src_rows, band_out_row0, band_out_rows;
-  /* Fields added after the struct was first published are APPENDED here, never inserted (a caller built against the older layout zero-fills them by
-   * value-initialising the struct, and every earlier field keeps its offset). */
+  /* Fields added after the struct was first published are APPENDED here, never inserted, so every earlier field keeps its offset.  That does NOT make
+   * the library binary-compatible with callers COMPILED against an older header: their object is shorter than this struct and the library would read
+   * the appended fields past its end.  A binding must be rebuilt against the header it loads the library with, and can verify that at start-up with
+   * ipk_abi_sizeof(0) == sizeof(ipk_fused_params) (1: ipk_pipeline_desc; tests/test_rust_binding.py checks the generated Rust layout the same way).  Rebuilt callers that value-initialise
+   * the struct get 0, 0 below, which means "take the shape from the string". */
   int cfa_width, cfa_height;       /* the tile's shape as the caller's CFA object has it (cfa.width / cfa.height, src/ops/demosaic.rs:33); 0, 0 = take
                                       it from the string (a "WxH:" prefix, or the letter count 4 / 36 / 144).  16 letters need one of the two. */
 } ipk_fused_params;

@@ -129,6 +129,7 @@ def test_bench_batch_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 6 and d["scaling"] == "strong" and d["value"] > 0
     assert d["with_gather"]["ipk_f32"]["ok"] and d["with_gather"]["ipk_u8"]["ok"]        # the library's gather; torch's over gloo may refuse device tensors
     assert d["scale"]["compute_only"]["speedup"] > 0 and d["scale"]["all_gather_f32_overlapped"]["ms"] > 0
+    assert d["scale_is_the_claim"] is True and "`scale` object" in d["value_basis"]      # an N > 1 line says which of its numbers carries the multi-GPU claim
 
 
 @pytest.mark.parametrize("cfa,H,W,nproc", [("RGGB", 150, 600, 2), ("GBRG", 301, 258, 3), ("GGRGGBGGBGGRBRGRBGGGBGGRGGRGGBRBGBRG", 180, 300, 4)])

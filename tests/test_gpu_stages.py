@@ -284,6 +284,23 @@ def test_demosaic_run_dispatch(ipa, orc, case):
         assert_bits_equal(out.numpy(), want, "demosaic run 4ch")
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_demosaic_random_filters_odd_sizes_and_scales(ipa, orc, seed):
+    """the fuzz of tests/test_oracle_second_restatement.py on the device: random pattern strings (three and four colours, every tile shape), odd frame sizes,
+    non-integer scales -- OpDemosaic::run at full size and at a random smaller size, against the oracle"""
+    from test_oracle_second_restatement import _random_cfa
+    rng = np.random.default_rng(0x5EC0ED + 100 + seed)
+    pat = _random_cfa(rng)
+    h, w = int(rng.integers(10, 400)), int(rng.integers(10, 600))
+    buf = util.uniform_f32(util.SEED + 3000 + seed, h * w, -0.05, 1.05).reshape(h, w)
+    assert_bits_equal(_demosaic(ipa, pat, buf).numpy(), orc.demosaic_full(pat, buf), "demosaic full %s %dx%d" % (pat, w, h))
+    nh, nw = int(rng.integers(2, max(3, h // 2))), int(rng.integers(2, max(3, w // 2)))
+    branch, want = orc.demosaic_run(pat, buf, nw, nh)
+    out = _demosaic(ipa, pat, buf, nw, nh)
+    assert (out.height, out.width) == want.shape[:2]
+    assert_bits_equal(out.numpy(), want, "demosaic run %s %dx%d -> %dx%d branch %d" % (pat, w, h, nw, nh, branch))
+
+
 # ---------------------------------------------------------------------------------------------
 # rotatecrop (src/ops/rotatecrop.rs:170-270 restated on the GPU + oracle parity)
 # ---------------------------------------------------------------------------------------------

@@ -134,6 +134,35 @@ def test_scaled_demosaic_against_a_second_restatement(orc, pat, h, w, nh, nw):
     util.assert_bits_equal(orc.scaled_demosaic(pat, buf, nw, nh), want, "scaled_demosaic %s" % pat[:4])
 
 
+def _random_cfa(rng):
+    """a random colour filter of a shape rawloader accepts: 2x2, 6x6, 12x12 by length, or a stated WxH tile (2x8, 8x2, 4x4 -- 16 letters); three
+    colours mostly, a fourth sometimes; every colour the draw uses appears at least once"""
+    wide, high, prefix = [(2, 2, ""), (6, 6, ""), (12, 12, ""), (2, 8, "2x8:"), (8, 2, "8x2:"), (4, 4, "4x4:")][int(rng.integers(0, 6))]
+    ncol = 4 if rng.random() < 0.25 else 3
+    letters = [int(v) for v in rng.integers(0, ncol, wide * high)]
+    for c in range(ncol):
+        letters[int(rng.integers(0, wide * high)) if c not in letters else letters.index(c)] = c
+    for c in range(ncol):                                  # the repair above can overwrite a colour's only cell: place the missing ones on distinct cells
+        if c not in letters:
+            cells = [i for i in range(wide * high) if letters.count(letters[i]) > 1]
+            letters[cells[int(rng.integers(0, len(cells)))]] = c
+    return prefix + "".join("RGBE"[c] for c in letters)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_filters_odd_sizes_and_scales_against_a_second_restatement(orc, seed):
+    """fuzz over what the fixed cases leave out: RANDOM pattern strings (not only the shipped filters), odd frame sizes, non-integer scales"""
+    rng = np.random.default_rng(0x5EC0ED + seed)
+    pat = _random_cfa(rng)
+    h, w = int(rng.integers(10, 30)), int(rng.integers(10, 30))
+    buf = util.uniform_f32(util.SEED + 2000 + seed, h * w, -0.05, 1.05).reshape(h, w)
+    buf[int(rng.integers(0, h)), int(rng.integers(0, w))] = np.float32(-0.0)
+    util.assert_bits_equal(orc.demosaic_full(pat, buf), _full(pat, buf), "demosaic::full %s %dx%d" % (pat, w, h))
+    nh, nw = int(rng.integers(2, max(3, h // 2))), int(rng.integers(2, max(3, w // 2)))     # scales between 2 and ~15, rarely whole numbers
+    want = _transform_buffer(buf.ravel(), w, h, (0, 0), (w - 1, 0), (0, h - 1), nw, nh, 4, pat).reshape(nh, nw, 4)
+    util.assert_bits_equal(orc.scaled_demosaic(pat, buf, nw, nh), want, "scaled_demosaic %s %dx%d -> %dx%d" % (pat, w, h, nw, nh))
+
+
 def test_transform_buffer_rotated_against_a_second_restatement(orc):
     """three components, corners of a rotated crop (negative skips, windows clamped at the frame edge)"""
     h, w = 20, 26
