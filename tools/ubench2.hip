@@ -35,6 +35,7 @@ DEF_KERNEL(add,        ALL16("v_add_f32 %0, %0, %1"), 16)
 DEF_KERNEL(fma,        ALL16("v_fma_f32 %0, %0, %1, %1"), 16)
 DEF_KERNEL(fma_3reg,   ND16("v_fma_f32 %0, %1, %2, %2"), 16)
 DEF_KERNEL(fmac,       ALL16("v_fmac_f32 %0, %1, %1"), 16)
+DEF_KERNEL(fmac_lit,   ALL16("v_fmac_f32 %0, 0x3f8ccccd, %1"), 16)
 DEF_KERNEL(fmaak,      ALL16("v_fmaak_f32 %0, %0, %1, 0x3f8ccccd"), 16)
 DEF_KERNEL(fmamk,      ALL16("v_fmamk_f32 %0, %0, 0x3f8ccccd, %1"), 16)
 DEF_KERNEL(min,        ALL16("v_min_f32 %0, %0, %1"), 16)
@@ -159,7 +160,7 @@ struct Entry { const char *name; void (*fn)(float *, float); int nins; };
 #define E(NAME) {#NAME, k_##NAME, n_##NAME}
 
 int main(int argc, char **argv) {
-  std::vector<Entry> es = {E(mul), E(mul_e64), E(mul_nd), E(mul_const), E(mul_inl), E(add), E(fma), E(fma_3reg), E(fmac), E(fmaak), E(fmamk), E(min), E(max),
+  std::vector<Entry> es = {E(mul), E(mul_e64), E(mul_nd), E(mul_const), E(mul_inl), E(add), E(fma), E(fma_3reg), E(fmac), E(fmac_lit), E(fmaak), E(fmamk), E(min), E(max),
                            E(cnd_e32), E(cnd_e64), E(or_b32), E(xor_b32), E(sub_u32), E(lshr), E(lshl), E(lshl_add), E(add3), E(and_or), E(bfe), E(mul_u24), E(mad_u24),
                            E(cvt_u32), E(cvt_i32), E(cvt_f32u), E(fract), E(floor), E(med3), E(cmp), E(cmp_e64), E(mul_legacy), E(subrev), E(mul_neg), E(add_abs), E(mul_clamp), E(pk_mul),
                            E(mix_mul_fma), E(mix_mul_min), E(mix_mul_add), E(mix_fma_min), E(dep_mul), E(dep_fma), E(dep_min), E(mix_min_max), E(mix_min_cvt), E(mix_min_cmp), E(mix_cvt_fra), E(mix_min_lshl), E(mix_cnd_min), E(mix_cmp_cnd), E(mix_cvt_cvtf), E(mix_med_fra), E(seq_mmmn), E(seq_mmnn), E(seq_mncf), E(seq_nnmm_blk), E(seq_fmul), E(seq_real), E(dep_real), E(dep2_real), E(mul_vv), E(add_vv), E(min_vv), E(fma_vvv), E(mul_sgpr), E(fma_sgpr), E(fma_sgpr2),
