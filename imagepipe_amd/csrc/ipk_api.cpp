@@ -695,7 +695,7 @@ int ipk_tolab(const float *src4, size_t width, size_t height, int monochrome, co
     ipk::FusedLaunch f;
     std::memset(&f, 0, sizeof(f));
     f.src = src4; f.dst = dst3; f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33; f.fast_ok = 1; f.has_curve = 0; f.linear = 1;
-    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.num_cus = g.num_cus;
+    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma]; f.num_cus = g.num_cus;
     ipk::launch_tolab_fast(f, width * height, S(stream));
   } else {
     ipk::launch_tolab(src4, width * height, mul, cm, g.lut_pairs[ipk::kLutXyzLab], dst3, g.num_cus, S(stream));
@@ -921,7 +921,7 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.spline = &sp;
   f.linear = p->linear;
   f.out_type = probe ? 4 : p->out_type;
-  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
+  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma];
   f.num_cus = g.num_cus;
   { const int lrc = ipk::launch_fused_bayer(f, S(stream));
     if (lrc == -4) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued; the stream's task queue is untouched)");
@@ -982,7 +982,7 @@ struct PointwisePrep {
     }
     f.spline = &sp;
     f.linear = linear;
-    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma];
+    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma];
     f.num_cus = g.num_cus;
     return IPK_OK;
   }

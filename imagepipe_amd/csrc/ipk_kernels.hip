@@ -78,6 +78,29 @@ __device__ __forceinline__ void fill_lds_tables(LT *__restrict__ s_lab, const fl
   }
 }
 
+// The same copies WITHOUT registers: global_load_lds_dwordx4 (gfx950) writes 16 bytes per lane straight into LDS at M0 + lane * 16, so a 1024-thread block
+// moves a 64 KB pair table with four instructions per thread and a 32 KB plain one with two, and the loads can sit in flight behind whatever the wave
+// does next -- the fused kernel issues them first thing, computes its first task's addresses, issues that task's row loads right behind them and meets the
+// block's other waves at ONE barrier in front of its first table read (round 4: load 24 registers, write them to LDS, barrier, and only then the first
+// row load: two memory round trips per launch where one will do; the form with the row loads ahead of a register-staged fill spilled).
+// The pair image comes from the host (ipk_init builds {v[i], v[i+1] - v[i]} for the staged kernels anyway: the same f32 subtraction).
+typedef const __attribute__((address_space(1))) void *ipk_gptr_t;
+typedef __attribute__((address_space(3))) void *ipk_lptr_t;
+__device__ __forceinline__ void lds_direct_16(const void *g_lane, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((ipk_gptr_t)g_lane, (ipk_lptr_t)lds_wave_base, 16, 0, 0);
+}
+// all 1024 threads; `bytes` a multiple of 16 KB (64 KB pair table, 32 KB = the first 8192 floats of a plain one)
+__device__ __forceinline__ void stage_lds_direct(void *lds, const void *g, uint32_t bytes) {
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  for (uint32_t off = wave * 1024u; off < bytes; off += 16u * 1024u)
+    lds_direct_16(reinterpret_cast<const char *>(g) + off + lane * 16u, reinterpret_cast<char *>(lds) + off);
+}
+__device__ __forceinline__ void stage_table_direct(LutPair *s_tab, const float *, const LutPair *pairs) { stage_lds_direct(s_tab, pairs, kLutPairs * 8u); }
+__device__ __forceinline__ void stage_table_direct(float *s_tab, const float *plain, const LutPair *) {
+  stage_lds_direct(s_tab, plain, kLutPairs * 4u);
+  if (threadIdx.x == 0) s_tab[kLutPairs] = plain[kLutPairs];            // the 8193rd entry: the plain device table ends there
+}
+
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
@@ -685,7 +708,7 @@ constexpr uint32_t kW8CellF4 = 9;
 // C4 = the filter has a fourth colour (RGBE ...): three-colour filters (Bayer, X-Trans) skip its two accumulations per tap -- as a runtime flag they
 // were two fused multiply-adds and two selects per tap, a quarter of the tap's arithmetic.
 template <typename T, uint32_t KU, bool C4>
-// (seven blocks per CU asked for: with the two register sets of the unrolled row loop hipcc otherwise takes 73 VGPRs -- six waves per SIMD, 3 % slower)
+// (seven waves per SIMD asked for: with the two register sets of the unrolled row loop hipcc otherwise takes 73 VGPRs -- six waves per SIMD, 3 % slower)
 __global__ __launch_bounds__(256, 7) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
                                                                 uint32_t pw, uint32_t ph, float *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
@@ -1296,6 +1319,7 @@ struct FusedArgs {
   uint32_t lc_base, lc_rem;   // lane-columns per strip: base (+1 for the first lc_rem strips)
   const float *lab_table;
   const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
+  const LutPair *lab_pairs, *gam_pairs;   // the two tables as 8192 {v, dv} pairs (the LDS image of the pair form)
   const float *gen_cells;     // generic-CFA mode: gen_pw*gen_ph cells of 36 floats (ipk_host.hpp Cfa::gen_cells), else null
   uint32_t gen_pw, gen_ph;    // pattern width / height (both divide 48)
   int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not show that every normalised sample is ordinary
@@ -1970,15 +1994,17 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // (the generic-CFA variants also hold their cell records in LDS and keep both tables plain)
   typedef typename std::conditional<GEN, float, LabTab>::type LabT;
   typedef typename std::conditional<GEN || OUTS == 0, float, GamTab>::type GamT;   // f32 output: 48 KB of staging, no room for two pair tables
-  __shared__ LabT s_lab[DEMO ? 4 : kLutPairs + 4];
-  __shared__ GamT s_gam[DEMO ? 4 : kLutPairs + 4];
+  __shared__ __attribute__((aligned(16))) LabT s_lab[DEMO ? 4 : kLutPairs + 4];
+  __shared__ __attribute__((aligned(16))) GamT s_gam[DEMO ? 4 : kLutPairs + 4];
+  // the two tables go straight into LDS (no registers, see stage_lds_direct) and are in flight from here to the block's one barrier, which every wave
+  // reaches in front of its first row's table reads (arrive() below)
+  if (!DEMO) { stage_table_direct(s_lab, a.lab_table, a.lab_pairs); stage_table_direct(s_gam, a.gam_table, a.gam_pairs); }
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];   // base-curve knots + the 3-knot form's segment records
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
   __shared__ __attribute__((aligned(16))) float s_cells[GEN ? kGenMaxCells * kGenCellFloats : 4];   // generic-CFA cell records
   if (GEN) for (uint32_t i = threadIdx.x; i < a.gen_pw * a.gen_ph * kGenCellFloats; i += blockDim.x) s_cells[i] = a.gen_cells[i];
   constexpr int STG = DEMO ? 1024 : (OUTS == 0 ? 768 : (OUTS == 1 ? 192 : 384));   // dwords of staging per wave: one output row segment
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[FULL ? 16 * STG : 4];
-  if (!DEMO) fill_lds_tables(s_lab, a.lab_table, s_gam, a.gam_table);
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
@@ -1991,8 +2017,13 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // row its task ends in front of; high word: serial << 22 | frame << 16 | strip -- and the row it is at
   __shared__ unsigned long long s_tdesc[16];
   __shared__ uint32_t s_tcur[16];
-  if (threadIdx.x < 16) { s_tdesc[threadIdx.x] = 0ull; s_tcur[threadIdx.x] = 0u; }
-  __syncthreads();
+  // every wave clears its OWN slot (one wave's LDS operations run in order, so its first publication below cannot be overtaken by the clearing; other
+  // waves look at the slot only behind the barrier)
+  if ((threadIdx.x & 63u) == 0) { s_tdesc[threadIdx.x >> 6] = 0ull; s_tcur[threadIdx.x >> 6] = 0u; }
+  // THE block barrier: tables, parameters, curve and cell records are in LDS behind it.  Every wave passes it exactly once -- in front of its first
+  // row, with that row's loads already in flight, or on its way out when it has no row to do.
+  bool arrived = false;
+  auto arrive = [&]() { if (!arrived) { __syncthreads(); arrived = true; } };
 
   const uint32_t lane = threadIdx.x & 63u;
   // (making the task index wave-uniform with readfirstlane moves the row/address arithmetic to the scalar unit: measured, no change)
@@ -2104,6 +2135,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       r0 = a.out_r0 + (uint32_t)(((uint64_t)seg * nrows) / a.n_segs);
       r1 = a.out_r0 + (uint32_t)(((uint64_t)(seg + 1) * nrows) / a.n_segs);
     } else {
+      arrive();
       if (!steal_on) break;
       if (lane == 0) __hip_atomic_store(&s_tdesc[wslot], (unsigned long long)(++tserial & 0x3FFu) << 54, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // nothing left here
       if (__builtin_amdgcn_readfirstlane(take_over(frame, strip, r0, r1) ? 1 : 0) == 0) break;
@@ -2135,7 +2167,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // for all 65 536 values
     // (a compile-time false for the Bayer variants, so that they carry no trace of it)
     const bool gen_guard = GEN && (sizeof(SrcT) == 4 || DEMO || a.gen_check != 0);
-    if (r0 >= r1) continue;
+    if (r0 >= r1) { arrive(); continue; }
     if (steal_on && lane == 0) {
       // this wave's task, for takers.  Takers read the descriptor first and the row second, and swap only against the descriptor they read; so the old
       // descriptor is withdrawn BEFORE the new task's row is published (one wave's LDS operations run in order): a taker that still holds the old
@@ -2245,6 +2277,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       raw_next = issue_row(min(r0 + 2, Hm1));
       P = finish_row(rp, fP); C = finish_row(rc, fC); N = finish_row(rn, fN);
     }
+    arrive();
     uint32_t ry = GEN ? r0 % a.gen_ph : 0u;                // pattern row of image row r
     // The prefetch is unconditional (row index clamped to the frame): a branch around a load makes the compiler's
     // s_waitcnt bookkeeping assume the shortest path and wait for the previous iteration's stores as well.
@@ -2413,6 +2446,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       if (steal_on) r1d = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_now);
     }
   }
+  arrive();
   // the last wave to leave zeroes the queue for the stream's next launch (every other wave's draws have returned before it arrived here)
   if (queued && (threadIdx.x & 63u) == 0) {
     uint32_t *const arrived = a.task_ctr + kQueueStride;
@@ -2643,6 +2677,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   }
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
+  a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs); a.gam_pairs = reinterpret_cast<const LutPair *>(f.gam_pairs);
   a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check; a.px_guard = f.px_guard;
   a.ori = f.ori;
   for (int i = 0; i < 4; ++i) a.roles[i] = f.roles[i];
@@ -2727,24 +2762,29 @@ template <bool TOLAB_ONLY>
 __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_t npix) {
   constexpr int NP = TOLAB_ONLY ? 1 : 2, PPL = 2 * NP;                  // pixel pairs / pixels per lane
   constexpr uint64_t CH = 64u * PPL;                                   // pixels per wave step
-  __shared__ LabTab s_lab[kLutPairs + 4];
-  __shared__ GamTab s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
+  __shared__ __attribute__((aligned(16))) LabTab s_lab[kLutPairs + 4];
+  __shared__ __attribute__((aligned(16))) GamTab s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
-  fill_lds_tables(s_lab, a.lab_table, s_gam, a.gam_table, !TOLAB_ONLY);
+  // the tables go straight into LDS (stage_lds_direct: no registers; 1024-thread blocks) and stay in flight while the wave loads its first pixels: the
+  // block's barrier sits behind those loads, so a block pays ONE memory round trip before its first pixel instead of two (sixteen blocks per CU slot)
+  stage_table_direct(s_lab, a.lab_table, a.lab_pairs);
+  if (!TOLAB_ONLY) stage_table_direct(s_gam, a.gam_table, a.gam_pairs);
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
   else if (threadIdx.x < 25) s_par[threadIdx.x] = a.rgbm.m[threadIdx.x - 16];
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
   __shared__ __attribute__((aligned(16))) float s_grid[TOLAB_ONLY ? 4 : kGridFloats];
   if (!TOLAB_ONLY && a.spline.grid_ok) fill_grid(s_grid, a.spline, (int)threadIdx.x);
-  __syncthreads();
+  bool arrived = false;
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const uint64_t nchunks = (npix + CH - 1) / CH;
   const float4 *src = reinterpret_cast<const float4 *>(a.src);
   f3 *dst = reinterpret_cast<f3 *>(a.dst);
+  // (round 5: the next chunk's pixels loaded during this one's arithmetic need 71 registers; held to the 64 that two resident blocks allow, the
+  // spills double the kernel's time, 477 -> 882 us)
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t base = chunk * CH + lane;
     float4 px[PPL];
@@ -2753,6 +2793,7 @@ __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_
       const uint64_t i = base + 64u * j;
       px[j] = ld_stream4(reinterpret_cast<const float *>(src + (i < npix ? i : npix - 1)));   // clamped, unpredicated: the tail lanes recompute the last pixel
     }
+    if (!arrived) { __syncthreads(); arrived = true; }                  // the block's one barrier, behind the first chunk's loads
     PixOut o[PPL];
     // the fast form drops the E term (e * cm[i][3]): legal while the fourth channel is +0.0, as every producer on this
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
@@ -2778,9 +2819,13 @@ __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_
       if (i < npix) { float *po = reinterpret_cast<float *>(dst + i); st_stream(po, o[j].r); st_stream(po + 1, o[j].g); st_stream(po + 2, o[j].b); }
     }
   }
+  if (!arrived) __syncthreads();                                        // a wave without a chunk
 }
 template <bool TOLAB_ONLY>
 __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) { pointwise_chain_body<TOLAB_ONLY>(a, npix); }
+// OpToLab alone: two resident blocks per CU (eight waves per SIMD) are the point of its two-pixel form, so the register budget is stated (64)
+template <>
+__global__ __launch_bounds__(1024, 8) void k_pointwise_chain<true>(FusedArgs a, uint64_t npix) { pointwise_chain_body<true>(a, npix); }
 static FusedArgs chain_args(const FusedLaunch &f) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -2792,6 +2837,7 @@ static FusedArgs chain_args(const FusedLaunch &f) {
   if (f.has_curve) a.spline = make_spline(*f.spline); else { a.spline.npoints = 0; a.spline.nseg = 0; }
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
+  a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs); a.gam_pairs = reinterpret_cast<const LutPair *>(f.gam_pairs);
   return a;
 }
 int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {

@@ -74,6 +74,7 @@ struct FusedLaunch {
   const SplineHost *spline;
   int out_type;                  // 0 f32, 1 u8, 2 u16
   const void *lab_table, *gam_table;   // plain 8193-float tables (XYZ_LAB_TRANSFORM, SRGB gamma)
+  const void *lab_pairs, *gam_pairs;   // the same two as 8192 x {v[i], v[i+1] - v[i]} (built at ipk_init): the LDS image of the pair form, copied without registers
   int px_guard;                  // 0: u16 source whose levels and parameters the host found ordinary (kernel variant without per-pixel input guards)
   const float *gen_cells; int gen_pw, gen_ph, gen_check;   // generic-CFA mode (device cell records) or null: RGGB phase (xoff, yoff)
   int num_cus;
