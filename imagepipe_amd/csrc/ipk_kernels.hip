@@ -1622,6 +1622,9 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     const float4 &pa = px[2 * g], &pb = px[2 * g + 1];
     if (PXG) bad |= !(fminf(fminf(pa.x, pa.y), pa.z) >= -0x1p40f) | !(fminf(fminf(pb.x, pb.y), pb.z) >= -0x1p40f);
     const f2 r = min2(F2(pa.x, pb.x) * S2(par0[0]), 1.0f);
+    // (round 5, again: the common-parameter variants without green's `* 1.0` and `.min(1.0)` -- the multiplier is exactly 1.0 after normalize_wbs and a
+    // demosaiced green is at most 1.0 and never NaN -- two instructions per pixel: the f32 variants go to 128 VGPRs + 1-2 spills whether the values are
+    // passed plainly or through an empty asm, time +-1 %; the u16 -> u8 variant keeps its registers: 0.4250 -> 0.4214 ms.  Not kept.)
     const f2 gc = min2(F2(pa.y, pb.y) * S2(par0[1]), 1.0f);
     const f2 b = min2(F2(pa.z, pb.z) * S2(par0[2]), 1.0f);
     const f2 x = r * S2(par0[4]) + gc * S2(par0[5]) + b * S2(par0[6]);
@@ -2292,24 +2295,12 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // One row: demosaic + point-wise stages + store of row r from the window (P, C, N) = rows r-1, r, r+1; then row r+2 is finished INTO P's
     // registers (P is dead by then) and row r+3 issued.  The caller passes the three windows in rotating roles -- (P, C, N), (C, N, P), (N, P, C) --
     // so the window never moves between registers (IPK_OPT_UNROLL3; the rolling form copies 18 registers per row).
-    auto row_step = [&](RowWin &P, RowWin &C, RowWin &N, bool &fP, bool &fC, bool &fN, const uint32_t r) {
-      // The four waves of a SIMD are served oldest first: left alone, the same 23 rows take one wave 83 us and another 164 (24 MP frame, one task per
-      // wave, tools/wave_timeline.py) and the launch ends on a quarter of its waves.  Where nothing is drawn from a queue a wave's issue priority
-      // therefore falls as it advances through its task, row by row in a cycle of four: whichever of a SIMD's waves is a row behind outranks the
-      // others until it has caught up (lifetimes 121-165 us, 24 MP frame 0.141 -> 0.133 ms).  With a queue the unevenness is harmless -- the fast
-      // waves simply draw more tasks -- and waves in step with each other wait for their table reads and stores at the same time: 100 MP frame
-      // 0.519 -> 0.542 ms with the priorities on, so they stay off there.
-      if (!queued) switch ((r - r0) & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(3); break;
-        case 1: __builtin_amdgcn_s_setprio(2); break;
-        case 2: __builtin_amdgcn_s_setprio(1); break;
-        default: __builtin_amdgcn_s_setprio(0); break;
-      }
+    // demosaic::full for the lane's four pixels of row r from the window (P, C, N) = rows r-1, r, r+1 (frame-edge pixels included)
+    auto compute_px = [&](const RowWin &P, const RowWin &C, const RowWin &N, const bool fP, const bool fC, const bool fN, const uint32_t r, float4 px[4]) {
       const int pr = (int)((r + (uint32_t)a.yoff) & 1u);
       const float pw[6] = {P.l, P.v0, P.v1, P.v2, P.v3, P.r};
       const float cw[6] = {C.l, C.v0, C.v1, C.v2, C.v3, C.r};
       const float nw[6] = {N.l, N.v0, N.v1, N.v2, N.v3, N.r};
-      float4 px[4];
       // interior formulas; role = (row parity, column parity) in the RGGB tile; the column parity of pixel j is
       // (j + xo) & 1 with a per-strip xo: wave-uniform branches only.
       const float *rowcells = s_cells + ry * a.gen_pw * kGenCellFloats;
@@ -2378,6 +2369,22 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
           }
         }
       }
+    };
+    auto row_step = [&](RowWin &P, RowWin &C, RowWin &N, bool &fP, bool &fC, bool &fN, const uint32_t r) {
+      // The four waves of a SIMD are served oldest first: left alone, the same 23 rows take one wave 83 us and another 164 (24 MP frame, one task per
+      // wave, tools/wave_timeline.py) and the launch ends on a quarter of its waves.  Where nothing is drawn from a queue a wave's issue priority
+      // therefore falls as it advances through its task, row by row in a cycle of four: whichever of a SIMD's waves is a row behind outranks the
+      // others until it has caught up (lifetimes 121-165 us, 24 MP frame 0.141 -> 0.133 ms).  With a queue the unevenness is harmless -- the fast
+      // waves simply draw more tasks -- and waves in step with each other wait for their table reads and stores at the same time: 100 MP frame
+      // 0.519 -> 0.542 ms with the priorities on, so they stay off there.
+      if (!queued) switch ((r - r0) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+      }
+      float4 px[4];
+      compute_px(P, C, N, fP, fC, fN, r, px);
       if (DEMO) {
         bool fNN;
         const RowWin NN = finish_row(raw_next, fNN);       // row r+2 (clamped past the frame: those rows are masked as edges)
@@ -2435,6 +2442,10 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
       P = NN; fP = fNN;
       if (GEN) ry = (ry + 1 == a.gen_ph) ? 0u : ry + 1;
     };
+    // (Round 5, the staged demosaic -- OUT == 3 -- with TWO rows per round trip: a four-row window, the two rows behind it in flight together, both rows'
+    // eight stores behind one wait for loads (gfx9 counts loads and stores in one vmcnt, so a wave otherwise has one row of stores in flight): 365.5 / 367.0
+    // -> 364.4 / 364.1 us at 100 MP on one box, nothing; the same kernel measured 406 us on another box the same day -- these memory-bound kernels move
+    // by 10 % from box to box, not with their row loop.)
     for (uint32_t r = r0, r1d = r1; r < r1d; ++r) {
       uint32_t e_now = r1;
       if (steal_on) {                                       // where this wave is, and where its task ends by now (asked for here, looked at behind the row)

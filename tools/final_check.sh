@@ -5,5 +5,5 @@ mkdir -p gpurun_out/final
 ( time python -m pytest tests -m gpu -q ) > gpurun_out/final/pytest.log 2>&1
 tail -4 gpurun_out/final/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-bash tools/evidence.sh r04 > gpurun_out/final/evidence.log 2>&1
+bash tools/evidence.sh r05 > gpurun_out/final/evidence.log 2>&1
 tail -3 gpurun_out/final/evidence.log

@@ -3,7 +3,7 @@
 # clean-up left the generated code untouched (diff two outputs).  usage: tools/isa_hash.sh [object]
 O=${1:-$(dirname "$0")/../imagepipe_amd/csrc/build/ipk_kernels.o}
 T=$(mktemp -d); L=/opt/rocm/lib/llvm/bin
-$L/llvm-objcopy --dump-section .hip_fatbin=$T/fat.bin "$O" 2>/dev/null
+cp "$O" $T/in.o; $L/llvm-objcopy --dump-section .hip_fatbin=$T/fat.bin $T/in.o $T/out.o 2>/dev/null
 $L/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fat.bin --output=$T/k.co --unbundle
 $L/llvm-objdump -d --no-show-raw-insn --no-leading-addr $T/k.co | python3 -c '
 import sys, re, hashlib, subprocess

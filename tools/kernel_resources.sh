@@ -4,7 +4,8 @@
 O=${1:-$(dirname "$0")/../imagepipe_amd/csrc/build/ipk_kernels.o}
 PAT=${2:-.}
 T=$(mktemp -d); L=/opt/rocm/lib/llvm/bin
-$L/llvm-objcopy --dump-section .hip_fatbin=$T/fat.bin "$O" 2>/dev/null
+cp "$O" $T/in.o   # (objcopy without an output file rewrites its input and bumps the mtime make looks at)
+$L/llvm-objcopy --dump-section .hip_fatbin=$T/fat.bin $T/in.o $T/out.o 2>/dev/null
 $L/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fat.bin --output=$T/k.co --unbundle
 $L/llvm-readelf --notes $T/k.co | python3 -c '
 import sys, re, subprocess
