@@ -23,9 +23,6 @@ using namespace ipkd;
 // Wave-uniform tests of rare paths are marked unlikely, so that their code is laid out behind the loop and the common path runs through not-taken
 // branches (a taken branch makes the wave refetch its instruction buffer).
 #define IPK_RARE(x) __builtin_expect(!!(x), 0)
-#ifndef IPK_EXP_HALVES
-#define IPK_EXP_HALVES 0
-#endif
 constexpr uint32_t kSpread = 4;        // static schedule: a block's waves start on groups of kSpread neighbouring tasks a round of blocks apart (fused_bayer_body)
 constexpr uint32_t kMinTaskRows = 4;   // one task per wave: at least this many rows each (fused_task_grid)
 constexpr uint32_t kStealMin = 4;      // a takeover needs at least this many rows left behind the owner's current one
@@ -2738,11 +2735,6 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   (void)task_counters_for(s, a, queue_lock);
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks);
-#if IPK_EXP_HALVES
-  // experiment: the one-task-per-wave schedule with every segment cut in IPK_EXP_HALVES, walked statically (wave i takes tasks i, i + n_waves, ...): a
-  // wave's pieces lie a fraction of the frame apart, so a blown region spreads over that many times as many waves, at one more priming per piece
-  if (a.n_strips * a.n_segs <= 256u * 16u && (a.out_r1 - a.out_r0) / a.n_segs >= 40u) { a.n_segs *= IPK_EXP_HALVES; a.task_ctr = nullptr; }
-#endif
   if (f.out_type == 4) {                                  // ipk_stream_probe: the skeleton of the headline variants (Bayer phase, full strips, no guards)
     if (a.gen_cells || a.ori != 0 || a.W < 256u || a.exact_norm || std::fabs(a.min0) < 0x1p-70f || std::fabs(a.min0) > 0x1p70f) return -2;
     if (!f.src_is_u16) hipLaunchKernelGGL((k_fused_bayer<float, true, 4, true, false, false, true>), dim3(blocks), dim3(1024), 0, s, a);
