@@ -95,8 +95,13 @@ __device__ __forceinline__ void stage_lds_direct(void *lds, const void *g, uint3
   for (uint32_t off = wave * 1024u; off < bytes; off += 16u * 1024u)
     lds_direct_16(reinterpret_cast<const char *>(g) + off + lane * 16u, reinterpret_cast<char *>(lds) + off);
 }
-__device__ __forceinline__ void stage_table_direct(LutPair *s_tab, const float *, const LutPair *pairs) { stage_lds_direct(s_tab, pairs, kLutPairs * 8u); }
+// (any other block size: the register-staged loop -- no launcher uses one, but a table silently left half-filled would be the worst kind of failure)
+__device__ __forceinline__ void stage_table_direct(LutPair *s_tab, const float *plain, const LutPair *pairs) {
+  if (blockDim.x == 1024) stage_lds_direct(s_tab, pairs, kLutPairs * 8u);
+  else fill_lds_table_any(s_tab, plain);
+}
 __device__ __forceinline__ void stage_table_direct(float *s_tab, const float *plain, const LutPair *) {
+  if (blockDim.x != 1024) { fill_lds_table_any(s_tab, plain); return; }
   stage_lds_direct(s_tab, plain, kLutPairs * 4u);
   if (threadIdx.x == 0) s_tab[kLutPairs] = plain[kLutPairs];            // the 8193rd entry: the plain device table ends there
 }
@@ -714,13 +719,14 @@ __global__ __launch_bounds__(256, 7) void k_raw_scaled_demosaic_w8m(const T *__r
   extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
   // one (cell, column) pair per thread and step: a block lives for two or three output rows, and eight dependent byte loads per cell in front of its
   // barrier were a sixth of its life
-  // (no division either: thread t takes column k = t & 7 of pattern cell x = (t >> 3) & 15 in the rows t >> 7, t >> 7 + 2, ...; pw <= 12 by the launcher's
-  // pw * ph <= kW8MaxCells with pw, ph dividing 48, and x + k < 48 needs no wrap)
+  // (no division either: thread t takes column k = t & 7 of the pattern cells x = (t >> 3) & 15, + 16, ... in the rows t >> 7, t >> 7 + 2, ...; tiles up to
+  // 48 wide are legal -- "24x2:", "48x1:" -- so x walks on and x + k wraps at the 48-column period of cfa48)
   {
-    const uint32_t k = threadIdx.x & 7u, x = (threadIdx.x >> 3) & 15u;
-    if (x < pw)
-      for (uint32_t y = threadIdx.x >> 7; y < ph; y += blockDim.x >> 7) {
-        const uint32_t c = cfa48[y * 48 + x + k] & 3u;
+    const uint32_t k = threadIdx.x & 7u;
+    for (uint32_t y = threadIdx.x >> 7; y < ph; y += blockDim.x >> 7)
+      for (uint32_t x = (threadIdx.x >> 3) & 15u; x < pw; x += 16u) {
+        const uint32_t xk = x + k;
+        const uint32_t c = cfa48[y * 48 + (xk >= 48u ? xk - 48u : xk)] & 3u;
         reinterpret_cast<float4 *>(s_m)[(y * pw + x) * kW8CellF4 + k] = make_float4(c == 0u ? 1.0f : 0.0f, c == 1u ? 1.0f : 0.0f, c == 2u ? 1.0f : 0.0f, c == 3u ? 1.0f : 0.0f);
       }
   }

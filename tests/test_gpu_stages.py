@@ -284,7 +284,25 @@ def test_demosaic_run_dispatch(ipa, orc, case):
         assert_bits_equal(out.numpy(), want, "demosaic run 4ch")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("shape", [(24, 2), (48, 1), (16, 3), (16, 8), (3, 16), (1, 48), (12, 4)])
+@pytest.mark.parametrize("size", [((96, 200), (24, 50)), ((90, 170), (33, 62)), ((120, 300), (20, 50))])
+def test_scaled_demosaic_wide_and_tall_tiles(ipa, orc, shape, size):
+    """tiles wider than 16 columns or taller than 12 rows through the one-hot-weights kernel (scales 4, 2.7 and 6: windows of at most 8 x 8, pw * ph <= 144):
+    its table fill walks the tile 16 columns at a time and wraps at cfa48's 48-column period"""
+    wide, high = shape
+    (h, w), (nh, nw) = size
+    rng = np.random.default_rng(1234 + 100 * wide + high)
+    letters = [int(v) for v in rng.integers(0, 3, wide * high)]
+    letters[:3] = [0, 1, 2]
+    pat = "%dx%d:%s" % (wide, high, "".join("RGB"[c] for c in letters))
+    buf = util.uniform_f32(util.SEED + 4000 + wide, h * w, -0.05, 1.05).reshape(h, w)
+    branch, want = orc.demosaic_run(pat, buf, nw, nh)
+    assert branch == (4 if wide == 12 else 2)            # scaled_demosaic; a 12-wide tile has minscale 12 (demosaic.rs:37): full + scale_down_opbuf
+    out = _demosaic(ipa, pat, buf, nw, nh)
+    assert_bits_equal(out.numpy(), want, "scaled demosaic %s %dx%d -> %dx%d" % (pat[:6], w, h, nw, nh))
+
+
+@pytest.mark.parametrize("seed", range(40))
 def test_demosaic_random_filters_odd_sizes_and_scales(ipa, orc, seed):
     """the fuzz of tests/test_oracle_second_restatement.py on the device: random pattern strings (three and four colours, every tile shape), odd frame sizes,
     non-integer scales -- OpDemosaic::run at full size and at a random smaller size, against the oracle"""

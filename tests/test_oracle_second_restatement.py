@@ -135,9 +135,11 @@ def test_scaled_demosaic_against_a_second_restatement(orc, pat, h, w, nh, nw):
 
 
 def _random_cfa(rng):
-    """a random colour filter of a shape rawloader accepts: 2x2, 6x6, 12x12 by length, or a stated WxH tile (2x8, 8x2, 4x4 -- 16 letters); three
+    """a random colour filter: 2x2, 6x6, 12x12 by length, or a stated WxH tile with W and H dividing 48 (16 letters and more); three
     colours mostly, a fourth sometimes; every colour the draw uses appears at least once"""
-    wide, high, prefix = [(2, 2, ""), (6, 6, ""), (12, 12, ""), (2, 8, "2x8:"), (8, 2, "8x2:"), (4, 4, "4x4:")][int(rng.integers(0, 6))]
+    shapes = [(2, 2, ""), (6, 6, ""), (12, 12, ""), (2, 8, "2x8:"), (8, 2, "8x2:"), (4, 4, "4x4:"),
+              (24, 2, "24x2:"), (16, 3, "16x3:"), (48, 1, "48x1:"), (3, 16, "3x16:"), (1, 48, "1x48:"), (12, 4, "12x4:")]    # wide and tall tiles too
+    wide, high, prefix = shapes[int(rng.integers(0, len(shapes)))]
     ncol = 4 if rng.random() < 0.25 else 3
     letters = [int(v) for v in rng.integers(0, ncol, wide * high)]
     for c in range(ncol):
@@ -149,7 +151,7 @@ def _random_cfa(rng):
     return prefix + "".join("RGBE"[c] for c in letters)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_filters_odd_sizes_and_scales_against_a_second_restatement(orc, seed):
     """fuzz over what the fixed cases leave out: RANDOM pattern strings (not only the shipped filters), odd frame sizes, non-integer scales"""
     rng = np.random.default_rng(0x5EC0ED + seed)
