@@ -19,6 +19,7 @@
 //!   ref/<name>.scaled.f32     scaling::scaled_demosaic to the case's demosaic size (only when it is smaller than the frame)
 //!   ref/<name>.cfa48.u8       CFA::new(cfa).color_at(row, col) for row, col in 0..48 (what demosaic.rs:77-90 and scaling.rs:110 index)
 //!   ref/<name>.cfa.dims       "width height" of the CFA as rawloader parsed the string
+//!   ref/pointwise.*.f32/u8/u16  camera_to_lab, xyz_to_lab, lab_to_xyz, lab_to_rgb, apply / expand_srgb_gamma, two splines, output8bit / 16bit on pin/pointwise.*
 //! and, only with `RUSTFLAGS="--cfg ipk_rawimage"` (needs rawloader 0.37's `RawImage` field list, see `raw_image` below):
 //!   ref/<name>.gofloat.f32    OpGoFloat::run on <name>.raw.u16 (1 channel)
 
@@ -121,6 +122,68 @@ fn ipk_dump_demosaic_goldens() {
     }
     println!("ipk_dump: {} -> {}x{}x{}", c.name, res.width, res.height, res.colors);
   }
+}
+
+// The point-wise functions: the reference's own tests pin them through ROUND TRIPS (gamma and Lab there and back), which a table of another length or
+// another interpolation would pass as well.  Here their one-way outputs are written for 4096 pixels: camera_to_lab, xyz_to_lab, lab_to_xyz, lab_to_rgb,
+// apply / expand_srgb_gamma on the clamped channel (what OpGamma and run_other call), SplineFunc::interpolate for two curves, output8bit / output16bit.
+// (XYZ_LAB_TRANSFORM calls the platform's cbrtf for ratios above 1: a libm other than glibc 2.35 may differ there in the last place -- the Python
+// side reports such pixels separately.)
+#[test]
+fn ipk_dump_pointwise_goldens() {
+  let dir = golden_dir();
+  let out = dir.join("ref");
+  fs::create_dir_all(&out).unwrap();
+  let px = read_f32(&dir.join("pin/pointwise.rgbe.f32"));
+  let par = read_f32(&dir.join("pin/pointwise.params.f32"));
+  let cur = read_f32(&dir.join("pin/pointwise.curves.f32"));
+  assert_eq!(px.len() % 4, 0);
+  assert_eq!(par.len(), 16);
+  assert_eq!(cur.len(), 10);
+  let mul = [par[0], par[1], par[2], par[3]];
+  let cm = [[par[4], par[5], par[6], par[7]], [par[8], par[9], par[10], par[11]], [par[12], par[13], par[14], par[15]]];
+  let n = px.len() / 4;
+  let (mut lab, mut xyzlab, mut labxyz, mut rgb, mut gam, mut exp) = (vec![], vec![], vec![], vec![], vec![], vec![]);
+  let (mut o8, mut o16) = (Vec::<u8>::new(), Vec::<u8>::new());
+  for i in 0..n {
+    let p = &px[4 * i..4 * i + 4];
+    let (l, a, b) = camera_to_lab(mul, cm, p);
+    lab.extend_from_slice(&[l, a, b]);
+    let (l2, a2, b2) = xyz_to_lab(p[0], p[1], p[2]);
+    xyzlab.extend_from_slice(&[l2, a2, b2]);
+    let (x, y, z) = lab_to_xyz(l2, a2, b2);
+    labxyz.extend_from_slice(&[x, y, z]);
+    let (r, g, bb) = lab_to_rgb(*XYZ_D65_33, &[l, a, b]);
+    rgb.extend_from_slice(&[r, g, bb]);
+    for c in 0..3 {
+      let v = p[c].max(0.0).min(1.0);
+      gam.push(apply_srgb_gamma(v));
+      exp.push(expand_srgb_gamma(v));
+      o8.push(output8bit(p[c]));
+      o16.extend_from_slice(&output16bit(p[c]).to_le_bytes());
+    }
+  }
+  write_f32(&out.join("pointwise.camera_to_lab.f32"), &lab);
+  write_f32(&out.join("pointwise.xyz_to_lab.f32"), &xyzlab);
+  write_f32(&out.join("pointwise.lab_to_xyz.f32"), &labxyz);
+  write_f32(&out.join("pointwise.lab_to_rgb.f32"), &rgb);
+  write_f32(&out.join("pointwise.apply_srgb_gamma.f32"), &gam);
+  write_f32(&out.join("pointwise.expand_srgb_gamma.f32"), &exp);
+  fs::write(out.join("pointwise.output8bit.u8"), &o8).unwrap();
+  fs::write(out.join("pointwise.output16bit.u16"), &o16).unwrap();
+  // curves: one user point, then four (SplineFunc::new adds the ends), evaluated on every input channel value
+  let c3 = crate::ops::curves::SplineFunc::new(&[(cur[0], cur[1])]);
+  let c6 = crate::ops::curves::SplineFunc::new(&[(cur[2], cur[3]), (cur[4], cur[5]), (cur[6], cur[7]), (cur[8], cur[9])]);
+  let (mut s3, mut s6) = (vec![], vec![]);
+  for i in 0..n {
+    for c in 0..3 {
+      s3.push(c3.interpolate(px[4 * i + c]));
+      s6.push(c6.interpolate(px[4 * i + c]));
+    }
+  }
+  write_f32(&out.join("pointwise.spline3.f32"), &s3);
+  write_f32(&out.join("pointwise.spline6.f32"), &s6);
+  println!("ipk_dump: pointwise, {} pixels", n);
 }
 
 // OpGoFloat::run_raw is private and reads a rawloader::RawImage.  The literal below lists RawImage's fields as of rawloader 0.37 (decoders/image.rs); if

@@ -8,6 +8,7 @@ and the HIP path with them).  Inputs only -- nothing here comes from the oracle.
 
 cases.txt, one case per line:  name cfa width height black white demosaic_width demosaic_height
   <name>.raw.u16      height x width sensor values, row-major
+  pointwise.rgbe.f32 / .params.f32 / .curves.f32   inputs of the point-wise functions (see main)
   <name>.mosaic.f32   the same frame as OpGoFloat's CFA branch must produce it -- stored as the INPUT of the demosaic step, computed here in numpy
                       with the reference's own expression ((v - black) / (white - black)).min(1.0) in f32, so that the demosaic pin does not hang on the
                       gofloat pin
@@ -40,6 +41,11 @@ CASES = {
 }
 
 
+POINTWISE_N = 4096
+POINTWISE_MUL = (2.0, 1.0, 1.5, 1.0)                      # normalize_wbs of the synthetic camera's coefficients
+POINTWISE_CURVES = ([(0.5, 0.6)], [(0.1, 0.05), (0.3, 0.35), (0.6, 0.7), (0.9, 0.85)])      # SplineFunc::new adds the (0, 0) / (1, 1) ends
+
+
 def main():
     out = os.path.join(HERE, "pin")
     os.makedirs(out, exist_ok=True)
@@ -52,6 +58,17 @@ def main():
         mosaic.astype("<f4").tofile(os.path.join(out, name + ".mosaic.f32"))
         lines.append("%s %s %d %d %d %d %d %d" % (name, cfa, w, h, int(util.BLACK), int(util.WHITE), dw, dh))
     open(os.path.join(out, "cases.txt"), "w").write("\n".join(lines) + "\n")
+    # the point-wise functions (color_conversions.rs, curves.rs): the reference's own tests pin them through round trips only, which a table of another
+    # length or another interpolation would pass too.  4096 RGBE pixels (E = 0) over [-0.05, 1.2] with the special values in front; the multipliers and
+    # the camera matrix the Rust side passes to camera_to_lab; a three-knot and a six-knot curve.
+    px = util.uniform_f32(util.SEED + 400, POINTWISE_N * 4, -0.05, 1.2).reshape(POINTWISE_N, 4)
+    sp = util.SPECIALS[np.isfinite(util.SPECIALS) & (np.abs(util.SPECIALS) < 1e20)]
+    px[: sp.size, 0] = sp; px[: sp.size, 1] = sp[::-1]; px[: sp.size, 2] = np.roll(sp, 7)
+    px[:, 3] = 0.0
+    px.astype("<f4").tofile(os.path.join(out, "pointwise.rgbe.f32"))
+    params = np.concatenate([np.array(POINTWISE_MUL, np.float32), util.cam_matrix().ravel()]).astype("<f4")       # mul[4], cmatrix[3][4]
+    params.tofile(os.path.join(out, "pointwise.params.f32"))
+    np.array(POINTWISE_CURVES[0] + POINTWISE_CURVES[1], np.float32).astype("<f4").tofile(os.path.join(out, "pointwise.curves.f32"))   # 1 + 4 (x, y) pairs
     print("\n".join(lines))
 
 
