@@ -710,26 +710,38 @@ constexpr uint32_t kW8MaxCells = 144;
 constexpr uint32_t kW8CellF4 = 9;
 // KU = the window columns every lane of every wave has (floor(skip) + 1, capped at 5): their taps are straight-line code; further columns (a
 // window whose phase wraps, the shifted loads at the right frame edge) sit behind one wave-uniform branch.
+// The one-hot cell records of k_raw_scaled_demosaic_w8m, one (cell, column) pair per thread and step (a block lives for two or three output rows: eight
+// dependent byte loads per cell in front of its barrier were a sixth of its life) and no division: thread t takes column k = t & 7 of the pattern cells
+// x = (t >> 3) & 15, + 16, ... in the rows t >> 7, t >> 7 + 2, ...; tiles up to 48 wide are legal ("24x2:", "48x1:"), so x walks on and x + k wraps at the
+// 48-column period of cfa48.  Out of line on purpose: inlined, its loop state pushed the row loop over the seven-waves-per-SIMD register budget (6 spills,
+// 48 -> 76 us at 50 MP).
+__device__ __attribute__((noinline)) static void w8m_fill_cells(float4 *__restrict__ cells, const uint8_t *__restrict__ cfa48, uint32_t pw, uint32_t ph) {
+  const uint32_t k = threadIdx.x & 7u;
+  for (uint32_t y = threadIdx.x >> 7; y < ph; y += blockDim.x >> 7)
+    for (uint32_t x = (threadIdx.x >> 3) & 15u; x < pw; x += 16u) {
+      const uint32_t xk = x + k;
+      const uint32_t c = cfa48[y * 48 + (xk >= 48u ? xk - 48u : xk)] & 3u;
+      cells[(y * pw + x) * kW8CellF4 + k] = make_float4(c == 0u ? 1.0f : 0.0f, c == 1u ? 1.0f : 0.0f, c == 2u ? 1.0f : 0.0f, c == 3u ? 1.0f : 0.0f);
+    }
+}
 // C4 = the filter has a fourth colour (RGBE ...): three-colour filters (Bayer, X-Trans) skip its two accumulations per tap -- as a runtime flag they
 // were two fused multiply-adds and two selects per tap, a quarter of the tap's arithmetic.
 template <typename T, uint32_t KU, bool C4>
-// (seven waves per SIMD asked for: with the two register sets of the unrolled row loop hipcc otherwise takes 73 VGPRs -- six waves per SIMD, 3 % slower)
-__global__ __launch_bounds__(256, 7) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
+// (seven waves per SIMD asked for: with the two register sets of the unrolled row loop hipcc otherwise takes 73 VGPRs -- six waves per SIMD, 3 % slower;
+// the four-colour variants, two more accumulators, get the six: at seven they spill)
+__global__ __launch_bounds__(256, C4 ? 6 : 7) void k_raw_scaled_demosaic_w8m(const T *__restrict__ src, TransformArgs a, const uint8_t *__restrict__ cfa48,
                                                                 uint32_t pw, uint32_t ph, float *__restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) float s_m[];          // [ph][pw] cells of kW8CellF4 float4: [8 columns][4 colours] one-hot weights + padding
-  // one (cell, column) pair per thread and step: a block lives for two or three output rows, and eight dependent byte loads per cell in front of its
-  // barrier were a sixth of its life
-  // (no division either: thread t takes column k = t & 7 of the pattern cells x = (t >> 3) & 15, + 16, ... in the rows t >> 7, t >> 7 + 2, ...; tiles up to
-  // 48 wide are legal -- "24x2:", "48x1:" -- so x walks on and x + k wraps at the 48-column period of cfa48)
-  {
-    const uint32_t k = threadIdx.x & 7u;
-    for (uint32_t y = threadIdx.x >> 7; y < ph; y += blockDim.x >> 7)
-      for (uint32_t x = (threadIdx.x >> 3) & 15u; x < pw; x += 16u) {
-        const uint32_t xk = x + k;
-        const uint32_t c = cfa48[y * 48 + (xk >= 48u ? xk - 48u : xk)] & 3u;
+  // tiles up to 16 wide (every shipped filter) in line -- thread t: column k = t & 7 of cell x = (t >> 3) & 15, rows t >> 7, + 2, ...; x + k < 48 needs no wrap;
+  // wider ones through the general routine
+  if (pw <= 16u) {
+    const uint32_t k = threadIdx.x & 7u, x = (threadIdx.x >> 3) & 15u;
+    if (x < pw)
+      for (uint32_t y = threadIdx.x >> 7; y < ph; y += blockDim.x >> 7) {
+        const uint32_t c = cfa48[y * 48 + x + k] & 3u;
         reinterpret_cast<float4 *>(s_m)[(y * pw + x) * kW8CellF4 + k] = make_float4(c == 0u ? 1.0f : 0.0f, c == 1u ? 1.0f : 0.0f, c == 2u ? 1.0f : 0.0f, c == 3u ? 1.0f : 0.0f);
       }
-  }
+  } else w8m_fill_cells(reinterpret_cast<float4 *>(s_m), cfa48, pw, ph);
   __syncthreads();
   // Which block takes which columns and rows.  Output row r reads the source rows floor(skip r) .. floor(skip (r + 1)), so rows r and r + 1 share
   // one (five rows for every four at scale 4: 1.22x the frame in HBM fetches, profiles/r02_c5_pmc.json).  The hardware deals consecutive block ids
