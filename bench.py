@@ -509,7 +509,7 @@ def main():
 
     extras = (not args.no_extras) and args.config == "c3" and args.width is None and args.height is None and args.batch is None
     cold_ms = None
-    if extras:
+    if extras or ((not args.no_extras) and args.config == "c2" and args.width is None and args.height is None and args.batch is None):   # the single 24 MP frame too
         # the same K steps straight after idle (rank 0 has just spent seconds in the parity check), no clock pre-warm
         ctx.barrier(); time.sleep(0.5)
         _, cold_ms, _ = timed(ctx, wl.step, args.steps, 0, 0.0)
