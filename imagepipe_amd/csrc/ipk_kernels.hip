@@ -1230,34 +1230,56 @@ __global__ void k_rotate1_rows(const T *__restrict__ src, uint32_t owidth, uint3
     }
   }
 }
-// tiles of TW x TW elements with TW * sizeof(T) = 128 bytes: every wave-level load and store covers whole 128-byte lines
-// (2-byte sensor samples: 32-wide tiles, 64-byte pieces, 2.0 TB/s; 64-wide, 2.55 TB/s; 128 x 128 tiles with two samples per lane on
-// both sides, 2.3 TB/s; 2 x 2 blocks with all LDS and global traffic 32 bits wide, 2.6 TB/s -- neither the line size nor the LDS
-// width is the limit; the walk across 64 source rows a pitch apart is)
+// Transposing orientations of the 1-channel mosaic: dst[r][c] = src[base + y_step r + x_step c] with y_step = +-1 (consecutive OUTPUT rows are consecutive
+// source elements).  Tiles of 64 x 64 elements through LDS; a full tile moves 16 bytes per lane on BOTH sides -- a lane loads the 8 (u16) / 4 (f32)
+// source-contiguous elements of one output column, and stores that many consecutive columns of one output row, gathered element by element from the tile.
+// Round 5 (tools/transpose_probe.hip, 100 MP u16): one element per lane and access, the form of rounds 1-4, 2.65 TB/s -- its limit was the texture
+// addresser's 64 lanes x 2 bytes per instruction, not the walk across 64 source rows as round 1 concluded from tile-shape sweeps that all kept
+// narrow accesses; 16 bytes per lane: 4.9 TB/s (a plain copy of the same bytes 5.3); tiles of 64 x 128 ... 128 x 128 4.8-5.1, 256 x 256 3.7.
+// Frame-edge tiles keep the element-wise form.
 template <typename T>
 __global__ __launch_bounds__(256) void k_rotate1_transposed(const T *__restrict__ src, uint32_t owidth, uint32_t oheight, int64_t base_offset,
                                                            int64_t x_step, int64_t y_step, T *__restrict__ dst) {
-  constexpr uint32_t TW = 128 / sizeof(T), RPP = 256 / TW;              // tile width; tile rows covered per pass of the 256 threads
-  __shared__ T tile[TW][TW + 2];
+  constexpr uint32_t TW = 64, NV = 16 / sizeof(T), PITCH = TW + 2;
+  struct __attribute__((packed, aligned(sizeof(T)))) Vec { T v[NV]; };
+  __shared__ T tile[TW * PITCH];                                        // tile[c_local][r_local]
   const uint32_t C0 = blockIdx.x * TW, R0 = blockIdx.y * TW;
+  if (C0 + TW <= owidth && R0 + TW <= oheight) {                        // block-uniform
+    constexpr uint32_t VPR = TW / NV;                                   // vectors per tile row
+    for (uint32_t v = threadIdx.x; v < TW * VPR; v += 256) {
+      const uint32_t lc = v / VPR, r8 = (v % VPR) * NV;                 // output column lc, output rows r8 .. r8 + NV - 1
+      const int64_t o = base_offset + x_step * (int64_t)(C0 + lc) + y_step * (int64_t)(R0 + r8);
+      const Vec x = *reinterpret_cast<const Vec *>(src + (y_step > 0 ? o : o - (int64_t)(NV - 1)));
+      #pragma unroll
+      for (uint32_t k = 0; k < NV; ++k) tile[lc * PITCH + r8 + (y_step > 0 ? k : NV - 1 - k)] = x.v[k];
+    }
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < TW * VPR; v += 256) {
+      const uint32_t lr = v / VPR, c8 = (v % VPR) * NV;
+      Vec x;
+      #pragma unroll
+      for (uint32_t k = 0; k < NV; ++k) x.v[k] = tile[(c8 + k) * PITCH + lr];
+      *reinterpret_cast<Vec *>(dst + (size_t)(R0 + lr) * owidth + C0 + c8) = x;
+    }
+    return;
+  }
+  constexpr uint32_t RPP = 256 / TW;                                    // tile rows covered per pass of the 256 threads
   const uint32_t a = threadIdx.x % TW, b = threadIdx.x / TW;
-  #pragma unroll
   for (uint32_t i = 0; i < TW / RPP; ++i) {
     const uint32_t lr = a, lc = b + RPP * i;                            // lanes run along the output rows = consecutive source elements
     const uint32_t r = R0 + lr, c = C0 + lc;
-    if (r < oheight && c < owidth) tile[lc][lr] = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
+    if (r < oheight && c < owidth) tile[lc * PITCH + lr] = src[base_offset + y_step * (int64_t)r + x_step * (int64_t)c];
   }
   __syncthreads();
-  #pragma unroll
   for (uint32_t i = 0; i < TW / RPP; ++i) {
     const uint32_t lc = a, lr = b + RPP * i;                            // lanes run along the output columns
     const uint32_t r = R0 + lr, c = C0 + lc;
-    if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = tile[lc][lr];
+    if (r < oheight && c < owidth) dst[(size_t)r * owidth + c] = tile[lc * PITCH + lr];
   }
 }
 template <typename T>
 void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_offset, int64_t x_step, int64_t y_step, T *dst, hipStream_t s) {
-  constexpr size_t TW = 128 / sizeof(T);
+  constexpr size_t TW = 64;
   if ((y_step == 1 || y_step == -1) && x_step != 1 && x_step != -1 && (oheight + TW - 1) / TW <= 65535) {
     hipLaunchKernelGGL(k_rotate1_transposed<T>, dim3((unsigned)((owidth + TW - 1) / TW), (unsigned)((oheight + TW - 1) / TW), 1), dim3(256), 0, s,
                        src, (uint32_t)owidth, (uint32_t)oheight, base_offset, x_step, y_step, dst);
