@@ -1297,17 +1297,46 @@ template void launch_rotate1<uint16_t>(const uint16_t *, size_t, size_t, int64_t
 void launch_output8(const float *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(k_output8, dim3(grid_1d((n + 3) / 4, 256, flat_cap((unsigned)num_cus * 16))), dim3(256), 0, s, src, n, dst);
 }
-__global__ void k_chan_8_to_16(const uint8_t *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint16_t)(src[i] * 257u);
+// The sample-depth changes of the raster fast path (src/pipeline.rs:381-402, :428-449): v * 257 and (v + 128) / 257, sixteen samples per lane -- 16-byte
+// loads and stores (round 5: one sample per lane and access ran at 3.8 / 4.5 TB/s of its 3 bytes per sample; see k_rotate1_transposed for the same finding)
+struct __attribute__((packed, aligned(1))) ChanB16 { uint32_t w[4]; };
+struct __attribute__((packed, aligned(2))) ChanH8 { uint32_t w[4]; };
+__global__ __launch_bounds__(256) void k_chan_8_to_16(const uint8_t *__restrict__ src, size_t n, uint16_t *__restrict__ dst) {
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+  if (i0 + 16u <= n) {
+    const ChanB16 v = *reinterpret_cast<const ChanB16 *>(src + i0);
+    ChanH8 lo, hi;
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) {                          // b * 257 = the byte twice: bytes (0,0,1,1) and (2,2,3,3) of each input dword
+      const uint32_t a = __builtin_amdgcn_perm(v.w[k], v.w[k], 0x01010000u), b = __builtin_amdgcn_perm(v.w[k], v.w[k], 0x03030202u);
+      if (k < 2) { lo.w[2 * k] = a; lo.w[2 * k + 1] = b; } else { hi.w[2 * (k - 2)] = a; hi.w[2 * (k - 2) + 1] = b; }
+    }
+    *reinterpret_cast<ChanH8 *>(dst + i0) = lo; *reinterpret_cast<ChanH8 *>(dst + i0 + 8) = hi;
+  } else {
+    for (size_t i = i0; i < n; ++i) dst[i] = (uint16_t)(src[i] * 257u);
+  }
 }
-__global__ void k_chan_16_to_8(const uint16_t *__restrict__ src, size_t n, uint8_t *__restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint8_t)(((uint32_t)src[i] + 128u) / 257u);
+__global__ __launch_bounds__(256) void k_chan_16_to_8(const uint16_t *__restrict__ src, size_t n, uint8_t *__restrict__ dst) {
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+  if (i0 + 16u <= n) {
+    const ChanH8 lo = *reinterpret_cast<const ChanH8 *>(src + i0), hi = *reinterpret_cast<const ChanH8 *>(src + i0 + 8);
+    ChanB16 o;
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w0 = k < 2 ? lo.w[2 * k] : hi.w[2 * (k - 2)], w1 = k < 2 ? lo.w[2 * k + 1] : hi.w[2 * (k - 2) + 1];
+      const uint32_t q0 = ((w0 & 0xFFFFu) + 128u) / 257u, q1 = ((w0 >> 16) + 128u) / 257u, q2 = ((w1 & 0xFFFFu) + 128u) / 257u, q3 = ((w1 >> 16) + 128u) / 257u;
+      o.w[k] = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+    }
+    *reinterpret_cast<ChanB16 *>(dst + i0) = o;
+  } else {
+    for (size_t i = i0; i < n; ++i) dst[i] = (uint8_t)(((uint32_t)src[i] + 128u) / 257u);
+  }
 }
-void launch_chan_8_to_16(const uint8_t *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s) {
-  hipLaunchKernelGGL(k_chan_8_to_16, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+void launch_chan_8_to_16(const uint8_t *src, size_t n, uint16_t *dst, int, hipStream_t s) {
+  hipLaunchKernelGGL(k_chan_8_to_16, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, src, n, dst);
 }
-void launch_chan_16_to_8(const uint16_t *src, size_t n, uint8_t *dst, int num_cus, hipStream_t s) {
-  hipLaunchKernelGGL(k_chan_16_to_8, dim3(grid_1d(n, 256, (unsigned)num_cus * 16)), dim3(256), 0, s, src, n, dst);
+void launch_chan_16_to_8(const uint16_t *src, size_t n, uint8_t *dst, int, hipStream_t s) {
+  hipLaunchKernelGGL(k_chan_16_to_8, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, src, n, dst);
 }
 void launch_output16(const float *src, size_t n, uint16_t *dst, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(k_output16, dim3(grid_1d((n + 3) / 4, 256, flat_cap((unsigned)num_cus * 16))), dim3(256), 0, s, src, n, dst);
