@@ -345,6 +345,10 @@ struct TransformArgs {
   // k_raw_scaled_demosaic_w8m: a one-dimensional launch of xcd_gx x xcd_gy blocks (xcd_gy a multiple of 8) laid out so that each XCD works on one
   // contiguous eighth of the block rows (see the kernel); 0 = the plain two-dimensional grid
   uint32_t xcd_gx, xcd_gy, xcd_group;
+  // k_transform_buffer: 1 when the transform is scale_down_buffer's (corner (0, 0), no cross terms, both skips >= 1, frame sides below 2^24): sample offsets and
+  // centres are then sums of terms that are zero or multiples of 2^-24, so a nonzero difference lies in [2^-24, 2^25] -- inside the multiply-fma
+  // division's proven zone without tb_div's per-tap exponent test and its divergent IEEE fallback
+  int plain_axis;
 };
 // (v - center) / skip  (scaling.rs:104-105): cdiv_fast when the host validated the divisor and the dividend is in the proven
 // zone, the IEEE division otherwise (zero or negative skips of degenerate / rotated transforms, absurd centres)
@@ -366,6 +370,8 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
   }
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= a.nwidth) return;
+  constexpr bool RGB3 = sizeof(T) <= 2;                                     // the integer instantiations are the raster fast path's
+  const bool plain = a.plain_axis != 0;
   for (uint32_t row = blockIdx.y; row < a.nheight; row += gridDim.y) {
     // per-row values (scaling.rs:77-82)
     const float from_x_r = a.tlx + a.skip_y_x * (float)row;
@@ -383,16 +389,84 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
     const float center_y = center_y_r + (a.skip_x_y * (float)col) + (a.skip_x_y / 2.0f);
 
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    // The thumbnail path of output_8bit / output_16bit (scale_down_srgb / 16, src/scaling.rs:162-182): a raster, three samples per pixel, windows of at most
+    // eight columns (scale <= 7).  One window row = eight pixel loads issued together (one access per pixel: 4 bytes for RGB8, 8 for RGB16; the last pixel
+    // of the frame reads the bytes in FRONT of it and shifts) -- the tap-by-tap loop below waits out one memory round trip per tap.  Columns outside the
+    // lane's window carry the weight 1 - dx dx = -inf, which the clamp turns into a factor of 0: 0 * sample and + 0 change nothing in sums that start at +0.0.
+    if (RGB3 && plain && a.components == 3u && !a.has_cfa && __builtin_amdgcn_ballot_w64(to_x - from_x >= 8u) == 0) {
+      float ax[8];
+      #pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const float dxv = (float)(from_x + k) - center_x;
+        const float delta_x = a.fast_x ? cdiv_fast(dxv, a.skip_x_x, a.inv_skip_x_x) : dxv / a.skip_x_x;
+        ax[k] = (from_x + k <= to_x) ? 1.0f - (delta_x * delta_x) : -__builtin_inff();
+      }
+      const size_t last_px = (size_t)a.width * a.height - 1;
+      for (uint32_t y = from_y; y <= to_y; ++y) {
+        const float dyv = (float)y - center_y;
+        const float delta_y = a.fast_y ? cdiv_fast(dyv, a.skip_y_y, a.inv_skip_y_y) : dyv / a.skip_y_y;
+        const float dy2 = delta_y * delta_y;
+        float c0[8], c1[8], c2[8];
+        #pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+          const size_t pi = (size_t)y * a.width + min(from_x + k, a.width - 1);
+          const bool tail = pi == last_px && last_px > 0;
+          if (sizeof(T) == 1) {
+            struct __attribute__((packed, aligned(1))) W4 { uint32_t w; };
+            uint32_t w = reinterpret_cast<const W4 *>(reinterpret_cast<const uint8_t *>(src) + pi * 3 - (tail ? 1 : 0))->w;
+            w = tail ? w >> 8 : w;
+            c0[k] = (float)(w & 0xFFu); c1[k] = (float)((w >> 8) & 0xFFu); c2[k] = (float)((w >> 16) & 0xFFu);
+          } else {
+            struct __attribute__((packed, aligned(2))) W8 { uint32_t lo, hi; };
+            const W8 w = *reinterpret_cast<const W8 *>(reinterpret_cast<const uint16_t *>(src) + pi * 3 - (tail ? 1 : 0));
+            const unsigned long long q = (((unsigned long long)w.hi << 32) | w.lo) >> (tail ? 16 : 0);
+            c0[k] = (float)((uint32_t)q & 0xFFFFu); c1[k] = (float)((uint32_t)(q >> 16) & 0xFFFFu); c2[k] = (float)((uint32_t)(q >> 32) & 0xFFFFu);
+          }
+        }
+        #pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+          float factor = ax[k] - dy2;                                         // 1.0 - dx dx - dy dy, left to right (scaling.rs:106)
+          factor = (factor < 0.0f) ? 0.0f : factor;
+          s0 += c0[k] * factor; n0 += factor; s1 += c1[k] * factor; n1 += factor; s2 += c2[k] * factor; n2 += factor;
+        }
+        if (y == 0xFFFFFFFFu) break;
+      }
+      T *o = dst + ((size_t)row * a.nwidth + col) * 3;
+      o[0] = (n0 > 0.0f) ? PixCast<T>::from(s0 / n0) : PixCast<T>::from(0.0f);
+      o[1] = (n1 > 0.0f) ? PixCast<T>::from(s1 / n1) : PixCast<T>::from(0.0f);
+      o[2] = (n2 > 0.0f) ? PixCast<T>::from(s2 / n2) : PixCast<T>::from(0.0f);
+      continue;
+    }
     const uint32_t xm0 = from_x % 48;                                       // cfa.color_at(y, x) = pattern[y%48][x%48], kept incrementally
     uint32_t ym48 = (from_y % 48) * 48;
     for (uint32_t y = from_y; y <= to_y; ++y) {
-      const float delta_y = tb_div((float)y - center_y, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
+      const float dyv = (float)y - center_y;
+      const float delta_y = plain ? (a.fast_y ? cdiv_fast(dyv, a.skip_y_y, a.inv_skip_y_y) : dyv / a.skip_y_y) : tb_div(dyv, a.skip_y_y, a.inv_skip_y_y, a.fast_y);
       const float dy2 = delta_y * delta_y;
       uint32_t xm = xm0;
       for (uint32_t x = from_x; x <= to_x; ++x) {
-        const float delta_x = tb_div((float)x - center_x, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
+        const float dxv = (float)x - center_x;
+        const float delta_x = plain ? (a.fast_x ? cdiv_fast(dxv, a.skip_x_x, a.inv_skip_x_x) : dxv / a.skip_x_x) : tb_div(dxv, a.skip_x_x, a.inv_skip_x_x, a.fast_x);
         float factor = 1.0f - (delta_x * delta_x) - dy2;                    // scaling.rs:106
         factor = (factor < 0.0f) ? 0.0f : factor;
+        if (RGB3 && plain && a.components == 3u && !a.has_cfa) {
+          // a raster pixel's three samples in one access (scale_down_srgb / scale_down_srgb16: the thumbnail path of output_8bit / output_16bit) instead
+          // of three one-sample loads; the frame's very last pixel keeps them (the wide load would read past the buffer)
+          const size_t pi = (size_t)y * a.width + x;
+          float c0, c1, c2;
+          if (pi + 1 < (size_t)a.width * a.height) {
+            if (sizeof(T) == 1) {
+              struct __attribute__((packed, aligned(1))) W4 { uint32_t w; };
+              const uint32_t w = reinterpret_cast<const W4 *>(reinterpret_cast<const uint8_t *>(src) + pi * 3)->w;
+              c0 = (float)(w & 0xFFu); c1 = (float)((w >> 8) & 0xFFu); c2 = (float)((w >> 16) & 0xFFu);
+            } else {
+              struct __attribute__((packed, aligned(2))) W8 { uint32_t lo, hi; };
+              const W8 w = *reinterpret_cast<const W8 *>(reinterpret_cast<const uint16_t *>(src) + pi * 3);
+              c0 = (float)(w.lo & 0xFFFFu); c1 = (float)(w.lo >> 16); c2 = (float)(w.hi & 0xFFFFu);
+            }
+          } else { const T *p = src + pi * 3; c0 = PixCast<T>::to(p[0]); c1 = PixCast<T>::to(p[1]); c2 = PixCast<T>::to(p[2]); }
+          s0 += c0 * factor; n0 += factor; s1 += c1 * factor; n1 += factor; s2 += c2 * factor; n2 += factor;
+        } else
         if (a.has_cfa) {
           const uint32_t c = s_cfa[ym48 + xm];                              // cfa.color_at(y, x)
           xm = (xm == 47) ? 0 : xm + 1;
@@ -431,6 +505,7 @@ void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t 
                              int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,
                              const uint8_t *cfa48_dev, T *dst, hipStream_t s) {
   TransformArgs a;
+  a.plain_axis = 0;
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight;
   a.components = (uint32_t)components;
   a.tlx = (float)tlx; a.tly = (float)tly;
@@ -443,6 +518,8 @@ void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t 
   a.fast_x = cdiv_host_ok(a.skip_x_x); a.fast_y = cdiv_host_ok(a.skip_y_y);
   a.has_cfa = cfa48_dev != nullptr;
   a.norm = 0; a.min0 = 0.0f; a.range0 = 1.0f; a.src_pitch = width; a.src_x = 0; a.src_y = 0; a.norm_fast = 0; a.inv_range0 = 1.0f;
+  a.plain_axis = (tlx == 0 && tly == 0 && a.skip_x_y == 0.0f && a.skip_y_x == 0.0f && a.skip_x_x >= 1.0f && a.skip_y_y >= 1.0f &&
+                  a.skip_x_x <= 0x1p24f && a.skip_y_y <= 0x1p24f && width < (size_t(1) << 24) && height < (size_t(1) << 24)) ? 1 : 0;
   hipLaunchKernelGGL(k_transform_buffer<T>, grid_rows_few(nwidth, nheight, 128, 8192), dim3(128), 0, s, src, a, cfa48_dev, dst);
 }
 
@@ -507,6 +584,7 @@ static int cdiv_host_ok(float c);
 void launch_raster_scale_down(const void *src, int src_is_u16, size_t owidth, size_t x, size_t y, size_t width, size_t height,
                               size_t nwidth, size_t nheight, const void *gamma_reverse_pairs, float *dst4, hipStream_t s) {
   TransformArgs a;
+  a.plain_axis = 0;
   std::memset(&a, 0, sizeof(a));
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
@@ -924,6 +1002,7 @@ void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y,
                                 int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pw, int ph, float *dst4, hipStream_t s,
                                 size_t band_src_row0, size_t band_out_row0, size_t band_out_rows) {
   TransformArgs a;
+  a.plain_axis = 0;
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
   a.skip_x_x = ((float)((int64_t)width - 1) - 0.0f) / ((float)(nwidth - 1));

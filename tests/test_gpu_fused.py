@@ -391,7 +391,7 @@ def test_roundtrip_16bit_gpu(ipa, fast):
 
 
 @pytest.mark.parametrize("bits", [8, 16])
-@pytest.mark.parametrize("maxwidth", [0, 100, 37])
+@pytest.mark.parametrize("maxwidth", [0, 100, 37, 29, 20, 6])      # scales 2.1, 5.7, 7.3 (windows of eight and nine columns side by side), 10.6, 35
 def test_raster_fastpath_vs_oracle(ipa, orc, bits, maxwidth):
     """output_8bit / output_16bit of a raster source with default ops (pipeline.rs:381-402, :428-449): no float pipeline, integer
     resampling (scale_down_srgb/16), channel-depth conversion when the depths differ; and the slow path beside it"""
