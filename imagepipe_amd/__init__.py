@@ -18,7 +18,7 @@ from ._lib import (IpkError, FusedParams, PipelineDesc, OUT_F32, OUT_U8, OUT_U16
                    OR_NORMAL, OR_HFLIP, OR_ROT180, OR_VFLIP, OR_TRANSPOSE, OR_ROT90, OR_TRANSVERSE, OR_ROT270, OR_UNKNOWN,
                    ROT_NORMAL, ROT_90, ROT_180, ROT_270, IPK_NOOP)
 
-__all__ = ["init", "lib", "OpBuffer", "RawImage", "OtherImage", "PipelineSettings", "PipelineGlobals", "PipelineOps",
+__all__ = ["init", "init_devices", "deal_frames", "Context", "lib", "OpBuffer", "RawImage", "OtherImage", "PipelineSettings", "PipelineGlobals", "PipelineOps",
            "Pipeline", "OpGoFloat", "OpDemosaic", "OpRotateCrop", "OpToLab", "OpBaseCurve", "OpFromLab", "OpGamma",
            "OpTransform", "raw_to_srgb", "FusedPlan", "IpkError"]
 
@@ -43,6 +43,66 @@ def init(device: Optional[int] = None):
         _lib.check(L.ipk_init(device), "ipk_init")
         _initialized_device = device
     return device
+
+
+class Context:
+    """ipk_ctx: one more device binding in this process (a second GPU, or a second independent pipeline on the same GPU).  `with ctx:` makes it
+    the calling thread's current context -- every ipk_* call inside runs on it -- and puts the previous one back on exit."""
+
+    def __init__(self, device: int = 0, handle=None):
+        if handle is None:
+            h = C.c_void_p()
+            _lib.check(lib().ipk_ctx_create(int(device), C.byref(h)), "ipk_ctx_create")
+            handle, self._owned = h.value, True
+        else:
+            self._owned = False
+        self.handle = handle
+        self.device = lib().ipk_ctx_device(handle)
+        self._prev = []
+
+    def make_current(self):
+        _lib.check(lib().ipk_ctx_make_current(self.handle), "ipk_ctx_make_current")
+
+    def __enter__(self):
+        self._prev.append(lib().ipk_ctx_current())
+        self.make_current()
+        return self
+
+    def __exit__(self, *exc):
+        prev = self._prev.pop()
+        # the process default is restored as "no explicit choice" (NULL), anything else as itself
+        lib().ipk_ctx_make_current(prev if prev and prev != self.handle else None)
+        return False
+
+    def destroy(self):
+        if self.handle and self._owned:
+            _lib.check(lib().ipk_ctx_destroy(self.handle), "ipk_ctx_destroy")
+        self._owned = False
+
+
+def init_devices(devices=None):
+    """ipk_init_devices: the process's device set, one context per listed device ([] / None = every visible device; an ordinal may repeat).
+    Returns the members as Context objects (not owned: ipk_init_devices / ipk_shutdown manage them)."""
+    global _initialized_device
+    L = lib()
+    if not torch.cuda.is_available():
+        raise IpkError("imagepipe_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    devs = list(devices or [])
+    for d in sorted(set(devs or range(torch.cuda.device_count()))):
+        torch.zeros(1, device="cuda:%d" % d)        # torch's HIP context on every device first
+    arr = (C.c_int * max(1, len(devs)))(*devs)
+    _lib.check(L.ipk_init_devices(arr if devs else None, len(devs)), "ipk_init_devices")
+    members = [Context(handle=L.ipk_device_ctx(i)) for i in range(L.ipk_device_set_size())]
+    if _initialized_device is None and members:
+        _initialized_device = members[0].device
+    return members
+
+
+def deal_frames(n_frames, n_devices, index):
+    """ipk_deal_frames: the frame indices set member `index` of `n_devices` gets of an n_frames batch (host arithmetic)"""
+    f, s, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _lib.check(lib().ipk_deal_frames(n_frames, n_devices, index, C.byref(f), C.byref(s), C.byref(c)), "ipk_deal_frames")
+    return [f.value + k * s.value for k in range(c.value)]
 
 
 def _stream():

@@ -22,10 +22,18 @@ _szp = C.POINTER(C.c_size_t)
 _i64 = C.c_int64
 
 
-class FusedParams(C.Structure):
+class _SizedDesc(C.Structure):
+    """a descriptor with a leading struct_size ("Descriptor versioning", include/imagepipe_amd.h): a new object states its own size"""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(self)
+
+
+class FusedParams(_SizedDesc):
     """ipk_fused_params"""
     _fields_ = [
-        ("src_type", C.c_int), ("owidth", _sz),
+        ("struct_size", C.c_uint32), ("src_type", C.c_int), ("owidth", _sz),
         ("x", _sz), ("y", _sz), ("width", _sz), ("height", _sz),
         ("black0", C.c_float), ("white0", C.c_float),
         ("cfa", C.c_char * 160),
@@ -37,10 +45,10 @@ class FusedParams(C.Structure):
     ]
 
 
-class PipelineDesc(C.Structure):
+class PipelineDesc(_SizedDesc):
     """ipk_pipeline_desc"""
     _fields_ = [
-        ("src_type", C.c_int), ("width", _sz), ("height", _sz),
+        ("struct_size", C.c_uint32), ("src_type", C.c_int), ("width", _sz), ("height", _sz),
         ("cpp", C.c_int), ("is_cfa", C.c_int), ("cfa", C.c_char * 160),
         ("crop_top", _sz), ("crop_right", _sz), ("crop_bottom", _sz), ("crop_left", _sz),
         ("blacklevels", C.c_float * 4), ("whitelevels", C.c_float * 4),
@@ -136,6 +144,19 @@ SIGNATURES = {
     "ipk_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int), _vp]),
     "ipk_host_pipeline_run": (C.c_int, [C.POINTER(PipelineDesc), _vp, _vp, C.c_int, C.POINTER(C.c_int)]),
     "ipk_host_pipeline_run_batch": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_vp), C.POINTER(_vp), _sz, C.c_int, C.POINTER(C.c_int)]),
+    "ipk_pipeline_run_batch": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_vp), C.POINTER(_vp), _sz, C.c_int, C.POINTER(C.c_int), _vp]),
+    "ipk_pipeline_run_batch_multi": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_vp), C.POINTER(_vp), _sz, C.c_int, C.POINTER(C.c_int)]),
+    "ipk_host_pipeline_run_batch_multi": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_vp), C.POINTER(_vp), _sz, C.c_int, C.POINTER(C.c_int)]),
+    "ipk_devices_sync": (C.c_int, []),
+    "ipk_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "ipk_ctx_destroy": (C.c_int, [_vp]),
+    "ipk_ctx_make_current": (C.c_int, [_vp]),
+    "ipk_ctx_current": (_vp, []),
+    "ipk_ctx_device": (C.c_int, [_vp]),
+    "ipk_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "ipk_device_set_size": (C.c_int, []),
+    "ipk_device_ctx": (_vp, [C.c_int]),
+    "ipk_deal_frames": (C.c_int, [_sz, C.c_int, C.c_int, _szp, _szp, _szp]),
     "ipk_host_alloc": (_vp, [_sz]),
     "ipk_host_free": (None, [_vp]),
     "ipk_host_gofloat_cfa_u16": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_float, C.c_float, _vp]),

@@ -10,9 +10,12 @@
 #include <cstdio>
 #include <cstddef>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/imagepipe_amd.h"
@@ -34,15 +37,37 @@ int fail(int code, const char *fmt, ...) {
 
 struct DevCfa { uint32_t *lookups = nullptr; uint8_t *cfa48 = nullptr; float *gen_cells = nullptr; int gen_pw = 0, gen_ph = 0; };   // gen_cells: null for filters with a fourth colour
 
-struct Context {
+}  // namespace
+
+namespace {
+// The streams, events and device slots of the host-pointer pipeline driver.  One set per context, grown on demand and kept
+// between calls (a fresh hipMalloc of two input and two output slots costs more than moving a frame), released with the context.
+struct HostLanes {
+  static constexpr int kSlots = 2;
+  std::mutex mu;                                  // one host-pointer pipeline call at a time per context
+  hipStream_t up = nullptr, run = nullptr, down = nullptr;
+  hipEvent_t up_done[kSlots] = {}, run_done[kSlots] = {}, down_done[kSlots] = {};
+  void *in[kSlots] = {}, *out[kSlots] = {};
+  size_t in_cap = 0, out_cap = 0;
+  bool made = false;
+  int ensure(size_t in_bytes, size_t out_bytes);
+  void release();
+};
+}  // namespace
+
+// One library context: a device binding plus everything the entry points keep on that device -- the lookup tables, the CFA table cache, the
+// stream-ordered scratch pool, the task-queue heads of the row-walking kernels, the host-pointer driver's lanes.  A process may hold several
+// (one per GPU for a batch dealt frame i -> device i mod N from ONE process -- the reference is one process, src/lib.rs:21-26 -- or several on one
+// GPU); every entry point works on the calling thread's CURRENT context (ipk_ctx_make_current), which defaults to the one ipk_init made.
+// Contexts are never deallocated before process exit (ipk_ctx_destroy releases the device resources and marks the object dead), so a stale
+// handle on another thread fails with IPK_ERR_NOT_INIT instead of touching freed memory.
+struct ipk_ctx {
   bool ready = false;
   int libm_matches = -1; size_t libm_mismatches = 0;      // init-time comparison of the host's cbrtf with the device routine
   int device = -1;
   int num_cus = 0;
-  std::vector<float> lut_host[3];
   void *lut_pairs[3] = {nullptr, nullptr, nullptr};      // device, 8192 x {v, dv}
   void *lut_plain[3] = {nullptr, nullptr, nullptr};      // device, 8193 floats
-  float xyz_d65_33[9];
   std::map<std::string, DevCfa> cfa_cache;
   std::map<std::string, float *> rot_cells;              // generic-CFA cell records laid out for a rotated space (pattern, orientation, frame phase)
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
@@ -50,22 +75,50 @@ struct Context {
   struct Block { void *p; size_t bytes; bool busy; hipStream_t last; bool clean; };
   std::vector<Block> pool;
   std::mutex mu;
+  ipk::TaskQueues *queues = nullptr;
+  HostLanes lanes;
+  hipStream_t multi_stream = nullptr;                    // the stream ipk_pipeline_run_batch_multi enqueues on for this context
 };
-Context g;
 
-void build_host_luts() {
-  if (!g.lut_host[0].empty()) return;
-  for (int i = 0; i < 3; ++i) g.lut_host[i] = ipk::build_lut(static_cast<ipk::LutId>(i));
-  const ipk::Mat33 inv = ipk::inverse(ipk::srgb_d65_33());
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g.xyz_d65_33[r * 3 + c] = inv.m[r][c];
+namespace {
+typedef ipk_ctx Context;
+// host-side state every context shares (immutable once built)
+struct HostTables {
+  std::mutex mu;
+  std::vector<float> lut_host[3];
+  float xyz_d65_33[9];
+} g_host;
+std::mutex g_reg_mu;                                      // registry, default context, device set
+std::vector<std::unique_ptr<Context>> g_registry;         // every context ever created (dead ones stay: see ipk_ctx)
+std::atomic<Context *> g_default{nullptr};                             // ipk_init's context: current on every thread that has not chosen another
+std::vector<Context *> g_devset;                          // ipk_init_devices: one context per listed device
+thread_local Context *t_current = nullptr;
+Context g_none;                                           // ready == false: what cx() answers before any context exists
+Context &cx() {
+  Context *c = t_current ? t_current : g_default.load(std::memory_order_acquire);
+  return c ? *c : g_none;
 }
 
-int require_init() {
-  if (!g.ready) return fail(IPK_ERR_NOT_INIT, "ipk_init() has not succeeded (no MI355X/HIP device bound); there is no CPU fallback");
-  // HIP's current device is per host thread: a caller on another thread than ipk_init's (a Rayon worker) must land on the same GPU
-  static thread_local int bound = -1;
-  if (bound != g.device) { HIPCHK(hipSetDevice(g.device)); bound = g.device; }
+void build_host_luts() {
+  std::lock_guard<std::mutex> lk(g_host.mu);
+  if (!g_host.lut_host[0].empty()) return;
+  for (int i = 0; i < 3; ++i) g_host.lut_host[i] = ipk::build_lut(static_cast<ipk::LutId>(i));
+  const ipk::Mat33 inv = ipk::inverse(ipk::srgb_d65_33());
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g_host.xyz_d65_33[r * 3 + c] = inv.m[r][c];
+}
+
+// HIP's current device is per host thread: a caller on another thread than the context's creator (a Rayon worker), or one that switched
+// contexts, must land on the context's GPU.  hipGetDevice is a thread-local read; asking every time (instead of remembering what this
+// library set last) stays correct when the host application calls hipSetDevice itself between two calls.
+int bind_device(int device) {
+  int now = -1;
+  if (hipGetDevice(&now) != hipSuccess || now != device) HIPCHK(hipSetDevice(device));
   return IPK_OK;
+}
+int require_init() {
+  Context &c = cx();
+  if (!c.ready) return fail(IPK_ERR_NOT_INIT, "no live context on this thread: ipk_init() / ipk_ctx_create() has not succeeded (no MI355X/HIP device bound) or the current context was destroyed; there is no CPU fallback");
+  return bind_device(c.device);
 }
 #define REQUIRE_INIT() do { int rc_ = require_init(); if (rc_) return rc_; } while (0)
 }  // namespace
@@ -75,7 +128,7 @@ int internal_fail(int code, const char *fmt, ...) {
   return code;
 }
 int internal_require_init() { return require_init(); }
-int internal_device() { return g.device; }
+int internal_device() { return cx().device; }
 }  // namespace ipk
 namespace {
 
@@ -94,15 +147,35 @@ int cfa_fail(const char *pat) {
 // fills the fields from its CFA object, one that writes a redundant "2x2:" prefix and one that passes the plain pattern therefore reach the same
 // device tables and -- through hash_chain -- the same ipk_pipeline_hashes / cache keys, which stay the hash of the reference's plain pattern string
 // (src/ops/demosaic.rs:13).  False: the fields contradict a prefix already in the string, or the result does not fit the buffer.
+// Every descriptor that crosses the ABI is first TAKEN: struct_size bytes of the caller's object into a zeroed struct of this library's layout
+// (include/imagepipe_amd.h, "Descriptor versioning"), so nothing is ever read past what the caller has, fields the caller's header did not know
+// keep their zero defaults, and an object from a newer header is refused instead of half understood.  Then the CFA shape is folded (below).
 #define IPK_FOLD_CFA(T, d) \
   T d##_folded; \
   if (d) { \
-    d##_folded = *(d); \
+    { const int trc_ = take_desc((d), d##_folded); if (trc_) return trc_; } \
     if (!fold_cfa_shape(d##_folded)) \
       return (d##_folded.cfa_width == 0 && d##_folded.cfa_height == 0) ? fail(IPK_ERR_INVALID, "invalid CFA shape prefix (expected \"WxH:letters\" with W*H letters)") \
                                                                         : fail(IPK_ERR_INVALID, "cfa_width / cfa_height do not fit the pattern string"); \
     (d) = &d##_folded; \
   }
+template <typename Desc>
+static int take_desc(const Desc *in, Desc &out) {
+  const size_t have = in->struct_size, oldest = offsetof(Desc, cfa_width);
+  if (have == 0) return fail(IPK_ERR_INVALID, "descriptor.struct_size is 0: initialise the descriptor with IPK_*_INIT (struct_size = sizeof of the struct as the caller was compiled)");
+  if (have < oldest) return fail(IPK_ERR_INVALID, "descriptor.struct_size %zu is smaller than the first published layout (%zu bytes)", have, oldest);
+  if (have > sizeof(Desc)) return fail(IPK_ERR_INVALID, "descriptor.struct_size %zu is larger than this library's struct (%zu bytes): the caller was built against a newer header", have, sizeof(Desc));
+  // Appended fields arrive in whole published layouts only: an object shorter than this library's struct is an object of the FIRST layout (its own
+  // sizeof is `oldest` rounded up to the struct's alignment -- the bytes between are that compiler's tail padding, indeterminate, and must not land in
+  // cfa_width), so exactly the first layout's fields are copied.  A later layout adds its boundary to this list.
+  const size_t layouts[] = {oldest, sizeof(Desc)};
+  size_t take = oldest;
+  for (size_t b : layouts) if (b <= have) take = b;
+  std::memset(static_cast<void *>(&out), 0, sizeof(Desc));
+  std::memcpy(static_cast<void *>(&out), in, take);
+  out.struct_size = (uint32_t)sizeof(Desc);
+  return IPK_OK;
+}
 template <typename Desc>
 static bool fold_cfa_shape(Desc &d) {
   d.cfa[sizeof(d.cfa) - 1] = 0;
@@ -125,9 +198,9 @@ static bool fold_cfa_shape(Desc &d) {
 // device-side tables for one CFA pattern string (uploaded once, cached)
 int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
   if (!ipk::Cfa::parse(pat, cfa) || !cfa.valid()) return cfa_fail(pat);
-  std::lock_guard<std::mutex> lk(g.mu);
-  auto it = g.cfa_cache.find(pat);
-  if (it != g.cfa_cache.end()) { dev = it->second; return IPK_OK; }
+  std::lock_guard<std::mutex> lk(cx().mu);
+  auto it = cx().cfa_cache.find(pat);
+  if (it != cx().cfa_cache.end()) { dev = it->second; return IPK_OK; }
   uint32_t lookups[48 * 48];
   cfa.demosaic_lookups(lookups);
   DevCfa d;
@@ -141,7 +214,7 @@ int get_cfa(const char *pat, ipk::Cfa &cfa, DevCfa &dev) {
     HIPCHK(hipMemcpy(d.gen_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
     d.gen_pw = cfa.width; d.gen_ph = cfa.height;
   }
-  g.cfa_cache[pat] = d;
+  cx().cfa_cache[pat] = d;
   dev = d;
   return IPK_OK;
 }
@@ -162,53 +235,53 @@ static hipStream_t pool_key(hipStream_t s) {
 }
 static int pool_pick(size_t bytes, hipStream_t stream) {
   int best = -1;
-  for (size_t i = 0; i < g.pool.size(); ++i) {
-    const auto &b = g.pool[i];
-    if (!b.busy && b.bytes >= bytes && (b.clean || b.last == stream) && (best < 0 || b.bytes < g.pool[best].bytes)) best = (int)i;
+  for (size_t i = 0; i < cx().pool.size(); ++i) {
+    const auto &b = cx().pool[i];
+    if (!b.busy && b.bytes >= bytes && (b.clean || b.last == stream) && (best < 0 || b.bytes < cx().pool[best].bytes)) best = (int)i;
   }
   return best;
 }
 int pool_get(size_t bytes, void **out, hipStream_t stream) {
   stream = pool_key(stream);
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(cx().mu);
   int best = pool_pick(bytes, stream);
   if (best < 0) {
     bool foreign_fits = false;
-    for (const auto &b : g.pool) foreign_fits = foreign_fits || (!b.busy && b.bytes >= bytes);
+    for (const auto &b : cx().pool) foreign_fits = foreign_fits || (!b.busy && b.bytes >= bytes);
     // nothing fits on any stream: the idle blocks are all too small for this frame size, so they go before a larger one is allocated
     // (a long-running process that moves between frame sizes keeps only what its current size needs; hipFree waits for their users)
     if (!foreign_fits)
-      for (size_t i = g.pool.size(); i-- > 0;)
-        if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
+      for (size_t i = cx().pool.size(); i-- > 0;)
+        if (!cx().pool[i].busy) { (void)hipFree(cx().pool[i].p); cx().pool.erase(cx().pool.begin() + (long)i); }
     void *p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 1) == hipSuccess) {
-      g.pool.push_back({p, bytes, true, stream, false});
+      cx().pool.push_back({p, bytes, true, stream, false});
       *out = p;
       return IPK_OK;
     }
     (void)hipGetLastError();
     // out of memory: drain the device -- every idle block is then free of users -- and look again, dropping what is too small
     if (hipDeviceSynchronize() != hipSuccess) return fail(IPK_ERR_HIP, "hipDeviceSynchronize failed");
-    for (auto &b : g.pool) if (!b.busy) b.clean = true;
+    for (auto &b : cx().pool) if (!b.busy) b.clean = true;
     best = pool_pick(bytes, stream);
     if (best < 0) {
-      for (size_t i = g.pool.size(); i-- > 0;)
-        if (!g.pool[i].busy) { (void)hipFree(g.pool[i].p); g.pool.erase(g.pool.begin() + (long)i); }
+      for (size_t i = cx().pool.size(); i-- > 0;)
+        if (!cx().pool[i].busy) { (void)hipFree(cx().pool[i].p); cx().pool.erase(cx().pool.begin() + (long)i); }
       if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-      g.pool.push_back({p, bytes, true, stream, false});
+      cx().pool.push_back({p, bytes, true, stream, false});
       *out = p;
       return IPK_OK;
     }
   }
-  auto &b = g.pool[best];
+  auto &b = cx().pool[best];
   b.busy = true; b.last = stream; b.clean = false; *out = b.p;
   return IPK_OK;
 }
 void pool_put(void *p, hipStream_t stream) {
   if (!p) return;
   stream = pool_key(stream);
-  std::lock_guard<std::mutex> lk(g.mu);
-  for (auto &b : g.pool) if (b.p == p) { b.last = stream; b.busy = false; return; }
+  std::lock_guard<std::mutex> lk(cx().mu);
+  for (auto &b : cx().pool) if (b.p == p) { b.last = stream; b.busy = false; return; }
 }
 struct Scratch {                       // RAII: returns its buffers to the pool
   hipStream_t stream;
@@ -296,7 +369,8 @@ int cbuf_new(size_t w, size_t h, size_t colors, int mono, CBufP &out) {
 
 struct ipk_cache {
   ipk::LruByteCache<CBuf> lru;
-  explicit ipk_cache(size_t bytes) : lru(bytes) {}
+  ipk_ctx *owner;                        // the context (device) whose memory the cached OpBuffers live in; null for a cache made before any context
+  explicit ipk_cache(size_t bytes, ipk_ctx *o) : lru(bytes), owner(o) {}
 };
 
 namespace {
@@ -324,30 +398,25 @@ extern "C" {
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-int ipk_init(int device) {
-  if (g.ready && g.device == device) return IPK_OK;
-  if (g.ready) ipk_shutdown();
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(IPK_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n) return fail(IPK_ERR_INVALID, "device %d out of range (%d visible)", device, n);
-  HIPCHK(hipSetDevice(device));
+// Everything a context keeps on its device.  `c` is not yet visible to any other thread; the caller has the device bound.
+static int ctx_build(Context &c, int device) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
-  g.num_cus = prop.multiProcessorCount;
+  c.device = device;
+  c.num_cus = prop.multiProcessorCount;
   build_host_luts();
   for (int t = 0; t < 3; ++t) {
     // {table[i], table[i+1]-table[i]}: the subtraction of lookup() (color_conversions.rs:112) hoisted
     std::vector<float> pairs(2 * 8192);
-    for (int i = 0; i < 8192; ++i) { pairs[2 * i] = g.lut_host[t][i]; pairs[2 * i + 1] = g.lut_host[t][i + 1] - g.lut_host[t][i]; }
-    HIPCHK(hipMalloc(&g.lut_pairs[t], pairs.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(g.lut_pairs[t], pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&g.lut_plain[t], ipk::kLutLen * sizeof(float)));
-    HIPCHK(hipMemcpy(g.lut_plain[t], g.lut_host[t].data(), ipk::kLutLen * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < 8192; ++i) { pairs[2 * i] = g_host.lut_host[t][i]; pairs[2 * i + 1] = g_host.lut_host[t][i + 1] - g_host.lut_host[t][i]; }
+    HIPCHK(hipMalloc(&c.lut_pairs[t], pairs.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(c.lut_pairs[t], pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c.lut_plain[t], ipk::kLutLen * sizeof(float)));
+    HIPCHK(hipMemcpy(c.lut_plain[t], g_host.lut_host[t].data(), ipk::kLutLen * sizeof(float), hipMemcpyHostToDevice));
   }
-  // the row-walking kernels' task-queue heads, one block for all streams (nothing is allocated at launch time, so launches can be captured)
-  if (!ipk::init_task_counters()) return fail(IPK_ERR_HIP, "task queue allocation failed");
-  g.device = device;
-  g.ready = true;
+  // the row-walking kernels' task-queue heads, one block for all streams of this context (nothing is allocated at launch time, so launches can be captured)
+  c.queues = ipk::create_task_queues();
+  if (!c.queues) return fail(IPK_ERR_HIP, "task queue allocation failed");
   // The device's cbrtf reproduces glibc 2.35's routine; the lookup tables above and a reference built on THIS host use this host's libm.
   // If the two disagree (another libc, a newer glibc with a correctly rounded cbrtf) results stay deterministic but are no longer
   // bit-identical to that reference for Lab ratios above 1: checked here on 65 536 arguments spread over (1, 8) and reported through
@@ -357,45 +426,177 @@ int ipk_init(int device) {
     std::vector<float> in(n), out(n);
     for (size_t i = 0; i < n; ++i) { const uint32_t bits = 0x3F800001u + (uint32_t)((i * 0x017FFFFFull) / n); std::memcpy(&in[i], &bits, 4); }   // (1, 8)
     void *din = nullptr, *dout = nullptr;
-    g.libm_matches = -1;
+    c.libm_matches = -1;
     if (hipMalloc(&din, n * 4) == hipSuccess && hipMalloc(&dout, n * 4) == hipSuccess &&
         hipMemcpy(din, in.data(), n * 4, hipMemcpyHostToDevice) == hipSuccess) {
       ipk::launch_selftest_cbrt(static_cast<const float *>(din), static_cast<float *>(dout), n, 1, nullptr);
       if (hipMemcpy(out.data(), dout, n * 4, hipMemcpyDeviceToHost) == hipSuccess) {
         size_t bad = 0;
         for (size_t i = 0; i < n; ++i) { const float h = cbrtf(in[i]); bad += std::memcmp(&h, &out[i], 4) != 0; }
-        g.libm_matches = bad == 0 ? 1 : 0;
-        g.libm_mismatches = bad;
+        c.libm_matches = bad == 0 ? 1 : 0;
+        c.libm_mismatches = bad;
       }
     }
     if (din) (void)hipFree(din);
     if (dout) (void)hipFree(dout);
   }
+  c.ready = true;
+  return IPK_OK;
+}
+// releases what ctx_build and later calls put on the device; the object itself stays in the registry (dead)
+static void ctx_release(Context &c) {
+  if (c.device < 0) return;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (hipSetDevice(c.device) != hipSuccess) { (void)hipGetLastError(); return; }
+  c.ready = false;
+  // only this context's work has to be over: its lanes, its batch stream and whatever its callers enqueued (their streams are theirs to drain
+  // before destroying a context -- the device-wide wait below is the backstop, as it was for ipk_shutdown)
+  (void)hipDeviceSynchronize();
+  for (int t = 0; t < 3; ++t) { if (c.lut_pairs[t]) (void)hipFree(c.lut_pairs[t]); c.lut_pairs[t] = nullptr; if (c.lut_plain[t]) (void)hipFree(c.lut_plain[t]); c.lut_plain[t] = nullptr; }
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (auto &kv : c.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); if (kv.second.gen_cells) (void)hipFree(kv.second.gen_cells); }
+    c.cfa_cache.clear();
+    for (auto &kv : c.rot_cells) (void)hipFree(kv.second);
+    c.rot_cells.clear();
+    for (auto &b : c.pool) (void)hipFree(b.p);
+    c.pool.clear();
+  }
+  { std::lock_guard<std::mutex> lk(c.lanes.mu); c.lanes.release(); }
+  if (c.multi_stream) { (void)hipStreamDestroy(c.multi_stream); c.multi_stream = nullptr; }
+  ipk::destroy_task_queues(c.queues); c.queues = nullptr;
+  c.num_cus = 0;
+  if (prev >= 0 && prev != c.device) (void)hipSetDevice(prev);
+}
+static int ctx_create_locked(int device, Context **out) {      // g_reg_mu held
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(IPK_ERR_NO_DEVICE, "no HIP device visible"); }
+  if (device < 0 || device >= n) return fail(IPK_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+  HIPCHK(hipSetDevice(device));
+  std::unique_ptr<Context> c(new Context);
+  const int rc = ctx_build(*c, device);
+  if (rc) { ctx_release(*c); return rc; }
+  *out = c.get();
+  g_registry.push_back(std::move(c));
+  return IPK_OK;
+}
+static bool ctx_known_locked(const Context *c) {
+  for (const auto &p : g_registry) if (p.get() == c) return true;
+  return false;
+}
+
+int ipk_init(int device) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  { Context *d0 = g_default.load(); if (d0 && d0->ready && d0->device == device) return IPK_OK; }
+  Context *c = nullptr;
+  const int rc = ctx_create_locked(device, &c);
+  if (rc) return rc;
+  // re-initialising on another device replaces the process default; the old default goes unless the device set still uses it
+  Context *old = g_default.load();
+  g_default = c;
+  if (old && old->ready && std::find(g_devset.begin(), g_devset.end(), old) == g_devset.end()) { ctx_release(*old); (void)bind_device(device); }
   return IPK_OK;
 }
 int ipk_host_libm_matches(size_t *mismatches_of_65536) {
-  if (!g.ready) return fail(IPK_ERR_NOT_INIT, "ipk_init() has not succeeded");
-  if (mismatches_of_65536) *mismatches_of_65536 = g.libm_mismatches;
-  return g.libm_matches;
+  if (!cx().ready) return fail(IPK_ERR_NOT_INIT, "ipk_init() has not succeeded");
+  if (mismatches_of_65536) *mismatches_of_65536 = cx().libm_mismatches;
+  return cx().libm_matches;
 }
-
-namespace { void host_lanes_release(); }   // the host-pointer driver's streams and device slots (defined with HostLanes below)
 
 void ipk_shutdown(void) {
-  if (!g.ready) return;
-  (void)hipDeviceSynchronize();
-  for (int t = 0; t < 3; ++t) { if (g.lut_pairs[t]) (void)hipFree(g.lut_pairs[t]); g.lut_pairs[t] = nullptr; if (g.lut_plain[t]) (void)hipFree(g.lut_plain[t]); g.lut_plain[t] = nullptr; }
-  for (auto &kv : g.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); if (kv.second.gen_cells) (void)hipFree(kv.second.gen_cells); }
-  g.cfa_cache.clear();
-  for (auto &kv : g.rot_cells) (void)hipFree(kv.second);
-  g.rot_cells.clear();
-  for (auto &b : g.pool) (void)hipFree(b.p);
-  g.pool.clear();
-  host_lanes_release();
-  ipk::release_task_counters();
-  g.ready = false; g.device = -1; g.num_cus = 0;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (auto &c : g_registry) if (c->ready) ctx_release(*c);
+  g_default = nullptr;
+  g_devset.clear();
+  t_current = nullptr;
 }
-int ipk_is_initialized(void) { return g.ready ? 1 : 0; }
+int ipk_is_initialized(void) { return cx().ready ? 1 : 0; }
+
+// ---- contexts (several devices from one process) ------------------------------------------------------------------------------
+int ipk_ctx_create(int device, ipk_ctx **out) {
+  if (!out) return fail(IPK_ERR_INVALID, "null output");
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  int prev = -1; (void)hipGetDevice(&prev);
+  const int rc = ctx_create_locked(device, out);
+  // creating a context does not move the calling thread: its current context (and that context's device) stay what they were
+  if (prev >= 0) (void)hipSetDevice(prev);
+  (void)hipGetLastError();
+  return rc;
+}
+int ipk_ctx_destroy(ipk_ctx *ctx) {
+  if (!ctx) return IPK_OK;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  if (!ctx_known_locked(ctx)) return fail(IPK_ERR_INVALID, "not a context of this library");
+  if (ctx->ready) ctx_release(*ctx);
+  if (g_default.load() == ctx) g_default = nullptr;
+  g_devset.erase(std::remove(g_devset.begin(), g_devset.end(), ctx), g_devset.end());
+  if (t_current == ctx) t_current = nullptr;
+  return IPK_OK;
+}
+int ipk_ctx_make_current(ipk_ctx *ctx) {
+  if (!ctx) { t_current = nullptr; return cx().ready ? bind_device(cx().device) : IPK_OK; }
+  { std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (!ctx_known_locked(ctx)) return fail(IPK_ERR_INVALID, "not a context of this library");
+    if (!ctx->ready) return fail(IPK_ERR_NOT_INIT, "the context has been destroyed"); }
+  t_current = ctx;
+  return bind_device(ctx->device);
+}
+ipk_ctx *ipk_ctx_current(void) { Context &c = cx(); return c.ready ? &c : nullptr; }
+int ipk_ctx_device(const ipk_ctx *ctx) { return (ctx && ctx->ready) ? ctx->device : -1; }
+
+int ipk_init_devices(const int *devices, int n) {
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) { (void)hipGetLastError(); return fail(IPK_ERR_NO_DEVICE, "no HIP device visible"); }
+  if (n < 0 || n > 64 || (n > 0 && !devices)) return fail(IPK_ERR_INVALID, "bad device list");
+  std::vector<int> want;
+  if (n == 0) for (int i = 0; i < visible; ++i) want.push_back(i);       // every visible device
+  else want.assign(devices, devices + n);
+  for (int d : want) if (d < 0 || d >= visible) return fail(IPK_ERR_INVALID, "device %d out of range (%d visible)", d, visible);
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  int prev = -1; (void)hipGetDevice(&prev);
+  // the previous set goes (its contexts are released unless one is the process default)
+  Context *const dflt = g_default.load();
+  for (Context *c : g_devset) if (c != dflt && c->ready) ctx_release(*c);
+  g_devset.clear();
+  int rc = IPK_OK;
+  for (size_t i = 0; i < want.size() && rc == IPK_OK; ++i) {
+    Context *c = nullptr;
+    // the process default serves its own device's first entry: a caller of ipk_init(0) + ipk_init_devices({0..7}) has eight contexts, not nine
+    if (dflt && dflt->ready && dflt->device == want[i] && std::find(g_devset.begin(), g_devset.end(), dflt) == g_devset.end()) c = dflt;
+    else rc = ctx_create_locked(want[i], &c);
+    if (rc == IPK_OK) g_devset.push_back(c);
+  }
+  if (rc != IPK_OK) {
+    for (Context *c : g_devset) if (c != dflt && c->ready) ctx_release(*c);
+    g_devset.clear();
+  } else if (!dflt || !dflt->ready) {
+    g_default = g_devset[0];                                             // ipk_init_devices alone is a complete initialisation
+  }
+  { Context *d1 = g_default.load();
+    if (d1 && d1->ready && !t_current) (void)hipSetDevice(d1->device);
+    else if (prev >= 0) (void)hipSetDevice(prev); }
+  (void)hipGetLastError();
+  return rc;
+}
+int ipk_device_set_size(void) { std::lock_guard<std::mutex> lk(g_reg_mu); return (int)g_devset.size(); }
+ipk_ctx *ipk_device_ctx(int index) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  return (index >= 0 && (size_t)index < g_devset.size()) ? g_devset[(size_t)index] : nullptr;
+}
+// The dealing rule of the multi-device batch entry points, as arithmetic a caller (and the CPU tests) can ask for: frame i of n goes to set
+// member i mod n_devices, so member `index` gets frames index, index + n_devices, ... -- *count of them.  Frames are independent pipelines
+// (src/pipeline.rs:246-249): nothing else is shared out.
+int ipk_deal_frames(size_t n_frames, int n_devices, int index, size_t *first, size_t *stride, size_t *count) {
+  if (n_devices < 1 || index < 0 || index >= n_devices) return fail(IPK_ERR_INVALID, "bad device index %d of %d", index, n_devices);
+  const size_t nd = (size_t)n_devices, ix = (size_t)index;
+  if (first) *first = ix;
+  if (stride) *stride = nd;
+  if (count) *count = n_frames > ix ? (n_frames - ix + nd - 1) / nd : 0;
+  return IPK_OK;
+}
+
 // the layout this library was built with, for bindings to check theirs against (no GPU needed)
 size_t ipk_abi_sizeof(int which) {
   switch (which) {
@@ -411,7 +612,7 @@ size_t ipk_abi_sizeof(int which) {
   }
 }
 const char *ipk_last_error(void) { return g_err; }
-int ipk_device_cus(void) { return g.num_cus; }
+int ipk_device_cus(void) { return cx().num_cus; }
 
 int ipk_malloc(void **dptr, size_t bytes) { REQUIRE_INIT(); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return IPK_OK; }
 int ipk_free(void *dptr) { REQUIRE_INIT(); HIPCHK(hipFree(dptr)); return IPK_OK; }
@@ -426,7 +627,7 @@ int ipk_stream_sync(void *stream) { REQUIRE_INIT(); HIPCHK(hipStreamSynchronize(
 int ipk_lut_table(int which, float *out8193) {
   if (which < 0 || which > 2 || !out8193) return fail(IPK_ERR_INVALID, "bad table id");
   build_host_luts();
-  std::memcpy(out8193, g.lut_host[which].data(), ipk::kLutLen * sizeof(float));
+  std::memcpy(out8193, g_host.lut_host[which].data(), ipk::kLutLen * sizeof(float));
   return IPK_OK;
 }
 
@@ -525,7 +726,7 @@ int ipk_gofloat_rgb_f32(const float *src, size_t owidth, size_t x, size_t y, siz
   GOFLOAT_ARGS_OK(); ipk::launch_gofloat_rgb<float>(src, owidth, x, y, width, height, black4, white4, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
 }
 int ipk_gofloat_other_u8(const uint8_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float *dst, void *stream) {
-  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_other_u8(src, owidth, x, y, width, height, g.lut_pairs[ipk::kLutGammaReverse], dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+  GOFLOAT_ARGS_OK(); ipk::launch_gofloat_other_u8(src, owidth, x, y, width, height, cx().lut_pairs[ipk::kLutGammaReverse], dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
 }
 int ipk_gofloat_other_u16(const uint16_t *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float *dst, void *stream) {
   GOFLOAT_ARGS_OK(); ipk::launch_gofloat_other_u16(src, owidth, x, y, width, height, dst, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
@@ -545,9 +746,9 @@ int ipk_demosaic_full_band(const float *src, size_t width, size_t img_height, si
   int xoff, yoff;
   int lrc = 0;
   if (cfa.bayer_phase(xoff, yoff))       // the four RGGB phases: row-walking kernel (coalesced loads, register window, staged stores)
-    lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, nullptr, 0, 0, dst4, g.num_cus, S(stream));
+    lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, xoff, yoff, nullptr, 0, 0, dst4, cx().num_cus, cx().queues, S(stream));
   else if (dev.gen_cells)                // any other three-colour filter (X-Trans ...): same kernel, generic-CFA mode
-    lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, 0, 0, dev.gen_cells, dev.gen_pw, dev.gen_ph, dst4, g.num_cus, S(stream));
+    lrc = ipk::launch_demosaic_bayer(src, width, img_height, src_row0, out_row0, out_rows, 0, 0, dev.gen_cells, dev.gen_pw, dev.gen_ph, dst4, cx().num_cus, cx().queues, S(stream));
   else ipk::launch_demosaic_full(src, width, img_height, src_row0, out_row0, out_rows, dev.lookups, dst4, S(stream));
   if (lrc) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued)");
   HIPCHK(hipGetLastError());
@@ -634,7 +835,7 @@ int ipk_raster_scale_down(const void *src, int src_type, size_t owidth, size_t x
   if (!src || !dst4 || !dims_ok(width, height) || !dims_ok(nwidth, nheight) || (src_type != IPK_SRC_RGB8 && src_type != IPK_SRC_RGB16))
     return fail(IPK_ERR_INVALID, "bad raster_scale_down arguments");
   if (x + width > owidth) return fail(IPK_ERR_INVALID, "raster_scale_down: window wider than the source pitch");
-  ipk::launch_raster_scale_down(src, src_type == IPK_SRC_RGB16, owidth, x, y, width, height, nwidth, nheight, g.lut_pairs[ipk::kLutGammaReverse],
+  ipk::launch_raster_scale_down(src, src_type == IPK_SRC_RGB16, owidth, x, y, width, height, nwidth, nheight, cx().lut_pairs[ipk::kLutGammaReverse],
                                 dst4, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
@@ -694,11 +895,11 @@ int ipk_tolab(const float *src4, size_t width, size_t height, int monochrome, co
   if (ok && width * height >= 256) {
     ipk::FusedLaunch f;
     std::memset(&f, 0, sizeof(f));
-    f.src = src4; f.dst = dst3; f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33; f.fast_ok = 1; f.has_curve = 0; f.linear = 1;
-    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma]; f.num_cus = g.num_cus;
+    f.src = src4; f.dst = dst3; f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g_host.xyz_d65_33; f.fast_ok = 1; f.has_curve = 0; f.linear = 1;
+    f.lab_table = cx().lut_plain[ipk::kLutXyzLab]; f.gam_table = cx().lut_plain[ipk::kLutGamma]; f.lab_pairs = cx().lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = cx().lut_pairs[ipk::kLutGamma]; f.num_cus = cx().num_cus;
     ipk::launch_tolab_fast(f, width * height, S(stream));
   } else {
-    ipk::launch_tolab(src4, width * height, mul, cm, g.lut_pairs[ipk::kLutXyzLab], dst3, g.num_cus, S(stream));
+    ipk::launch_tolab(src4, width * height, mul, cm, cx().lut_pairs[ipk::kLutXyzLab], dst3, cx().num_cus, S(stream));
   }
   HIPCHK(hipGetLastError());
   return IPK_OK;
@@ -720,14 +921,14 @@ int ipk_basecurve(const float *src3, size_t width, size_t height, float exposure
   if (curve_is_noop(exposure, npoints)) return IPK_NOOP;
   if (!src3 || !dst3 || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad basecurve arguments");
   ipk::Spline sp; int rc = build_curve(exposure, points, npoints, sp); if (rc) return rc;
-  ipk::launch_basecurve(src3, width * height, sp, dst3, g.num_cus, S(stream));
+  ipk::launch_basecurve(src3, width * height, sp, dst3, cx().num_cus, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
 int ipk_fromlab(const float *src3, size_t width, size_t height, float *dst3, void *stream) {
   REQUIRE_INIT();
   if (!src3 || !dst3 || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad fromlab arguments");
-  ipk::launch_fromlab(src3, width * height, g.xyz_d65_33, dst3, g.num_cus, S(stream));
+  ipk::launch_fromlab(src3, width * height, g_host.xyz_d65_33, dst3, cx().num_cus, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
@@ -735,7 +936,7 @@ int ipk_gamma(const float *src, size_t width, size_t height, size_t colors, int 
   REQUIRE_INIT();
   if (linear) return IPK_NOOP;                                                                             // gamma.rs:17-18
   if (!src || !dst || !dims_ok(width, height) || colors < 1) return fail(IPK_ERR_INVALID, "bad gamma arguments");
-  ipk::launch_gamma(src, width * height * colors, g.lut_pairs[ipk::kLutGamma], dst, g.num_cus, S(stream));
+  ipk::launch_gamma(src, width * height * colors, cx().lut_pairs[ipk::kLutGamma], dst, cx().num_cus, S(stream));
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
@@ -760,11 +961,11 @@ int ipk_transform(const float *src3, size_t width, size_t height, int rotation, 
 }
 int ipk_output8bit(const float *src, size_t n, uint8_t *dst, void *stream) {
   REQUIRE_INIT(); if (!src || !dst) return fail(IPK_ERR_INVALID, "null buffer");
-  ipk::launch_output8(src, n, dst, g.num_cus, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+  ipk::launch_output8(src, n, dst, cx().num_cus, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
 }
 int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *stream) {
   REQUIRE_INIT(); if (!src || !dst) return fail(IPK_ERR_INVALID, "null buffer");
-  ipk::launch_output16(src, n, dst, g.num_cus, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
+  ipk::launch_output16(src, n, dst, cx().num_cus, S(stream)); HIPCHK(hipGetLastError()); return IPK_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -779,9 +980,9 @@ static int get_rot_cells(const char *pat, const ipk::Cfa &cfa, int ori, size_t w
   const int pw = cfa.width, ph = cfa.height;
   char key[160];
   snprintf(key, sizeof(key), "%s|%d|%d|%d", pat, ori, (int)(width % (size_t)pw), (int)(height % (size_t)ph));
-  std::lock_guard<std::mutex> lk(g.mu);
-  auto it = g.rot_cells.find(key);
-  if (it != g.rot_cells.end()) { *out = it->second; return IPK_OK; }
+  std::lock_guard<std::mutex> lk(cx().mu);
+  auto it = cx().rot_cells.find(key);
+  if (it != cx().rot_cells.end()) { *out = it->second; return IPK_OK; }
   std::vector<float> cells;
   if (!cfa.gen_cells(cells)) return fail(IPK_ERR_UNSUPPORTED, "CFA has a fourth colour");
   const int rpw = t ? ph : pw, rph = t ? pw : ph;          // rotated pattern: width follows the sensor rows when transposed
@@ -796,7 +997,7 @@ static int get_rot_cells(const char *pat, const ipk::Cfa &cfa, int ori, size_t w
   float *dev = nullptr;
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&dev), rot.size() * sizeof(float)));
   HIPCHK(hipMemcpy(dev, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice));
-  g.rot_cells[key] = dev;
+  cx().rot_cells[key] = dev;
   *out = dev;
   return IPK_OK;
 }
@@ -893,7 +1094,7 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.gen_check = (!bayer && f.src_is_u16 && !gen_levels_ok_u16(p->black0, p->white0 - p->black0)) ? 1 : 0;
   float mul[4];
   ipk::normalize_wbs(p->wb_coeffs, mul);                                                                   // colorspaces.rs:100
-  f.mul4 = mul; f.cm12 = p->cam_to_xyz_normalized; f.rgbm9 = g.xyz_d65_33;
+  f.mul4 = mul; f.cm12 = p->cam_to_xyz_normalized; f.rgbm9 = g_host.xyz_d65_33;
   // the fast point-wise form assumes finite, ordinary parameters (see pointwise4_fast): |value| <= 2^20, no NaN/inf
   {
     auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };        // false for NaN and inf
@@ -921,8 +1122,8 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.spline = &sp;
   f.linear = p->linear;
   f.out_type = probe ? 4 : p->out_type;
-  f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma];
-  f.num_cus = g.num_cus;
+  f.lab_table = cx().lut_plain[ipk::kLutXyzLab]; f.gam_table = cx().lut_plain[ipk::kLutGamma]; f.lab_pairs = cx().lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = cx().lut_pairs[ipk::kLutGamma];
+  f.num_cus = cx().num_cus; f.queues = cx().queues;
   { const int lrc = ipk::launch_fused_bayer(f, S(stream));
     if (lrc == -4) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued; the stream's task queue is untouched)");
     if (lrc != 0) return fail(IPK_ERR_UNSUPPORTED, probe ? "the stream probe exists for Bayer frames of 256+ columns with validated levels" : "no rotated-space variant for these parameters"); }
@@ -933,6 +1134,7 @@ int ipk_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst, void 
 // Measurement aid: the fused kernel's memory skeleton (its launch, task walk, row loads, OpGoFloat, demosaic::full, LDS staging, nontemporal stores) without
 // the point-wise stages -- dst receives the demosaiced R, G, B as width*rows*3 f32.  bench.py times it next to ipk_raw_to_srgb (roofline.ceiling_ms).
 int ipk_stream_probe(const ipk_fused_params *p, const void *src, void *dst, void *stream) {
+  IPK_FOLD_CFA(ipk_fused_params, p)
   if (p && p->band_out_rows != 0) return fail(IPK_ERR_INVALID, "the stream probe takes whole frames");
   return fused_impl(p, src, dst, stream, 0, 0, nullptr, nullptr, true);
 }
@@ -942,11 +1144,13 @@ int ipk_raw_to_srgb_batch(const ipk_fused_params *p, const void *const *srcs, vo
   if (!p || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
   if (n == 0) return IPK_OK;
   if (n > (size_t)1 << 20) return fail(IPK_ERR_INVALID, "batch too large");
+  IPK_FOLD_CFA(ipk_fused_params, p)
   if (p->band_out_rows != 0) return fail(IPK_ERR_INVALID, "a batch takes whole frames, not bands");
   return fused_impl(p, srcs[0], dsts[0], stream, 0, n, srcs, dsts);
 }
 int ipk_raw_to_srgb_oriented(const ipk_fused_params *p, const void *src, int orientation, void *dst, size_t *out_width, size_t *out_height, void *stream) {
   if (!p || !out_width || !out_height) return fail(IPK_ERR_INVALID, "null argument");
+  IPK_FOLD_CFA(ipk_fused_params, p)
   if (orientation == IPK_OR_NORMAL || orientation == IPK_OR_UNKNOWN) { *out_width = p->width; *out_height = p->height; return fused_impl(p, src, dst, stream, 0); }
   if (orientation < 0 || orientation > 8) return fail(IPK_ERR_INVALID, "bad orientation");
   { bool t, fx, fy; ipk::orientation_to_flips(orientation, t, fx, fy); *out_width = t ? p->height : p->width; *out_height = t ? p->width : p->height; }
@@ -968,7 +1172,7 @@ struct PointwisePrep {
     if (monochrome) { ipk::srgb_d65_43(cm); mul[0] = mul[1] = mul[2] = mul[3] = 1.0f; }                     // colorspaces.rs:90-101
     else { std::memcpy(cm, cam_to_xyz_normalized, sizeof(cm)); ipk::normalize_wbs(wb_coeffs, mul); }
     std::memset(&f, 0, sizeof(f));
-    f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g.xyz_d65_33;
+    f.mul4 = mul; f.cm12 = cm; f.rgbm9 = g_host.xyz_d65_33;
     auto sane = [](float v) { return std::fabs(v) <= 0x1p20f; };
     bool ok = true;
     for (int i = 0; i < 4; ++i) ok = ok && sane(mul[i]);
@@ -982,8 +1186,8 @@ struct PointwisePrep {
     }
     f.spline = &sp;
     f.linear = linear;
-    f.lab_table = g.lut_plain[ipk::kLutXyzLab]; f.gam_table = g.lut_plain[ipk::kLutGamma]; f.lab_pairs = g.lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = g.lut_pairs[ipk::kLutGamma];
-    f.num_cus = g.num_cus;
+    f.lab_table = cx().lut_plain[ipk::kLutXyzLab]; f.gam_table = cx().lut_plain[ipk::kLutGamma]; f.lab_pairs = cx().lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = cx().lut_pairs[ipk::kLutGamma];
+    f.num_cus = cx().num_cus;
     return IPK_OK;
   }
 };
@@ -1011,7 +1215,7 @@ int ipk_raster_to_srgb(const void *src, int src_type, size_t width, size_t heigh
   PointwisePrep pp;
   int rc = pp.prepare(0, wb_coeffs, cam_to_xyz_normalized, exposure, points, npoints, linear); if (rc) return rc;
   pp.f.src = src; pp.f.dst = dst; pp.f.out_type = out_type;
-  if (ipk::launch_raster_chain(pp.f, width * height, src_type == IPK_SRC_RGB16, g.lut_pairs[ipk::kLutGammaReverse], S(stream)) != 0)
+  if (ipk::launch_raster_chain(pp.f, width * height, src_type == IPK_SRC_RGB16, cx().lut_pairs[ipk::kLutGammaReverse], S(stream)) != 0)
     return fail(IPK_ERR_UNSUPPORTED, "raster_to_srgb: frame too small");
   HIPCHK(hipGetLastError());
   return IPK_OK;
@@ -1057,7 +1261,7 @@ int ipk_selftest_clamp01(uint64_t *n_bad, uint32_t *first_bad_bits) {
 int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *stream) {
   REQUIRE_INIT();
   if (!src || !dst || (bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(IPK_ERR_INVALID, "ipk_copy_probe wants 16-byte aligned buffers and a multiple of 16 bytes");
-  ipk::launch_copy_probe(src, dst, bytes, g.num_cus, S(stream)); HIPCHK(hipGetLastError());
+  ipk::launch_copy_probe(src, dst, bytes, cx().num_cus, S(stream)); HIPCHK(hipGetLastError());
   return IPK_OK;
 }
 int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream) {
@@ -1157,6 +1361,9 @@ static bool default_ops_other(const ipk_pipeline_desc *d) {
 }
 int ipk_pipeline_takes_fastpath(const ipk_pipeline_desc *d, int out_type) {
   if (!d) return fail(IPK_ERR_INVALID, "null descriptor");
+  ipk_pipeline_desc taken;
+  { const int rc = take_desc(d, taken); if (rc) return rc; }
+  d = &taken;
   return (d->use_fastpath && (out_type == IPK_OUT_U8 || out_type == IPK_OUT_U16) && default_ops_other(d)) ? 1 : 0;
 }
 // output_8bit / output_16bit fast path (pipeline.rs:381-402, :428-449) on device buffers
@@ -1171,8 +1378,8 @@ static int run_fastpath(const ipk_pipeline_desc *d, const void *src, void *dst, 
   if (want16 != have16) {                                                  // to_rgb8 / to_rgb16
     void *conv = dst;
     if (scaled) { int rc = tmp.get(n * esz, &conv); if (rc) return rc; }
-    if (want16) ipk::launch_chan_8_to_16(static_cast<const uint8_t *>(src), n, static_cast<uint16_t *>(conv), g.num_cus, S(stream));
-    else ipk::launch_chan_16_to_8(static_cast<const uint16_t *>(src), n, static_cast<uint8_t *>(conv), g.num_cus, S(stream));
+    if (want16) ipk::launch_chan_8_to_16(static_cast<const uint8_t *>(src), n, static_cast<uint16_t *>(conv), cx().num_cus, S(stream));
+    else ipk::launch_chan_16_to_8(static_cast<const uint16_t *>(src), n, static_cast<uint8_t *>(conv), cx().num_cus, S(stream));
     HIPCHK(hipGetLastError());
     rgb = conv;
   }
@@ -1268,6 +1475,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
     if (scale <= 1.0f && ipk::Cfa::parse(d->cfa, cfa) && (cfa.bayer_phase(xo, yo) || cfa.three_colour())) {
       ipk_fused_params fp;
       std::memset(&fp, 0, sizeof(fp));
+      fp.struct_size = (uint32_t)sizeof(fp);
       fp.src_type = d->src_type; fp.owidth = d->width; fp.x = r.x; fp.y = r.y; fp.width = r.width; fp.height = r.height;
       fp.black0 = d->blacklevels[0]; fp.white0 = d->whitelevels[0];
       std::memcpy(fp.cfa, d->cfa, sizeof(fp.cfa));
@@ -1563,18 +1771,27 @@ int ipk_pipeline_hashes(const ipk_pipeline_desc *d, int out_type, uint64_t sourc
   return IPK_OK;
 }
 
+// the cached buffers' users run on the owner's device: drain THAT device (whatever context the calling thread has current) before they are freed
+static void cache_drain(ipk_cache *c) {
+  ipk_ctx *o = c->owner ? c->owner : ipk_ctx_current();
+  if (!o || !o->ready) return;
+  int prev = -1; (void)hipGetDevice(&prev);
+  if (prev != o->device) (void)hipSetDevice(o->device);
+  (void)hipDeviceSynchronize();
+  if (prev >= 0 && prev != o->device) (void)hipSetDevice(prev);
+}
 int ipk_cache_new(size_t max_bytes, ipk_cache **out) {
   if (!out) return fail(IPK_ERR_INVALID, "null output");
-  *out = new ipk_cache(max_bytes);
+  *out = new ipk_cache(max_bytes, ipk_ctx_current());
   return IPK_OK;
 }
 int ipk_cache_free(ipk_cache *c) {
-  if (c) { if (g.ready) (void)hipDeviceSynchronize(); delete c; }
+  if (c) { cache_drain(c); delete c; }
   return IPK_OK;
 }
 int ipk_cache_clear(ipk_cache *c) {
   if (!c) return fail(IPK_ERR_INVALID, "null cache");
-  if (g.ready) (void)hipDeviceSynchronize();
+  cache_drain(c);
   c->lru.clear();
   return IPK_OK;
 }
@@ -1609,6 +1826,8 @@ int ipk_pipeline_run_cached(const ipk_pipeline_desc *d, const void *src, uint64_
                             int *ops_run, int *used_fused, void *stream) {
   REQUIRE_INIT();
   if (!d || !src || !dst || !cache) return fail(IPK_ERR_INVALID, "null argument");
+  if (!cache->owner) cache->owner = ipk_ctx_current();                   // a cache made before ipk_init belongs to the first context that fills it
+  if (cache->owner != ipk_ctx_current()) return fail(IPK_ERR_INVALID, "the cache belongs to another context (its buffers live on that context's device)");
   IPK_FOLD_CFA(ipk_pipeline_desc, d)
   if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
   if (ipk_pipeline_takes_fastpath(d, out_type) == 1) {                    // returns before the cache is consulted (pipeline.rs:381-402)
@@ -1778,56 +1997,189 @@ int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst
 }
 void *ipk_host_alloc(size_t bytes) {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return p;
 }
 void ipk_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 namespace {
-// The streams, events and device slots of the host-pointer pipeline driver.  One set per process, grown on demand and kept
-// between calls (a fresh hipMalloc of two input and two output slots costs more than moving a frame), released by ipk_shutdown.
-struct HostLanes {
-  static constexpr int kSlots = 2;
-  std::mutex mu;                                  // one host-pointer pipeline call at a time
-  hipStream_t up = nullptr, run = nullptr, down = nullptr;
-  hipEvent_t up_done[kSlots] = {}, run_done[kSlots] = {}, down_done[kSlots] = {};
-  void *in[kSlots] = {}, *out[kSlots] = {};
-  size_t in_cap = 0, out_cap = 0;
-  bool made = false;
-  int ensure(size_t in_bytes, size_t out_bytes) {
-    if (!made) {
-      for (hipStream_t *s : {&up, &run, &down}) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-      for (int i = 0; i < kSlots; ++i)
-        for (hipEvent_t *e : {&up_done[i], &run_done[i], &down_done[i]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-      made = true;
-    }
-    if (in_bytes > in_cap) {
-      for (int i = 0; i < kSlots; ++i) { if (in[i]) (void)hipFree(in[i]); in[i] = nullptr; }
-      in_cap = 0;
-      for (int i = 0; i < kSlots; ++i) if (hipMalloc(&in[i], in_bytes) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", in_bytes);
-      in_cap = in_bytes;
-    }
-    if (out_bytes > out_cap) {
-      for (int i = 0; i < kSlots; ++i) { if (out[i]) (void)hipFree(out[i]); out[i] = nullptr; }
-      out_cap = 0;
-      for (int i = 0; i < kSlots; ++i) if (hipMalloc(&out[i], out_bytes) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", out_bytes);
-      out_cap = out_bytes;
-    }
-    return IPK_OK;
+int HostLanes::ensure(size_t in_bytes, size_t out_bytes) {
+  if (!made) {
+    for (hipStream_t *s : {&up, &run, &down}) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (int i = 0; i < kSlots; ++i)
+      for (hipEvent_t *e : {&up_done[i], &run_done[i], &down_done[i]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    made = true;
   }
-  void release() {
-    for (hipStream_t *s : {&up, &run, &down}) if (*s) { (void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr; }
-    for (int i = 0; i < kSlots; ++i) {
-      for (hipEvent_t *e : {&up_done[i], &run_done[i], &down_done[i]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-      if (in[i]) (void)hipFree(in[i]); if (out[i]) (void)hipFree(out[i]);
-      in[i] = out[i] = nullptr;
-    }
-    in_cap = out_cap = 0; made = false;
+  if (in_bytes > in_cap) {
+    for (int i = 0; i < kSlots; ++i) { if (in[i]) (void)hipFree(in[i]); in[i] = nullptr; }
+    in_cap = 0;
+    for (int i = 0; i < kSlots; ++i) if (hipMalloc(&in[i], in_bytes) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", in_bytes);
+    in_cap = in_bytes;
   }
-};
-HostLanes g_lanes;
-void host_lanes_release() { std::lock_guard<std::mutex> lk(g_lanes.mu); g_lanes.release(); }
+  if (out_bytes > out_cap) {
+    for (int i = 0; i < kSlots; ++i) { if (out[i]) (void)hipFree(out[i]); out[i] = nullptr; }
+    out_cap = 0;
+    for (int i = 0; i < kSlots; ++i) if (hipMalloc(&out[i], out_bytes) != hipSuccess) return fail(IPK_ERR_NOMEM, "hipMalloc(%zu) failed", out_bytes);
+    out_cap = out_bytes;
+  }
+  return IPK_OK;
+}
+void HostLanes::release() {
+  for (hipStream_t *s : {&up, &run, &down}) if (*s) { (void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr; }
+  for (int i = 0; i < kSlots; ++i) {
+    for (hipEvent_t *e : {&up_done[i], &run_done[i], &down_done[i]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    if (in[i]) (void)hipFree(in[i]); if (out[i]) (void)hipFree(out[i]);
+    in[i] = out[i] = nullptr;
+  }
+  in_cap = out_cap = 0; made = false;
+}
 }  // namespace
+
+// ------------------------------------------------------------------------------------------
+// A caller looping Pipeline::run over the frames of a shoot (src/pipeline.rs:246-249: frames are independent), device pointers
+// ------------------------------------------------------------------------------------------
+namespace {
+// Is Pipeline::run for this descriptor exactly one fused launch per frame with nothing in front of or behind it (the conditions of
+// ipk_pipeline_run's first branch, with OpTransform a no-op)?  Then a batch of such frames is one persistent launch per 64 (ipk_raw_to_srgb_batch).
+bool desc_is_one_fused_launch(const ipk_pipeline_desc *d, int out_type, ipk_fused_params &fp) {
+  size_t dw, dh, fw, fh;
+  if (pipeline_sizes_impl(d, &dw, &dh, &fw, &fh, nullptr) != IPK_OK) return false;
+  if (ipk_pipeline_takes_fastpath(d, out_type) == 1) return false;
+  ipk::Rect r;
+  if (!ipk::size_image(d->crop_top, d->crop_right, d->crop_bottom, d->crop_left, d->width, d->height, r)) return false;
+  const bool raw = d->src_type == IPK_SRC_U16 || d->src_type == IPK_SRC_F32;
+  const bool cfa_branch = raw && !(d->cpp == 1 && !d->is_cfa) && d->cpp != 3;
+  const int orientation = ipk::transform_orientation(d->rotation, d->fliph != 0, d->flipv != 0);
+  ipk::RotateCrop rcop;
+  rcop.crop_top = d->rotatecrop[0]; rcop.crop_right = d->rotatecrop[1]; rcop.crop_bottom = d->rotatecrop[2];
+  rcop.crop_left = d->rotatecrop[3]; rcop.rotation = d->rotatecrop[4];
+  if (!(d->allow_fused && cfa_branch && d->cpp == 1 && rcop.noop())) return false;
+  if (!(orientation == IPK_OR_NORMAL || orientation == IPK_OR_UNKNOWN)) return false;
+  if (ipk::calculate_scaling_total(r.width, r.height, dw, dh).scale > 1.0f) return false;
+  ipk::Cfa cfa; int xo, yo;
+  if (!ipk::Cfa::parse(d->cfa, cfa) || !(cfa.bayer_phase(xo, yo) || cfa.three_colour())) return false;
+  std::memset(&fp, 0, sizeof(fp));
+  fp.struct_size = (uint32_t)sizeof(fp);
+  fp.src_type = d->src_type; fp.owidth = d->width; fp.x = r.x; fp.y = r.y; fp.width = r.width; fp.height = r.height;
+  fp.black0 = d->blacklevels[0]; fp.white0 = d->whitelevels[0];
+  std::memcpy(fp.cfa, d->cfa, sizeof(fp.cfa));
+  std::memcpy(fp.wb_coeffs, d->wb_coeffs, sizeof(fp.wb_coeffs));
+  std::memcpy(fp.cam_to_xyz_normalized, d->cam_to_xyz_normalized, sizeof(fp.cam_to_xyz_normalized));
+  fp.exposure = d->exposure; fp.npoints = d->npoints; std::memcpy(fp.points, d->points, sizeof(fp.points));
+  fp.linear = out_type == IPK_OUT_U8 ? 0 : (out_type == IPK_OUT_U16 ? 1 : d->linear);   // pipeline.rs:405, :452
+  fp.out_type = out_type;
+  return true;
+}
+}  // namespace
+
+int ipk_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type, int *used_fused, void *stream) {
+  REQUIRE_INIT();
+  if (!d || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
+  if (out_type < 0 || out_type > 2) return fail(IPK_ERR_INVALID, "bad out_type");
+  IPK_FOLD_CFA(ipk_pipeline_desc, d)
+  if (d->npoints < 0 || d->npoints > 64) return fail(IPK_ERR_INVALID, "npoints out of range");
+  for (size_t i = 0; i < n; ++i) if (!srcs[i] || !dsts[i]) return fail(IPK_ERR_INVALID, "null frame pointer at index %zu", i);
+  if (used_fused) *used_fused = 0;
+  if (n == 0) return IPK_OK;
+  ipk_fused_params fp;
+  if (n > 1 && desc_is_one_fused_launch(d, out_type, fp)) {
+    const int rc = ipk_raw_to_srgb_batch(&fp, srcs, dsts, n, stream);
+    if (rc == IPK_OK && used_fused) *used_fused = 1;
+    return rc;
+  }
+  for (size_t i = 0; i < n; ++i) { const int rc = ipk_pipeline_run(d, srcs[i], dsts[i], out_type, used_fused, stream); if (rc < 0) return rc; }
+  return IPK_OK;
+}
+
+// ---- the same over the process's device set: frame i -> set member i mod N, from ONE host thread (launches are asynchronous) -------------
+namespace {
+void devset_snapshot(std::vector<Context *> &v) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  v = g_devset;
+  if (v.empty() && cx().ready) v.push_back(&cx());      // no set: the current context alone
+}
+struct CurrentGuard {                                    // puts the calling thread's current context (and its device) back
+  Context *saved = t_current;
+  ~CurrentGuard() { t_current = saved; if (cx().ready) (void)hipSetDevice(cx().device); }
+};
+}  // namespace
+
+int ipk_pipeline_run_batch_multi(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type, int *used_fused) {
+  REQUIRE_INIT();
+  if (!d || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
+  std::vector<Context *> set; devset_snapshot(set);
+  const size_t nd = set.size();
+  CurrentGuard guard;
+  int fused_all = 1;
+  for (size_t k = 0; k < nd; ++k) {
+    std::vector<const void *> s; std::vector<void *> o;
+    for (size_t i = k; i < n; i += nd) { s.push_back(srcs[i]); o.push_back(dsts[i]); }
+    if (s.empty()) continue;
+    if (!set[k]->ready) return fail(IPK_ERR_NOT_INIT, "device-set member %zu has been destroyed", k);
+    t_current = set[k];
+    { int rc = bind_device(set[k]->device); if (rc) return rc; }
+    if (!set[k]->multi_stream) HIPCHK(hipStreamCreateWithFlags(&set[k]->multi_stream, hipStreamNonBlocking));
+    int fused = 0;
+    const int rc = ipk_pipeline_run_batch(d, s.data(), o.data(), s.size(), out_type, &fused, set[k]->multi_stream);
+    if (rc < 0) return rc;
+    fused_all = fused_all && fused;
+  }
+  if (used_fused) *used_fused = n ? fused_all : 0;
+  return IPK_OK;
+}
+int ipk_devices_sync(void) {
+  REQUIRE_INIT();
+  std::vector<Context *> set; devset_snapshot(set);
+  CurrentGuard guard;
+  int rc = IPK_OK;
+  for (Context *c : set) {
+    if (!c->ready || !c->multi_stream) continue;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->multi_stream) != hipSuccess) {
+      rc = fail(IPK_ERR_HIP, "synchronising device %d failed: %s", c->device, hipGetErrorString(hipGetLastError()));
+    }
+  }
+  return rc;
+}
+
+// Host buffers in, host buffers out, over the device set: one host thread per member runs ipk_host_pipeline_run_batch on the frames dealt
+// to it (its own three streams and two device slots), so every GPU uploads, computes and downloads at the same time.  Synchronous at return,
+// like every ipk_host_* entry point.  The buffers should come from ipk_host_alloc (page-locked, visible to every device).
+int ipk_host_pipeline_run_batch_multi(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type, int *used_fused) {
+  REQUIRE_INIT();
+  if (!d || (n && (!srcs || !dsts))) return fail(IPK_ERR_INVALID, "null argument");
+  std::vector<Context *> set; devset_snapshot(set);
+  const size_t nd = set.size();
+  if (nd == 1) {
+    CurrentGuard guard;
+    t_current = set[0];
+    return ipk_host_pipeline_run_batch(d, srcs, dsts, n, out_type, used_fused);
+  }
+  struct Share { int rc = IPK_OK; int fused = 0; size_t frames = 0; std::string err; };
+  std::vector<Share> res(nd);
+  auto work = [&](size_t k) {
+    std::vector<const void *> s; std::vector<void *> o;
+    for (size_t i = k; i < n; i += nd) { s.push_back(srcs[i]); o.push_back(dsts[i]); }
+    res[k].frames = s.size();
+    if (s.empty()) return;
+    t_current = set[k];                                  // this worker thread's current context
+    res[k].rc = ipk_host_pipeline_run_batch(d, s.data(), o.data(), s.size(), out_type, &res[k].fused);
+    if (res[k].rc < 0) res[k].err = g_err;               // ipk_last_error() is per thread: hand the text to the caller's
+    t_current = nullptr;
+  };
+  {
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < nd; ++k) th.emplace_back(work, k);
+    { CurrentGuard guard; work(0); }                     // the caller's thread takes the first share
+    for (auto &t : th) t.join();
+  }
+  int fused_all = 1;
+  for (size_t k = 0; k < nd; ++k) {
+    if (res[k].rc < 0) return fail(res[k].rc, "device-set member %zu (device %d): %s", k, set[k]->device, res[k].err.c_str());
+    if (res[k].frames) fused_all = fused_all && res[k].fused;
+  }
+  if (used_fused) *used_fused = n ? fused_all : 0;
+  return IPK_OK;
+}
 
 int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type, int *used_fused) {
   REQUIRE_INIT();
@@ -1840,8 +2192,8 @@ int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *s
   const bool raw = d->src_type == IPK_SRC_U16 || d->src_type == IPK_SRC_F32;
   const size_t in_bytes = d->width * d->height * (raw ? (size_t)d->cpp : 3) * src_elem_size(d->src_type);
   const size_t out_bytes = fw * fh * 3 * out_elem_size(out_type);
-  std::lock_guard<std::mutex> lk(g_lanes.mu);
-  HostLanes &L = g_lanes;
+  HostLanes &L = cx().lanes;
+  std::lock_guard<std::mutex> lk(L.mu);
   HIPCHK(hipDeviceSynchronize());   // the lanes are non-blocking streams: nothing enqueued earlier (scratch-pool users on other streams) may still be running
   HOST_TRY(L.ensure(in_bytes, out_bytes));
   // one frame's enqueues; any failure stops the batch, and the lanes are drained in every case before the return (the
@@ -1952,6 +2304,7 @@ int ipk_host_output16bit(const float *src, size_t n, uint16_t *dst) {
 int ipk_host_raw_to_srgb(const ipk_fused_params *p, const void *src, void *dst) {
   REQUIRE_INIT();
   if (!p || !src || !dst) return fail(IPK_ERR_INVALID, "null argument");
+  IPK_FOLD_CFA(ipk_fused_params, p)
   const size_t esz = p->src_type == IPK_SRC_U16 ? 2 : 4;
   const bool band = p->band_out_rows != 0;
   const size_t src_rows = band ? p->band_src_rows : p->y + p->height;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cmath>
 #include <type_traits>
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -94,6 +95,12 @@ __device__ __forceinline__ void stage_lds_direct(void *lds, const void *g, uint3
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   for (uint32_t off = wave * 1024u; off < bytes; off += 16u * 1024u)
     lds_direct_16(reinterpret_cast<const char *>(g) + off + lane * 16u, reinterpret_cast<char *>(lds) + off);
+}
+// The barrier that publishes an LDS-direct fill: the DMA into LDS is counted by vmcnt, which a workgroup barrier does not formally wait for (its fence
+// orders lgkmcnt traffic), so the wait is stated here rather than left to what this compiler version happens to emit in front of s_barrier.
+__device__ __forceinline__ void sync_after_lds_direct() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 // (any other block size: the register-staged loop -- no launcher uses one, but a table silently left half-filled would be the worst kind of failure)
 __device__ __forceinline__ void stage_table_direct(LutPair *s_tab, const float *plain, const LutPair *pairs) {
@@ -393,7 +400,7 @@ __global__ void k_transform_buffer(const T *__restrict__ src, TransformArgs a, c
     // eight columns (scale <= 7).  One window row = eight pixel loads issued together (one access per pixel: 4 bytes for RGB8, 8 for RGB16; the last pixel
     // of the frame reads the bytes in FRONT of it and shifts) -- the tap-by-tap loop below waits out one memory round trip per tap.  Columns outside the
     // lane's window carry the weight 1 - dx dx = -inf, which the clamp turns into a factor of 0: 0 * sample and + 0 change nothing in sums that start at +0.0.
-    if (RGB3 && plain && a.components == 3u && !a.has_cfa && __builtin_amdgcn_ballot_w64(to_x - from_x >= 8u) == 0) {
+    if (RGB3 && plain && a.components == 3u && !a.has_cfa && (size_t)a.width * a.height > 1 && __builtin_amdgcn_ballot_w64(to_x - from_x >= 8u) == 0) {   // (a 1x1 source has no byte in front of its last pixel: tap loop)
       float ax[8];
       #pragma unroll
       for (uint32_t k = 0; k < 8; ++k) {
@@ -504,8 +511,7 @@ template <typename T>
 void launch_transform_buffer(const T *src, size_t width, size_t height, int64_t tlx, int64_t tly, int64_t trx, int64_t try_,
                              int64_t blx, int64_t bly, size_t nwidth, size_t nheight, size_t components,
                              const uint8_t *cfa48_dev, T *dst, hipStream_t s) {
-  TransformArgs a;
-  a.plain_axis = 0;
+  TransformArgs a{};
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight;
   a.components = (uint32_t)components;
   a.tlx = (float)tlx; a.tly = (float)tly;
@@ -586,9 +592,7 @@ __global__ void k_raster_scale_down(const SrcT *__restrict__ src, TransformArgs 
 static int cdiv_host_ok(float c);
 void launch_raster_scale_down(const void *src, int src_is_u16, size_t owidth, size_t x, size_t y, size_t width, size_t height,
                               size_t nwidth, size_t nheight, const void *gamma_reverse_pairs, float *dst4, hipStream_t s) {
-  TransformArgs a;
-  a.plain_axis = 0;
-  std::memset(&a, 0, sizeof(a));
+  TransformArgs a{};
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
   a.skip_x_x = ((float)((int64_t)width - 1) - 0.0f) / ((float)(nwidth - 1));
@@ -1004,8 +1008,7 @@ template <typename T>
 void launch_raw_scaled_demosaic(const T *src, size_t owidth, size_t x, size_t y, size_t width, size_t height, float black0, float white0,
                                 int norm_fast, int has_fourth_colour, size_t nwidth, size_t nheight, const uint8_t *cfa48_dev, int pw, int ph, float *dst4, hipStream_t s,
                                 size_t band_src_row0, size_t band_out_row0, size_t band_out_rows) {
-  TransformArgs a;
-  a.plain_axis = 0;
+  TransformArgs a{};
   a.width = (uint32_t)width; a.height = (uint32_t)height; a.nwidth = (uint32_t)nwidth; a.nheight = (uint32_t)nheight; a.components = 4;
   a.tlx = 0.0f; a.tly = 0.0f;                                               // scale_down_buffer's corners (scaling.rs:35-48)
   a.skip_x_x = ((float)((int64_t)width - 1) - 0.0f) / ((float)(nwidth - 1));
@@ -2177,7 +2180,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // THE block barrier: tables, parameters, curve and cell records are in LDS behind it.  Every wave passes it exactly once -- in front of its first
   // row, with that row's loads already in flight, or on its way out when it has no row to do.
   bool arrived = false;
-  auto arrive = [&]() { if (!arrived) { __syncthreads(); arrived = true; } };
+  auto arrive = [&]() { if (!arrived) { sync_after_lds_direct(); arrived = true; } };
 
   const uint32_t lane = threadIdx.x & 63u;
   // (making the task index wave-uniform with readfirstlane moves the row/address arithmetic to the scalar unit: measured, no change)
@@ -2636,7 +2639,7 @@ template <typename SrcT, bool VEC, int OUT, bool PXG>
 __global__ __launch_bounds__(1024) void k_fused_bayer_batch(FusedArgs a, BatchPtrs bp) { fused_bayer_body<SrcT, VEC, OUT, true, false, PXG, 1, false, true>(a, &bp); }
 
 static void fused_task_grid(FusedArgs &a, int num_cus, unsigned &blocks, uint32_t frames = 1, uint32_t waves_per_block = 16);
-static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk);
+static bool task_counters_for(TaskQueues *q, hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk);
 // after hipLaunchKernelGGL: an enqueue error becomes the launcher's return value (-4); nothing is left to undo, the heads were not touched
 static int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -4; }
 
@@ -2644,7 +2647,7 @@ static int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -4; }
 // generic kernel: src row 0 = image row src_row0, output rows [out_row0, out_row0+out_rows).
 // gen_cells != null: generic-CFA mode (pattern gen_pw x gen_ph, no fourth colour) instead of the RGGB phase (xoff, yoff).
 int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
-                          int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s) {
+                          int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, TaskQueues *queues, hipStream_t s) {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
   a.src = src; a.dst = dst4; a.W = (uint32_t)width; a.H = (uint32_t)img_height; a.owidth = width;
@@ -2653,7 +2656,7 @@ int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, siz
   a.gen_cells = gen_cells; a.gen_pw = (uint32_t)gen_pw; a.gen_ph = (uint32_t)gen_ph;
   unsigned blocks;
   std::unique_lock<std::mutex> queue_lock;
-  (void)task_counters_for(s, a, queue_lock);
+  (void)task_counters_for(queues, s, a, queue_lock);
   // the demosaic-only variants are memory-bound and small (78 VGPRs, 67 KB of LDS): two blocks per CU are launched, of which one is resident at a time
   // (round 4: blocks of eight waves, three resident per CU -- six waves per SIMD instead of four -- measured slower, 402 -> 416 us at 100 MP)
   // (1 / 2 / 3 / 4 / 6 blocks per CU launched: 0.416 / 0.415 / 0.422 / 0.417 / 0.426 ms at 100 MP)
@@ -2722,38 +2725,45 @@ static void launch_fused_t(const FusedArgs &a, unsigned grid, hipStream_t s) {
 // hipStreamPerThread is a different stream in every host thread and is keyed by the calling thread.  When the table is full the least recently used
 // slot whose stream has drained is reused; when there is none the launch runs the static schedule (task_ctr = null) -- the queue is an optimisation
 // and never fails a call.
-namespace {
-std::mutex g_ctr_mu;
-uint32_t *g_ctr_block = nullptr;
-struct StreamCtr { hipStream_t key; hipStream_t stream; uint32_t slot; uint64_t last_use; };
-std::vector<StreamCtr> g_ctr_of;
-uint64_t g_ctr_clock = 0;
+// One TaskQueues object per library context (ipk_ctx): its device block lives on the context's device, so two contexts -- on two GPUs, or two on one --
+// never share a head, and launches of different contexts are issued under different locks.
 constexpr uint32_t kCtrSlots = 1024;
 constexpr uint32_t kCtrSlotWords = 2 * kQueueStride;
+struct StreamCtr { hipStream_t key; hipStream_t stream; uint32_t slot; uint64_t last_use; };
+struct TaskQueues {
+  std::mutex mu;
+  uint32_t *block = nullptr;
+  std::vector<StreamCtr> of;
+  uint64_t clock = 0;
+};
+static std::atomic<bool> g_ctr_disabled{false};            // test hook (ipk_selftest_task_queue): every launch runs as if no queue slot could be had
+TaskQueues *create_task_queues() {
+  TaskQueues *q = new TaskQueues;
+  if (hipMalloc(reinterpret_cast<void **>(&q->block), (size_t)kCtrSlots * kCtrSlotWords * sizeof(uint32_t)) != hipSuccess) { delete q; return nullptr; }
+  if (hipMemset(q->block, 0, (size_t)kCtrSlots * kCtrSlotWords * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(q->block); delete q; return nullptr; }
+  return q;
 }
-bool init_task_counters() {
-  std::lock_guard<std::mutex> lk(g_ctr_mu);
-  if (g_ctr_block) return true;
-  if (hipMalloc(reinterpret_cast<void **>(&g_ctr_block), (size_t)kCtrSlots * kCtrSlotWords * sizeof(uint32_t)) != hipSuccess) { g_ctr_block = nullptr; return false; }
-  if (hipMemset(g_ctr_block, 0, (size_t)kCtrSlots * kCtrSlotWords * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(g_ctr_block); g_ctr_block = nullptr; return false; }
-  return true;
+void destroy_task_queues(TaskQueues *q) {
+  if (!q) return;
+  { std::lock_guard<std::mutex> lk(q->mu); if (q->block) (void)hipFree(q->block); q->block = nullptr; q->of.clear(); }
+  delete q;
 }
+void selftest_task_queue(bool enabled) { g_ctr_disabled.store(!enabled); }
 // `lk` is held by the caller until its kernel launch has been issued: two host threads launching on one stream must enqueue one after the other.
 // Returns false (a.task_ctr = null: static schedule) when no slot can be had.
-static bool g_ctr_disabled = false;                          // test hook (ipk_selftest_task_queue): every launch runs as if no queue slot could be had
-void selftest_task_queue(bool enabled) { std::lock_guard<std::mutex> lk(g_ctr_mu); g_ctr_disabled = !enabled; }
-static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk) {
+static bool task_counters_for(TaskQueues *q, hipStream_t s, FusedArgs &a, std::unique_lock<std::mutex> &lk) {
   a.task_ctr = nullptr;
-  lk = std::unique_lock<std::mutex>(g_ctr_mu);
-  if (!g_ctr_block || g_ctr_disabled) return false;
+  if (!q) return false;
+  lk = std::unique_lock<std::mutex>(q->mu);
+  if (!q->block || g_ctr_disabled.load()) return false;
   static thread_local char per_thread_key;
   const hipStream_t key = (s == hipStreamPerThread) ? reinterpret_cast<hipStream_t>(&per_thread_key) : s;
   StreamCtr *e = nullptr;
-  for (auto &c : g_ctr_of) if (c.key == key) { e = &c; break; }
+  for (auto &c : q->of) if (c.key == key) { e = &c; break; }
   if (!e) {
-    if (g_ctr_of.size() < kCtrSlots) {
-      g_ctr_of.push_back({key, s, (uint32_t)g_ctr_of.size(), 0});
-      e = &g_ctr_of.back();
+    if (q->of.size() < kCtrSlots) {
+      q->of.push_back({key, s, (uint32_t)q->of.size(), 0});
+      e = &q->of.back();
     } else {
       // reuse the least recently used slot whose stream has nothing in flight (a destroyed stream's handle answers with an error: also free).  Slots of
       // per-thread streams cannot be queried from this thread and are passed over -- one of them at the head of the order used to block reuse for
@@ -2764,26 +2774,21 @@ static bool task_counters_for(hipStream_t s, FusedArgs &a, std::unique_lock<std:
       uint64_t older_than = 0;
       for (int attempt = 0; attempt < 8 && !lru; ++attempt) {
         StreamCtr *cand = nullptr;
-        for (auto &c : g_ctr_of) if (c.key == c.stream && c.last_use > older_than && (!cand || c.last_use < cand->last_use)) cand = &c;
+        for (auto &c : q->of) if (c.key == c.stream && c.last_use > older_than && (!cand || c.last_use < cand->last_use)) cand = &c;
         if (!cand) break;
         older_than = cand->last_use;
-        const hipError_t q = hipStreamQuery(cand->stream);
+        const hipError_t qs = hipStreamQuery(cand->stream);
         (void)hipGetLastError();
-        if (q != hipErrorNotReady) lru = cand;
+        if (qs != hipErrorNotReady) lru = cand;
       }
       if (!lru) return false;
       lru->key = key; lru->stream = s;
       e = lru;
     }
   }
-  e->last_use = ++g_ctr_clock;
-  a.task_ctr = g_ctr_block + (size_t)e->slot * kCtrSlotWords;
+  e->last_use = ++q->clock;
+  a.task_ctr = q->block + (size_t)e->slot * kCtrSlotWords;
   return true;
-}
-void release_task_counters() {
-  std::lock_guard<std::mutex> lk(g_ctr_mu);
-  if (g_ctr_block) (void)hipFree(g_ctr_block);
-  g_ctr_block = nullptr; g_ctr_of.clear();
 }
 
 // Task grid: strips of <= 64 lane-columns x row segments.  A task costs its rows plus about 2.5 rows' worth of set-up (two halo rows, the three-row
@@ -2878,7 +2883,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
         a.n_frames = (uint32_t)n;
         unsigned grid;
         std::unique_lock<std::mutex> queue_lock;
-        (void)task_counters_for(s, a, queue_lock);
+        (void)task_counters_for(f.queues, s, a, queue_lock);
         fused_task_grid(a, f.num_cus, grid, (uint32_t)n);
 #define IPK_BATCH_LAUNCH(T, V, O) hipLaunchKernelGGL((k_fused_bayer_batch<T, V, O, false>), dim3(grid), dim3(1024), 0, s, a, bp)
         if (!f.src_is_u16) { if (f.out_type == 0) IPK_BATCH_LAUNCH(float, true, 0); else if (f.out_type == 1) IPK_BATCH_LAUNCH(float, true, 1); else IPK_BATCH_LAUNCH(float, true, 2); }
@@ -2894,7 +2899,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
     return 0;
   }
   std::unique_lock<std::mutex> queue_lock;
-  (void)task_counters_for(s, a, queue_lock);
+  (void)task_counters_for(f.queues, s, a, queue_lock);
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks);
   if (f.out_type == 4) {                                  // ipk_stream_probe: the skeleton of the headline variants (Bayer phase, full strips, no guards)
@@ -2966,7 +2971,7 @@ __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_
       const uint64_t i = base + 64u * j;
       px[j] = ld_stream4(reinterpret_cast<const float *>(src + (i < npix ? i : npix - 1)));   // clamped, unpredicated: the tail lanes recompute the last pixel
     }
-    if (!arrived) { __syncthreads(); arrived = true; }                  // the block's one barrier, behind the first chunk's loads
+    if (!arrived) { sync_after_lds_direct(); arrived = true; }          // the block's one barrier, behind the first chunk's loads
     PixOut o[PPL];
     // the fast form drops the E term (e * cm[i][3]): legal while the fourth channel is +0.0, as every producer on this
     // path writes it (gofloat's RGB/mono/raster branches, demosaic of RGB filters); RGBE mosaics take the literal form
@@ -2992,7 +2997,7 @@ __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_
       if (i < npix) { float *po = reinterpret_cast<float *>(dst + i); st_stream(po, o[j].r); st_stream(po + 1, o[j].g); st_stream(po + 2, o[j].b); }
     }
   }
-  if (!arrived) __syncthreads();                                        // a wave without a chunk
+  if (!arrived) sync_after_lds_direct();                                // a wave without a chunk
 }
 template <bool TOLAB_ONLY>
 __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) { pointwise_chain_body<TOLAB_ONLY>(a, npix); }

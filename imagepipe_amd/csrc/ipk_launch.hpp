@@ -10,6 +10,12 @@ namespace ipk {
 
 typedef Spline SplineHost;
 
+// the per-stream task-queue heads of the row-walking kernels: one device block per library context, allocated on the device that is current when
+// create_task_queues() is called (ipk_ctx_create) and released by destroy_task_queues() (ipk_ctx_destroy); null = every launch runs its static schedule
+struct TaskQueues;
+TaskQueues *create_task_queues();
+void destroy_task_queues(TaskQueues *q);
+
 template <typename T>
 void launch_gofloat_cfa(const T *src, size_t owidth, size_t x, size_t y, size_t w, size_t h, float black0, float white0,
                         float *dst, hipStream_t s);
@@ -28,9 +34,7 @@ void launch_demosaic_full(const float *src, size_t width, size_t img_height, siz
 
 // returns 0, or -4 when the launch could not be enqueued (hipGetLastError after the launch)
 int launch_demosaic_bayer(const float *src, size_t width, size_t img_height, size_t src_row0, size_t out_row0, size_t out_rows,
-                          int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, hipStream_t s);
-bool init_task_counters();      // the per-stream task-queue heads of the row-walking kernels: one device block (ipk_init)
-void release_task_counters();   // (ipk_shutdown)
+                          int xoff, int yoff, const float *gen_cells, int gen_pw, int gen_ph, float *dst4, int num_cus, TaskQueues *queues, hipStream_t s);
 void selftest_task_queue(bool enabled);   // test hook: false = every following launch runs the queue-less static schedule
 
 template <typename T>
@@ -78,6 +82,7 @@ struct FusedLaunch {
   int px_guard;                  // 0: u16 source whose levels and parameters the host found ordinary (kernel variant without per-pixel input guards)
   const float *gen_cells; int gen_pw, gen_ph, gen_check;   // generic-CFA mode (device cell records) or null: RGGB phase (xoff, yoff)
   int num_cus;
+  TaskQueues *queues;            // the launching context's task queues (launch_fused_bayer only; may be null)
   int ori;                       // 0, or the ipk_orientation (Rotate90 / Rotate270) in whose rotated space the launch works: src is the permuted mosaic
   int roles[4];                  // ori != 0: demosaic role of the rotated-space pixel with parities (row & 1, col & 1), index 2 * row parity + col parity
   // launch_fused_bayer only: batch_n > 0 = that many frames of this shape and these parameters (host arrays of device pointers, src already

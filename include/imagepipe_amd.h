@@ -85,6 +85,35 @@ IPK_API int ipk_host_libm_matches(size_t *mismatches_of_65536);
 /* Number of compute units of the selected device (0 before ipk_init). */
 IPK_API int ipk_device_cus(void);
 
+/* ---- Several devices from ONE process --------------------------------------------------------------------------------------------
+ * The reference is one process whose callers loop Pipeline::run over frames on Rayon threads (src/lib.rs:21-26, src/pipeline.rs:246-249); a
+ * drop-in therefore reaches eight GPUs from one process, not through eight processes and a communicator.  A CONTEXT (ipk_ctx) is one device
+ * binding plus everything the library keeps on that device (lookup tables, CFA tables, scratch pool, task queues, host-pointer lanes).
+ * Every entry point of this header works on the calling thread's CURRENT context: ipk_init's context on every thread that has not chosen
+ * another, else what ipk_ctx_make_current set (HIP's own per-thread current-device model; the call also binds the HIP device).  Several
+ * contexts may share one device (two independent pipelines on one GPU); contexts share nothing mutable, so threads that use different
+ * contexts never contend.  Device pointers belong to the device of the context that was current when they were allocated (ipk_malloc,
+ * ipk_cache_new ...): pass them only to calls made under a context of that device. */
+typedef struct ipk_ctx ipk_ctx;
+/* A new context on `device`.  Does not change the calling thread's current context.  ipk_ctx_destroy releases its device memory (after
+ * draining the device); a destroyed handle stays a valid argument and fails with IPK_ERR_NOT_INIT wherever it is used. */
+IPK_API int ipk_ctx_create(int device, ipk_ctx **out);
+IPK_API int ipk_ctx_destroy(ipk_ctx *ctx);
+/* ctx becomes the calling thread's current context (NULL: back to the process default, ipk_init's). */
+IPK_API int ipk_ctx_make_current(ipk_ctx *ctx);
+IPK_API ipk_ctx *ipk_ctx_current(void);                 /* NULL before any context exists */
+IPK_API int ipk_ctx_device(const ipk_ctx *ctx);         /* HIP device ordinal, -1 for a destroyed context */
+/* The process's DEVICE SET: one context per entry of devices[0..n) (n = 0: one per visible device; the same ordinal may appear more than
+ * once -- two contexts on one GPU).  The batch entry points below deal frame i to member i mod N.  A context ipk_init made serves as the
+ * member for its device; without one, member 0 becomes the process default, so ipk_init_devices alone is a complete initialisation.
+ * Calling it again replaces the set.  ipk_shutdown destroys every context of the process. */
+IPK_API int ipk_init_devices(const int *devices, int n);
+IPK_API int ipk_device_set_size(void);
+IPK_API ipk_ctx *ipk_device_ctx(int index);             /* member `index` of the set (NULL outside it): make it current to allocate on its device */
+/* The dealing rule as arithmetic (no GPU needed): of n_frames frames, set member `index` of n_devices gets frames
+ * *first, *first + *stride, ... -- *count of them (frame i -> member i mod n_devices). */
+IPK_API int ipk_deal_frames(size_t n_frames, int n_devices, int index, size_t *first, size_t *stride, size_t *count);
+
 /* Device memory / stream helpers for callers that do not bring their own allocator. */
 IPK_API int ipk_malloc(void **dptr, size_t bytes);
 IPK_API int ipk_free(void *dptr);
@@ -257,6 +286,7 @@ IPK_API int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *str
 /* Everything the ops between OpGoFloat and OpGamma read, for a CFA raw source at full scale with
  * a no-op rotatecrop (the default Pipeline::run on a RawImage). */
 typedef struct {
+  uint32_t struct_size;            /* sizeof(ipk_fused_params) as the CALLER was compiled (IPK_FUSED_PARAMS_INIT sets it): see "Descriptor versioning" below */
   int src_type;                    /* IPK_SRC_U16 or IPK_SRC_F32 */
   size_t owidth;                   /* RawImage.width: row pitch of src in elements */
   size_t x, y, width, height;      /* OpGoFloat::size_image result */
@@ -273,14 +303,17 @@ typedef struct {
    * image row band_src_row0 (in cropped coordinates, i.e. row y+band_src_row0 of the sensor), and
    * only output rows [band_out_row0, band_out_row0+band_out_rows) are produced into dst. */
   size_t band_src_row0, band_src_rows, band_out_row0, band_out_rows;
-  /* Fields added after the struct was first published are APPENDED here, never inserted, so every earlier field keeps its offset.  That does NOT make
-   * the library binary-compatible with callers COMPILED against an older header: their object is shorter than this struct and the library would read
-   * the appended fields past its end.  A binding must be rebuilt against the header it loads the library with, and can verify that at start-up with
-   * ipk_abi_sizeof(0) == sizeof(ipk_fused_params) (1: ipk_pipeline_desc; tests/test_rust_binding.py checks the generated Rust layout the same way).  Rebuilt callers that value-initialise
-   * the struct get 0, 0 below, which means "take the shape from the string". */
+  /* Descriptor versioning.  Fields added after a struct was first published are APPENDED, never inserted, and the leading struct_size says how many
+   * bytes of it the caller's object really has: the library copies exactly that many into a zeroed struct of its own and never reads past them, so a
+   * caller compiled against an older header (an object that ends in front of the fields below) keeps working with the defaults of the fields it
+   * does not know -- 0, 0 below: "take the shape from the string".  A struct_size smaller than the first published layout (ipk_abi_sizeof(16) / (17):
+   * everything in front of cfa_width), or LARGER than this library's struct (a caller built against a newer header: fields this library would
+   * silently ignore), fails with IPK_ERR_INVALID; so does 0 (an object that was never initialised).  ipk_abi_sizeof(0) / (1) still let a binding
+   * compare whole layouts at start-up (tests/test_rust_binding.py checks the generated Rust layout the same way). */
   int cfa_width, cfa_height;       /* the tile's shape as the caller's CFA object has it (cfa.width / cfa.height, src/ops/demosaic.rs:33); 0, 0 = take
                                       it from the string (a "WxH:" prefix, or the letter count 4 / 36 / 144).  16 letters need one of the two. */
 } ipk_fused_params;
+#define IPK_FUSED_PARAMS_INIT {(uint32_t)sizeof(ipk_fused_params)}      /* ipk_fused_params p = IPK_FUSED_PARAMS_INIT;  (everything else zero) */
 
 /* src: device pointer to the sensor data (element (0,0) of the uncropped frame, or of the band's
  * first source row); dst: device pointer to width*rows*3 elements of out_type.
@@ -327,6 +360,7 @@ IPK_API int ipk_raster_to_srgb(const void *src, int src_type, size_t width, size
 
 /* The fields of ImageSource + PipelineOps + PipelineSettings the hot path reads. */
 typedef struct {
+  uint32_t struct_size;            /* sizeof(ipk_pipeline_desc) as the caller was compiled (IPK_PIPELINE_DESC_INIT); see ipk_fused_params, "Descriptor versioning" */
   int src_type;                    /* ipk_src_type */
   size_t width, height;            /* RawImage.width/height or raster dims */
   int cpp;                         /* RawImage.cpp (1 or 3); ignored for RGB8/RGB16 */
@@ -346,6 +380,7 @@ typedef struct {
   /* later additions are appended (see ipk_fused_params) */
   int cfa_width, cfa_height;       /* as in ipk_fused_params: the tile's shape from the caller's CFA object, 0, 0 = from the string */
 } ipk_pipeline_desc;
+#define IPK_PIPELINE_DESC_INIT {(uint32_t)sizeof(ipk_pipeline_desc)}
 
 /* Size negotiation of Pipeline::run (src/pipeline.rs:314-338): demosaic_{w,h} as stored in the
  * settings, and the size of the buffer run() returns.  The ops size their outputs from the buffer
@@ -385,6 +420,24 @@ IPK_API int ipk_host_pipeline_run(const ipk_pipeline_desc *d, const void *src, v
  * registered); pageable buffers work but serialise.  Results are what n calls of ipk_host_pipeline_run give.  Synchronous at return. */
 IPK_API int ipk_host_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n,
                                         int out_type, int *used_fused);
+/* n same-shaped DEVICE frames through one descriptor on the current context (the device-pointer form of the above, enqueued on `stream`):
+ * where Pipeline::run is exactly one fused launch per frame the batch is one persistent launch per 64 frames (ipk_raw_to_srgb_batch), otherwise
+ * n calls of ipk_pipeline_run.  Results are what n calls of ipk_pipeline_run give. */
+IPK_API int ipk_pipeline_run_batch(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type,
+                                   int *used_fused, void *stream);
+/* The same over the DEVICE SET (ipk_init_devices) from one host thread: frame i runs on set member i mod N, so srcs[i] / dsts[i] must live on
+ * that member's device.  Nothing is exchanged between devices and every result stays where it was computed (frames are independent pipelines,
+ * src/pipeline.rs:246-249).  Enqueues on one internal stream per member and returns; ipk_devices_sync waits for all of them.  Without a device
+ * set the current context takes every frame. */
+IPK_API int ipk_pipeline_run_batch_multi(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n, int out_type,
+                                         int *used_fused);
+IPK_API int ipk_devices_sync(void);
+/* HOST frames in, HOST results out, over the device set: the drop-in for a caller looping Pipeline::run / output_8bit over a shoot on a
+ * multi-GPU node.  One host thread per member runs ipk_host_pipeline_run_batch on the frames dealt to it (frame i -> member i mod N), so all
+ * GPUs upload, compute and download concurrently; the caller's Vecs are the "gather".  Synchronous at return; results are what n calls of
+ * ipk_host_pipeline_run give.  Use ipk_host_alloc buffers (page-locked and visible to every device). */
+IPK_API int ipk_host_pipeline_run_batch_multi(const ipk_pipeline_desc *d, const void *const *srcs, void *const *dsts, size_t n,
+                                              int out_type, int *used_fused);
 /* Page-locked host memory for the buffers handed to the ipk_host_* entry points (NULL on failure). */
 IPK_API void *ipk_host_alloc(size_t bytes);
 IPK_API void ipk_host_free(void *p);

@@ -344,7 +344,7 @@ class Pipeline {
     return fin;
   }
   ipk_pipeline_desc desc() const {
-    ipk_pipeline_desc d; std::memset(&d, 0, sizeof(d));
+    ipk_pipeline_desc d; std::memset(&d, 0, sizeof(d)); d.struct_size = (uint32_t)sizeof(d);
     const ImageSource &img = globals.image;
     d.src_type = img.kind == ImageSource::Raw ? (img.is_float ? IPK_SRC_F32 : IPK_SRC_U16) : (img.bits == 8 ? IPK_SRC_RGB8 : IPK_SRC_RGB16);
     d.width = img.width; d.height = img.height; d.cpp = img.kind == ImageSource::Raw ? img.cpp : 3; d.is_cfa = ops.gofloat.is_cfa;

@@ -57,8 +57,7 @@ int main(int argc, char **argv) {
   std::vector<ipk_band> bands((size_t)n);
   if (ipk_band_plan(H, n, 2, bands.data()) != 0) { std::fprintf(stderr, "band plan: %s\n", ipk_last_error()); return 3; }
 
-  ipk_fused_params p;
-  std::memset(&p, 0, sizeof(p));
+  ipk_fused_params p = IPK_FUSED_PARAMS_INIT;
   p.src_type = IPK_SRC_U16; p.owidth = W; p.width = W; p.height = H; p.black0 = 512.0f; p.white0 = 16383.0f;
   std::strcpy(p.cfa, "RGGB");
   const float wb[4] = {2.0f, 1.0f, 1.5f, 1.0f};

@@ -17,7 +17,7 @@ HDR = os.path.join(ROOT, "include", "imagepipe_amd.h")
 
 RUST_SIZES = {"c_int": 4, "c_uint": 4, "i32": 4, "u32": 4, "f32": 4, "usize": 8, "u64": 8, "i64": 8, "f64": 8, "u8": 1, "c_char": 1, "u16": 2}
 C_TO_RUST = {"int": "c_int", "size_t": "usize", "float": "f32", "char": "c_char", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32",
-             "uint64_t": "u64", "int64_t": "i64", "void": "c_void", "ipk_cache": "IpkCache", "ipk_pipeline_desc": "IpkPipelineDesc",
+             "uint64_t": "u64", "int64_t": "i64", "void": "c_void", "ipk_cache": "IpkCache", "ipk_ctx": "IpkCtx", "ipk_pipeline_desc": "IpkPipelineDesc",
              "ipk_fused_params": "IpkFusedParams", "ipk_comm": "IpkComm", "ipk_band": "IpkBand", "ipk_stage_time": "IpkStageTime", "ipk_exchange_fn": "IpkExchangeFn"}
 
 
