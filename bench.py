@@ -77,6 +77,13 @@ def parse():
                          "the same workload without it is reported as config.cold_ms")
     ap.add_argument("--band", action="store_true",
                     help="additionally time ONE frame row-sharded over the N GPUs with the halo exchange (extra 'band_mode' object)")
+    ap.add_argument("--host-boundary", action="store_true", help="additionally run the host-buffers-in / host-buffers-out leg (`host_boundary`; part of the default run)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process, the shape a drop-in behind the reference's Pipeline::run has (no torch.distributed, no RCCL): one ipk_ctx per "
+                         "device (ipk_init_devices), frame i -> device i mod N (ipk_pipeline_run_batch_multi); prints the same line with a `scale` object")
+    ap.add_argument("--devices", default=None, help="--single-process: the device ordinals, comma separated (default 0..N-1; an ordinal may repeat -- "
+                                                    "development: two contexts on the one GPU of a 1-GPU box)")
+    ap.add_argument("--sp-child", default=None, metavar="DEVICES", help=argparse.SUPPRESS)
     ap.add_argument("--band-child", nargs=4, metavar=("RANK", "WORLD", "LOCAL_RANK", "IDHEX"), default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -441,6 +448,176 @@ def live_traffic(timeout_s=45):
                              "per-launch mean; FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 note"}
 
 
+def _hwmon_for(torch, dev):
+    """the amdgpu hwmon directory of HIP device `dev` (matched by PCI bus id; a box with one GPU: its only card), or None"""
+    cands = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        hm = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+        if not hm or not (os.path.exists(os.path.join(hm[0], "power1_average")) or os.path.exists(os.path.join(hm[0], "power1_input"))):
+            continue
+        slot = None
+        try:
+            for line in open(os.path.join(d, "uevent")):
+                if line.startswith("PCI_SLOT_NAME="):
+                    slot = line.strip().split("=", 1)[1].lower()
+        except OSError:
+            pass
+        cands.append((slot, hm[0]))
+    if not cands:
+        return None
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        for slot, hm in cands:
+            if slot and slot.startswith(want):
+                return hm
+    except Exception:
+        pass
+    return cands[0][1] if len(cands) == 1 else None
+
+
+def clock_power_leg(ctx, wl, seconds=1.0):
+    """The box's state under THIS workload, so that a slower box and a slower kernel can be told apart (the kernel is clock / power bound, DESIGN.md
+    section 4): the same step back to back for ~`seconds` in the pre-warmed steady state, while
+      - a one-wave kernel on a second stream (ipk_clock_probe) counts shader-clock cycles (s_memtime) against the fixed 100 MHz reference (s_memrealtime)
+        over 20 ms spans BESIDE the running launches: shader_clock_GHz, measured on the device itself;
+      - a host thread reads the amdgpu hwmon files of the device (socket power, sclk) every 10 ms.
+    Outside the timed region (a sampling thread and a co-resident wave have no business inside it); same launches, same clock regime."""
+    import threading
+    torch = ctx.torch
+    import imagepipe_amd as ipa
+    L = ipa.lib()
+    out = {}
+    hm = _hwmon_for(torch, torch.cuda.current_device())
+    pfile = None
+    if hm:
+        for n in ("power1_average", "power1_input"):
+            if os.path.exists(os.path.join(hm, n)):
+                pfile = os.path.join(hm, n)
+                break
+    ffile = os.path.join(hm, "freq1_input") if hm and os.path.exists(os.path.join(hm, "freq1_input")) else None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                pw = float(open(pfile).read()) / 1e6 if pfile else None
+                fq = float(open(ffile).read()) / 1e9 if ffile else None
+                samples.append((pw, fq))
+            except Exception:
+                pass
+            stop.wait(0.01)
+    side = torch.cuda.Stream()
+    res = torch.zeros(2 * 64, dtype=torch.int64, device="cuda")
+    n_probe = 0
+    for _ in range(30):
+        wl.step()
+    th = threading.Thread(target=poll)
+    th.start()
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds:
+        if n_probe < 64 and k % 2 == 0:
+            rc = L.ipk_clock_probe(res.data_ptr() + 16 * n_probe, 20000, side.cuda_stream)
+            n_probe += 1 if rc == 0 else 0
+        for _ in range(40):
+            wl.step()
+        torch.cuda.synchronize()
+        k += 1
+    stop.set(); th.join()
+    torch.cuda.synchronize()
+    r = res.cpu().numpy().reshape(-1, 2)[:n_probe]
+    ghz = sorted(float(c) / float(t) / 10.0 for c, t in r if t > 0)
+    if ghz:
+        out["shader_clock_GHz"] = round(ghz[len(ghz) // 2], 3)
+        out["shader_clock_GHz_min_max"] = [round(ghz[0], 3), round(ghz[-1], 3)]
+    pw = sorted(p for p, _ in samples if p is not None)
+    fq = sorted(f for _, f in samples if f is not None)
+    if pw:
+        busy = pw[len(pw) // 5:]                                   # the lowest fifth: ramp-up and the gaps at the synchronisations
+        out["socket_power_W"] = round(sum(busy) / len(busy), 1)
+        out["socket_power_W_max"] = round(pw[-1], 1)
+    if fq:
+        out["sclk_sysfs_GHz"] = round(fq[len(fq) // 2], 3)
+    out["clock_power_method"] = ("%d ipk_clock_probe spans of 20 ms (s_memtime / s_memrealtime) on a second stream beside %.1f s of back-to-back launches of the timed "
+                                 "workload; %d hwmon samples (%s) at 10 ms" % (len(ghz), seconds, len(samples), os.path.basename(pfile) if pfile else "no power file"))
+    return out
+
+
+def host_boundary_leg(ctx, ipa, util, n=6, check=True):
+    """The boundary a drop-in actually crosses (Rust Vecs in, Vecs out): BASELINE.json configs[1]'s 24 MP frame as u16 sensor data in HOST
+    memory -> f32 / 8-bit sRGB in HOST memory through ipk_host_pipeline_run (one frame, synchronous: upload + kernel + download in turn) and
+    ipk_host_pipeline_run_batch (three streams over two device slots: per-frame cost tends to the slowest of the three).  Page-locked buffers
+    (ipk_host_alloc).  pcie_floor_ms = the bytes of the busier direction / 63 GB/s (PCIe 5.0 x16, one direction); frac = floor / measured."""
+    import numpy as np
+    L = ipa.lib()
+    W, H = 6000, 4000
+    PCIE_GBS = 63.0
+    img = ipa.RawImage(width=W, height=H, data=None, cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                       wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    d = ipa.Pipeline(img).desc()
+    in_bytes = W * H * 2
+    frames = [util.noise_u16(util.SEED + 40 + i, H, W) for i in range(2)]
+    sp = [L.ipk_host_alloc(in_bytes) for _ in range(n)]
+    out = {"frame": [W, H], "src": "u16 host buffer (page-locked)", "frames": n, "pcie_GBps_assumed": PCIE_GBS}
+    dp = []
+    try:
+        if not all(sp):
+            raise RuntimeError("ipk_host_alloc failed")
+        for i, q in enumerate(sp):
+            ctypes.memmove(q, frames[i % 2].ctypes.data, in_bytes)
+        for name, ot, esz in (("to_u8", ipa.OUT_U8, 1), ("to_f32", ipa.OUT_F32, 4)):
+            ob = W * H * 3 * esz
+            dp = [L.ipk_host_alloc(ob) for _ in range(n)]
+            if not all(dp):
+                raise RuntimeError("ipk_host_alloc failed")
+            srcs = (ctypes.c_void_p * n)(*sp); dsts = (ctypes.c_void_p * n)(*dp)
+            used = ctypes.c_int(0)
+
+            def one():
+                rc = L.ipk_host_pipeline_run(ctypes.byref(d), sp[0], dp[0], ot, ctypes.byref(used))
+                assert rc == 0, L.ipk_last_error()
+
+            def batch():
+                rc = L.ipk_host_pipeline_run_batch(ctypes.byref(d), srcs, dsts, n, ot, ctypes.byref(used))
+                assert rc == 0, L.ipk_last_error()
+            one(); batch()                                          # warm: lanes, device slots
+            t0 = time.perf_counter()
+            for _ in range(3):
+                one()
+            t_one = (time.perf_counter() - t0) / 3 * 1e3
+            t0 = time.perf_counter()
+            for _ in range(2):
+                batch()
+            t_b = (time.perf_counter() - t0) / (2 * n) * 1e3
+            floor_serial = (in_bytes + ob) / (PCIE_GBS * 1e9) * 1e3
+            floor_overlap = max(in_bytes, ob) / (PCIE_GBS * 1e9) * 1e3
+            e = {"ms_per_frame_single": round(t_one, 3), "ms_per_frame_batched": round(t_b, 3), "MP_per_s_batched": round(W * H / 1e6 / (t_b * 1e-3), 1),
+                 "pcie_bytes_per_frame": {"up": in_bytes, "down": ob},
+                 "pcie_floor_ms": {"single (up + down in turn)": round(floor_serial, 3), "batched (directions overlap)": round(floor_overlap, 3)},
+                 "frac_of_pcie_floor": {"single": round(floor_serial / t_one, 4), "batched": round(floor_overlap / t_b, 4)},
+                 "used_fused": bool(used.value)}
+            if check and name == "to_u8":
+                import oracle
+                od = oracle.make_pipeline(frames[(n - 1) % 2], cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB,
+                                          cam_to_xyz_normalized=util.cam_matrix())
+                want = oracle.pipeline_output_8bit(od).reshape(-1)
+                got = np.frombuffer((ctypes.c_char * ob).from_address(dp[n - 1]), dtype=np.uint8)
+                if not np.array_equal(got, want):
+                    raise AssertionError("host boundary: the batch's last 8-bit frame differs from the oracle's output_8bit")
+                e["parity_check"] = "last frame of the batch: all %d samples equal the oracle's output_8bit" % want.size
+            out[name] = e
+            for q in dp:
+                L.ipk_host_free(q)
+            dp = []
+        out["device_resident_ms_per_frame"] = "roofline.kernel_ms of --config c2 (0.116 ms, profiles/): the PCIe-inclusive figures above are never `value`"
+    finally:
+        for q in sp + dp:
+            if q:
+                L.ipk_host_free(q)
+    return out
+
+
 def valu_model(kernel_ms, data):
     """The VALU-issue account of the fused kernel from the tracked file profiles/r*_valu_model.json (tools/evidence_r03.sh):
     dynamic instruction counts per launch by class (rocprofv3 PMC), priced two ways with tools/ubench2.hip's figures -- `interleaved`: at the cost
@@ -473,6 +650,10 @@ def main():
     args = parse()
     if args.band_child:
         return band_child(args)
+    if args.sp_child is not None:
+        return sp_child(args)
+    if args.single_process:
+        return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return relaunch_as_ranks(args)
     ctx = Ctx(args)
@@ -548,7 +729,6 @@ def main():
         # what a reader of an N > 1 line must not miss: `value` is weak scaling of independent frames (one frame per GPU per step, nothing exchanged), so it
         # grows ~N x by construction and proves nothing about a node; the judgeable object is `scale` (BASELINE.json configs[3]: the SAME 64 x 24 MP batch on
         # N GPUs against one GPU, compute-only and with the results gathered, each beside its xGMI expectation)
-        result["scale_is_the_claim"] = True
         result["value_basis"] = (("WEAK scaling, no data-path collective: every rank runs its own %dx%d frame per step, value = N frames' pixels / wall time of the K timed "
                                   "steps (barrier + synchronize on both sides, max over ranks) -- ~N x the one-GPU value by construction.  " % (W, H) if weak else
                                   "STRONG scaling of %d independent %dx%d frames per step, frame i on rank i mod N, nothing exchanged: value = their pixels / wall time of the K "
@@ -557,6 +737,12 @@ def main():
                                  "in this run and beside expected_ms from the xGMI link arithmetic), not this number")
     if cold_ms is not None:
         result["config"]["cold_ms"] = round(cold_ms / wl.launches_per_step, 4)
+    if cold_ms is not None and not dev_small:
+        # the box's state under this workload, straight behind the timed region (the clock is where the timed steps left it)
+        try:
+            result["config"].update(clock_power_leg(ctx, wl))
+        except Exception as e:
+            ctx.fail("clock_power", repr(e))
     if checked:
         result["parity_check"] = checked
     # HBM traffic per launch: not measurable from inside this process (PMC counters need rocprofv3); taken from the
@@ -623,6 +809,17 @@ def main():
         result["batch_64x24MP"] = batch_mode(ctx, ipa, util, bw, bh, bn, "f32", "f32", args.data, steps=5, warmup=1, gather=world > 1)
         if "scale" in result["batch_64x24MP"]:
             result["scale"] = result["batch_64x24MP"].pop("scale")     # first-class in the N > 1 line
+        if world > 1:
+            # the same batch over the same N devices from ONE process (rank 0's child; the ranks wait): the shape a drop-in has
+            torch.cuda.empty_cache()
+            sp = sp_children(ctx, args)
+            if rank == 0 and "scale" in result:
+                result["scale"]["single_process"] = sp
+    if world == 1 and ((extras and not dev_small) or args.host_boundary):
+        try:
+            result["host_boundary"] = host_boundary_leg(ctx, ipa, util, check=not args.no_check)
+        except Exception as e:
+            ctx.fail("host_boundary", repr(e))
 
     if extras and world > 1:
         # ONE frame row-sharded over the N GPUs on the library's RCCL transport, in child processes (so that it cannot cost this line)
@@ -652,6 +849,10 @@ def main():
         except Exception as e:
             result["config"]["ipk_comm"] = {"ok": False, "error": repr(e)}
             ctx.fail("ipk_comm", repr(e))
+    if world > 1:
+        result["scale_is_the_claim"] = "scale" in result          # value_basis points at `scale`: say whether this run carries one
+        if "scale" not in result:
+            result["value_basis"] += " -- THIS run carries no `scale` object (it is emitted by the default run, --config c4 or --batch > N)"
     result["failed_legs"] = ctx.failed
     assert result["n_gpus"] == args.gpus, (result["n_gpus"], args.gpus)
     if rank == 0:
@@ -659,6 +860,224 @@ def main():
     if ctx.dist is not None:
         ctx.dist.barrier()                  # the other ranks wait here while rank 0 runs the CPU baseline leg
         ctx.dist.destroy_process_group()
+
+
+class MultiBatch:
+    """B frames of W x H, frame i resident on device-set member i mod N, run from THIS process through ipk_pipeline_run_batch_multi (one internal stream
+    per member, launches issued from one host thread) + ipk_devices_sync -- the batch split of DESIGN.md section 6 as a drop-in would call it."""
+
+    def __init__(self, torch, ipa, util, members, W, H, B, data, seed0, out_type=None):
+        self.torch, self.ipa, self.members, self.W, self.H, self.B = torch, ipa, members, W, H, B
+        self.L = ipa.lib()
+        out_type = ipa.OUT_F32 if out_type is None else out_type
+        self.out_type = out_type
+        odt = {ipa.OUT_F32: torch.float32, ipa.OUT_U8: torch.uint8, ipa.OUT_U16: torch.int16}[out_type]
+        img = ipa.RawImage(width=W, height=H, data=None, cfa="RGGB", is_float=True, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                           wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+        self.desc = ipa.Pipeline(img).desc()
+        n = len(members)
+        self.srcs, self.dsts = [], []
+        for i in range(B):
+            dev = "cuda:%d" % members[i % n].device
+            with torch.cuda.device(members[0].device):
+                f = synth_frame(torch, H, W, data, seed0 + i).to(torch.float32).reshape(-1)
+            self.srcs.append(f.to(dev).contiguous())
+            del f
+            self.dsts.append(torch.empty(H * W * 3, dtype=odt, device=dev))
+        for m in members:
+            torch.cuda.synchronize(m.device)
+        self._s = (ctypes.c_void_p * max(B, 1))(*[t.data_ptr() for t in self.srcs])
+        self._d = (ctypes.c_void_p * max(B, 1))(*[t.data_ptr() for t in self.dsts])
+        self.used = ctypes.c_int(0)
+
+    def step(self):
+        rc = self.L.ipk_pipeline_run_batch_multi(ctypes.byref(self.desc), self._s, self._d, self.B, self.out_type, ctypes.byref(self.used))
+        if rc < 0:
+            raise RuntimeError("ipk_pipeline_run_batch_multi: " + self.L.ipk_last_error().decode())
+
+    def sync(self):
+        rc = self.L.ipk_devices_sync()
+        if rc < 0:
+            raise RuntimeError("ipk_devices_sync: " + self.L.ipk_last_error().decode())
+
+    def time(self, steps, warmup, prewarm_ms=0.0):
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < prewarm_ms:
+            self.step(); self.sync()
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+
+def single_process_scale(torch, ipa, util, members, W, H, B, data, steps, warmup, host_frames=16, check=True):
+    """The `scale` object of the single-process mode: BASELINE.json configs[3]'s batch on the N members against the same batch on member 0 alone,
+    measured in this process; device-resident (compute_only: results stay on the GPUs that computed them) and host-to-host (8-bit results into the
+    caller's page-locked buffers, ipk_host_pipeline_run_batch_multi: one host thread, three streams and two device slots per member)."""
+    import numpy as np
+    L = ipa.lib()
+    n = len(members)
+    out = {"mode": "ONE process: one ipk_ctx per device (ipk_init_devices), frame i -> member i mod N, ipk_pipeline_run_batch_multi + ipk_devices_sync; "
+                   "no torch.distributed, no RCCL, nothing exchanged between devices (src/pipeline.rs:246-249: frames are independent pipelines)",
+           "devices": [m.device for m in members], "n_gpus": n, "distinct_devices": len({m.device for m in members}),
+           "workload": "%d x %dx%d RGGB f32 frames (BASELINE.json configs[3])" % (B, W, H)}
+    multi = MultiBatch(torch, ipa, util, members, W, H, B, data, util.SEED + 1000)
+    tN = multi.time(steps, warmup, 200.0)
+    out["fused_batch_launches"] = bool(multi.used.value)
+    if check:
+        import oracle
+        i = B - 1                                                   # the last frame: computed on the last member that got one
+        part = multi.srcs[i].cpu().numpy().reshape(H, W)
+        desc = oracle.make_pipeline(part, cfa="RGGB", source_kind=1, blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB,
+                                    cam_to_xyz_normalized=util.cam_matrix())
+        want = torch.from_numpy(oracle.pipeline_run(desc).reshape(-1))
+        got = multi.dsts[i].cpu()
+        if not torch.equal(got.view(torch.int32), want.view(torch.int32)):
+            raise AssertionError("single-process batch: frame %d (device %d) differs from the CPU oracle" % (i, members[i % n].device))
+        out["parity_check"] = "frame %d (computed on set member %d, device %d) bit-identical to the CPU oracle, every sample" % (i, i % n, members[i % n].device)
+    del multi
+    torch.cuda.empty_cache()
+    solo = MultiBatch(torch, ipa, util, members[:1], W, H, B, data, util.SEED + 1000)
+    solo_set = ipa.init_devices([members[0].device])                # the set shrinks to member 0 for the one-GPU reference ...
+    t1 = solo.time(steps, warmup, 200.0)
+    del solo
+    torch.cuda.empty_cache()
+    members2 = ipa.init_devices([m.device for m in members])        # ... and comes back
+    out["n1_batch_ms"] = round(t1, 3)
+    out["compute_only"] = {"ms": round(tN, 3), "speedup": round(t1 / tN, 2), "expected_ms": round(t1 / n, 3), "expected_speedup": float(n),
+                           "MP_per_s": round(B * W * H / 1e6 / (tN * 1e-3), 1)}
+    # host buffers in, host buffers out (what a Rust caller of output_8bit over a shoot sees)
+    try:
+        img = ipa.RawImage(width=W, height=H, data=None, cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                           wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+        d = ipa.Pipeline(img).desc()
+        nb = host_frames
+        in_b, out_b = W * H * 2, W * H * 3
+        sp = [L.ipk_host_alloc(in_b) for _ in range(min(nb, 4))]
+        dp = [L.ipk_host_alloc(out_b) for _ in range(nb)]
+        if not all(sp) or not all(dp):
+            raise RuntimeError("ipk_host_alloc failed")
+        for k, q in enumerate(sp):
+            f = util.noise_u16(util.SEED + 40 + k, H, W)
+            ctypes.memmove(q, f.ctypes.data, in_b)
+        srcs = (ctypes.c_void_p * nb)(*[sp[k % len(sp)] for k in range(nb)]); dsts = (ctypes.c_void_p * nb)(*dp)
+
+        def run(fn):
+            for rep in range(3):                                    # the first call builds the lanes
+                t0 = time.perf_counter()
+                rc = fn(ctypes.byref(d), srcs, dsts, nb, ipa.OUT_U8, None)
+                if rc < 0:
+                    raise RuntimeError(L.ipk_last_error().decode())
+                t = (time.perf_counter() - t0) * 1e3
+            return t
+        tNh = run(L.ipk_host_pipeline_run_batch_multi)
+        first = np.frombuffer((ctypes.c_char * out_b).from_address(dp[0]), dtype=np.uint8).copy()
+        with members2[0]:
+            t1h = run(L.ipk_host_pipeline_run_batch)
+        same = bool(np.array_equal(first, np.frombuffer((ctypes.c_char * out_b).from_address(dp[0]), dtype=np.uint8)))
+        out["host_in_host_out_u8"] = {"frames": nb, "ms": round(tNh, 3), "n1_ms": round(t1h, 3), "speedup": round(t1h / tNh, 2),
+                                      "ms_per_frame": round(tNh / nb, 3), "pcie_bytes_per_frame": {"up": in_b, "down": out_b},
+                                      "same_bytes_as_one_context": same,
+                                      "entry_point": "ipk_host_pipeline_run_batch_multi (u16 host frames -> 8-bit sRGB host frames, page-locked), against ipk_host_pipeline_run_batch on member 0"}
+        for q in sp + dp:
+            L.ipk_host_free(q)
+    except Exception as e:
+        out["host_in_host_out_u8"] = {"ok": False, "error": repr(e)}
+    return out
+
+
+def sp_child(args):
+    """child process of the N > 1 default run: the single-process mode over the same N devices while the ranks wait (its own process: nothing it does
+    can cost the parent its line)"""
+    import torch
+    import imagepipe_amd as ipa
+    import util
+    devs = [int(x) for x in args.sp_child.split(",")]
+    members = ipa.init_devices(devs)
+    small = os.environ.get("IPK_BENCH_DEV_SMALL") == "1"
+    bw, bh, bn = (600, 400, 8) if small else (6000, 4000, 64)
+    res = single_process_scale(torch, ipa, util, members, bw, bh, bn, args.data, max(3, args.steps // 4), 1, host_frames=4 if small else 16)
+    print("SP_CHILD " + json.dumps(res), flush=True)
+
+
+def sp_children(ctx, args):
+    """rank 0 starts sp_child over the job's devices; every rank waits for it at the barrier that follows"""
+    import subprocess
+    res = None
+    if ctx.rank == 0:
+        try:
+            devs = ",".join(str(i) for i in range(ctx.world)) if not ctx.share else ",".join("0" for _ in range(ctx.world))
+            cmd = [sys.executable, os.path.abspath(__file__), "--sp-child", devs, "--steps", str(args.steps), "--data", args.data]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+            for line in r.stdout.splitlines():
+                if line.startswith("SP_CHILD "):
+                    res = json.loads(line[len("SP_CHILD "):])
+            if res is None:
+                res = {"ok": False, "error": "child rc=%s: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+        except Exception as e:
+            res = {"ok": False, "error": repr(e)}
+        if res.get("ok") is False:
+            ctx.fail("scale.single_process", res["error"])
+    ctx.barrier()
+    return res
+
+
+def main_single_process(args):
+    """python bench.py --gpus N --single-process: the same metric and line from ONE process driving N devices (see MultiBatch).  A step is one 100 MP
+    frame per device (weak scaling, as the N-rank line); the judgeable multi-GPU object is `scale` (the 64 x 24 MP batch on N devices against one)."""
+    import torch
+    import imagepipe_amd as ipa
+    import util
+    devs = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devs) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but --devices names %d\n" % (args.gpus, len(devs)))
+        raise SystemExit(2)
+    if max(devs) >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: device %d asked for, %d visible\n" % (max(devs), torch.cuda.device_count()))
+        raise SystemExit(2)
+    members = ipa.init_devices(devs)
+    small = os.environ.get("IPK_BENCH_DEV_SMALL") == "1"
+    W, H = (2048, 1024) if small else (args.width or 10000, args.height or 10000)
+    N = len(members)
+    wl = MultiBatch(torch, ipa, util, members, W, H, N, args.data, util.SEED + 2)
+    for _ in range(args.warmup):
+        wl.step()
+    wl.sync()
+    ms = wl.time(args.steps, args.warmup, args.prewarm_ms)
+    alg = 16.0 * W * H
+    result = {
+        "metric": "megapixels/sec full raw->sRGB pipe, 100 MP f32 frame", "value": round(N * W * H / 1e6 / (ms * 1e-3), 1), "unit": "MP/s",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (%s, 14-bit RGGB sensor values, torch Philox seed 0x%X+frame)" % (args.data, util.SEED + 2),
+        "value_basis": "ONE process, one 100 MP frame per device per step launched from one host thread (ipk_pipeline_run_batch_multi), wall time of the K steps "
+                       "between ipk_devices_sync on both sides; weak scaling, nothing exchanged -- the multi-GPU claim is `scale`",
+        "config": {"workload": "%dx%d (%.0f MP) synthetic RGGB f32 mosaic -> fused gofloat+demosaic+tolab+basecurve+fromlab+gamma -> f32 RGB, one frame per device per step, single process"
+                               % (W, H, W * H / 1e6), "baseline_config": "BASELINE.json configs[2]", "frame": [W, H], "devices": devs, "single_process": True,
+                   "distinct_devices": len(set(devs)), "host_glibc": glibc_version()},
+        "roofline": {"bound": "hbm", "achieved": round(alg * N / (ms * 1e-3) / 1e9 / len(set(devs)), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg * N / (ms * 1e-3) / 1e9 / len(set(devs)) / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_fused_bayer",
+                     "kernel_ms": round(ms * len(set(devs)) / N, 4), "algorithmic_bytes_per_launch": alg,
+                     "note": "per physical device: wall time per step x distinct devices / frames (host-side clock; the one-GPU line carries the HIP-event figure)"},
+    }
+    del wl
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        bw, bh, bn = (600, 400, 8) if small else (6000, 4000, 64)
+        try:
+            result["scale"] = single_process_scale(torch, ipa, util, members, bw, bh, bn, args.data, max(3, args.steps // 4), 1,
+                                                   host_frames=4 if small else 16, check=not args.no_check)
+        except Exception as e:
+            result["scale"] = {"ok": False, "error": repr(e)}
+            result["failed_legs"] = ["scale"]
+    result["scale_is_the_claim"] = "scale" in result and result["scale"].get("ok") is not False
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(util, args.data, args.cpu_seconds)
+    print(json.dumps(result), flush=True)
 
 
 def gather_leg(ctx, wl, steps):

@@ -177,6 +177,7 @@ SIGNATURES = {
     "ipk_abi_sizeof": (_sz, [C.c_int]),
     "ipk_copy_probe": (C.c_int, [_vp, _vp, _sz, _vp]),
     "ipk_mix_probe": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ipk_clock_probe": (C.c_int, [_vp, C.c_uint32, _vp]),
     "ipk_stream_probe": (C.c_int, [C.POINTER(FusedParams), _vp, _vp, _vp]),
     "ipk_selftest_spline3": (C.c_int, [C.c_float, _fp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_quant8": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),

@@ -1270,6 +1270,12 @@ int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream) {
   ipk::launch_mix_probe(src, dst, src_bytes, S(stream)); HIPCHK(hipGetLastError());
   return IPK_OK;
 }
+int ipk_clock_probe(uint64_t *out2_dev, uint32_t spin_us, void *stream) {
+  REQUIRE_INIT();
+  if (!out2_dev || spin_us == 0 || spin_us > 2000000u) return fail(IPK_ERR_INVALID, "ipk_clock_probe: null output or a spin outside (0, 2 s]");
+  ipk::launch_clock_probe(out2_dev, (unsigned long long)spin_us * 100ull, S(stream)); HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
 int ipk_selftest_task_queue(int enabled) { REQUIRE_INIT(); ipk::selftest_task_queue(enabled != 0); return IPK_OK; }
 int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint64_t *n_bad, uint32_t *first_bad_bits) {
   REQUIRE_INIT();

@@ -3215,6 +3215,18 @@ void launch_copy_probe(const void *src, void *dst, size_t bytes, int, hipStream_
   const size_t n16 = bytes / 16;
   hipLaunchKernelGGL(k_copy_probe, dim3((unsigned)std::max<size_t>(1, (n16 + 1023) / 1024)), dim3(256), 0, s, reinterpret_cast<const ipk_f4v *>(src), reinterpret_cast<ipk_f4v *>(dst), n16);
 }
+// Shader clock during whatever else the device runs: one wave spins for spin_ticks of the fixed 100 MHz reference counter (s_memrealtime) and reports
+// how far the shader-clock counter (s_memtime) moved meanwhile.  Launched on a second stream beside the kernel under test (bench.py config.shader_clock_GHz).
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out2, unsigned long long spin_ticks) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < spin_ticks) { __builtin_amdgcn_s_sleep(32); r1 = __builtin_amdgcn_s_memrealtime(); }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out2[0] = c1 - c0; out2[1] = r1 - r0; }
+}
+void launch_clock_probe(void *out2_dev, unsigned long long spin_ticks, hipStream_t s) {
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long *>(out2_dev), spin_ticks);
+}
 // every f32 argument through the arithmetic 3-knot form against the literal search (curves.rs:126-157)
 __global__ void k_selftest_spline3(SplineDev sp, SelftestOut *out) {
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];

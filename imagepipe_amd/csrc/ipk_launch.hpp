@@ -103,7 +103,8 @@ int launch_raster_chain(const FusedLaunch &f, size_t npix, int src_is_u16, const
 // exhaustive on-device checks of the arithmetic shortcuts (see ipk_kernels.hip "Self-test kernels")
 int launch_selftest_cdiv(float c, int variant, unsigned lo_bits, unsigned hi_bits, int include_special, void *out_dev, hipStream_t s);
 void launch_copy_probe(const void *src, void *dst, size_t bytes, int num_cus, hipStream_t s);
-void launch_mix_probe(const void *src, void *dst, size_t src_bytes, hipStream_t s);   // 1 : 3 read : write, dst holds 3 * src_bytes
+void launch_mix_probe(const void *src, void *dst, size_t src_bytes, hipStream_t s);
+void launch_clock_probe(void *out2_dev, unsigned long long spin_ticks, hipStream_t s);   // out2 = {shader-clock cycles, 100 MHz reference ticks} over the spin   // 1 : 3 read : write, dst holds 3 * src_bytes
 int launch_selftest_spline3(const SplineHost &h, void *out_dev, hipStream_t s);
 int launch_selftest_fract(void *out_dev, hipStream_t s);
 int launch_selftest_clamp(void *out_dev, hipStream_t s);

@@ -580,6 +580,11 @@ IPK_API int ipk_copy_probe(const void *src, void *dst, size_t bytes, void *strea
  * contiguous, nontemporal, no arithmetic: the ceiling of ANY kernel with that traffic (bench.py roofline.mix_ceiling_GBps).  dst holds 3 * src_bytes;
  * src_bytes a multiple of 4096 (whole blocks of 256 lanes x 16 bytes), both pointers 16-byte aligned. */
 IPK_API int ipk_mix_probe(const void *src, void *dst, size_t src_bytes, void *stream);
+/* Measurement aid: the shader clock WHILE other work runs.  One wave on `stream` spins for spin_us microseconds of the fixed 100 MHz reference counter
+ * (s_memrealtime) and writes {shader-clock cycles (s_memtime), reference ticks} over that span to out2_dev (two uint64 in device memory): clock in GHz =
+ * out2[0] / out2[1] / 10.  bench.py launches it on a second stream beside the kernel under test (config.shader_clock_GHz), so that a slower box and a
+ * slower kernel can be told apart. */
+IPK_API int ipk_clock_probe(uint64_t *out2_dev, uint32_t spin_us, void *stream);
 /* Measurement aid, no counterpart in the reference: the memory skeleton of ipk_raw_to_srgb as a launch of its own -- the same persistent launch and
  * task walk, the same row loads, OpGoFloat normalisation (src/ops/gofloat.rs:126), demosaic::full (src/ops/demosaic.rs:67-119), LDS staging and
  * nontemporal stores, WITHOUT OpToLab..OpGamma: dst receives the demosaiced R, G, B channels (the first three of demosaic::full's RGBE pixel) as

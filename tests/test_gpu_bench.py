@@ -98,9 +98,53 @@ def test_bench_default_control_flow_with_extras(nproc):
         # and the leg must say so loudly (ok false, named in failed_legs) instead of costing the line or passing silently
         assert d["band_mode"]["ok"] is False and "band_mode" in d["failed_legs"], d.get("band_mode")
         assert d["config"]["ipk_comm"] == {"ranks": 2, "transport": "host"}
+        # ... and the same batch over the same devices from ONE process (rank 0's child, two contexts on the shared GPU here)
+        sp = sc["single_process"]
+        assert sp["n_gpus"] == 2 and sp["devices"] == [0, 0] and sp["compute_only"]["speedup"] > 0 and "bit-identical" in sp["parity_check"], sp
+        assert sp["host_in_host_out_u8"]["same_bytes_as_one_context"] is True
+        assert d["scale_is_the_claim"] is True
     else:
         assert d["failed_legs"] == []
     assert "bit-identical" in d["parity_check"] and "cpu_baseline" in d
+
+
+def test_bench_single_process_over_two_contexts():
+    """python bench.py --gpus 2 --single-process: ONE process, one ipk_ctx per device (two on this box's one GPU), frame i -> member i mod 2 through
+    ipk_pipeline_run_batch_multi; the line keeps the contract and carries the `scale` object of that mode, device-resident and host-to-host"""
+    env = dict(os.environ, IPK_BENCH_DEV_SMALL="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--single-process", "--devices", "0,0", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5",
+                        "--prewarm-ms", "10"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["config"]["single_process"] is True and d["config"]["devices"] == [0, 0] and d["value"] > 0
+    sc = d["scale"]
+    assert sc["n_gpus"] == 2 and sc["distinct_devices"] == 1 and sc["n1_batch_ms"] > 0 and sc["compute_only"]["ms"] > 0 and sc["fused_batch_launches"] is True
+    assert "bit-identical" in sc["parity_check"] and sc["host_in_host_out_u8"]["same_bytes_as_one_context"] is True and d["scale_is_the_claim"] is True
+    # a device list that does not name N devices, or names one the box does not have, is refused without a line
+    for extra in (["--devices", "0"], ["--devices", "0,7"]):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--single-process", "--steps", "1"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_reports_the_box_state_and_the_host_boundary():
+    """config.shader_clock_GHz / socket_power_W (the box's state under the timed workload: a slow box and a slow kernel can be told apart) and the
+    host_boundary object (host Vec in, host Vec out: what a drop-in behind Pipeline::run crosses) in the line"""
+    r = subprocess.run([sys.executable, "bench.py", "--config", "c2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--host-boundary"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    c = d["config"]
+    assert 0.3 < c["shader_clock_GHz"] < 3.0 and "ipk_clock_probe" in c["clock_power_method"], c
+    if "socket_power_W" in c:                                   # hwmon is there on the MI355X boxes; a container without /sys access reports the clock alone
+        assert 50 < c["socket_power_W"] < 2000
+    hb = d["host_boundary"]
+    for k in ("to_u8", "to_f32"):
+        e = hb[k]
+        assert e["ms_per_frame_batched"] > 0 and e["ms_per_frame_single"] > 0 and 0 < e["frac_of_pcie_floor"]["batched"] <= 1.2 and e["used_fused"] is True, e
+    assert "output_8bit" in hb["to_u8"]["parity_check"] and hb["to_f32"]["pcie_bytes_per_frame"]["down"] == 4 * hb["to_u8"]["pcie_bytes_per_frame"]["down"]
+    assert d["failed_legs"] == []
 
 
 def test_bench_batch_mode_and_configs():
