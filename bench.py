@@ -77,6 +77,8 @@ def parse():
                          "the same workload without it is reported as config.cold_ms")
     ap.add_argument("--band", action="store_true",
                     help="additionally time ONE frame row-sharded over the N GPUs with the halo exchange (extra 'band_mode' object)")
+    ap.add_argument("--schedule", choices=["auto", "split"], default="auto",
+                    help="ipk_fused_params.schedule: split = every wave gets two pieces half a frame apart (frames with blown regions; results identical)")
     ap.add_argument("--host-boundary", action="store_true", help="additionally run the host-buffers-in / host-buffers-out leg (`host_boundary`; part of the default run)")
     ap.add_argument("--single-process", action="store_true",
                     help="N GPUs from ONE process, the shape a drop-in behind the reference's Pipeline::run has (no torch.distributed, no RCCL): one ipk_ctx per "
@@ -250,7 +252,7 @@ def timed(ctx, step, steps, warmup, prewarm_ms=0.0):
 class FusedBatch:
     """B frames of W x H through the fused raw->sRGB launch, frame i on rank i mod N; every frame keeps its own output buffer"""
 
-    def __init__(self, ctx, ipa, util, W, H, B, cfa, src_kind, out_kind, data, seed0, points=((0.5, 0.6),), exposure=0.0, linear=False):
+    def __init__(self, ctx, ipa, util, W, H, B, cfa, src_kind, out_kind, data, seed0, points=((0.5, 0.6),), exposure=0.0, linear=False, schedule=0):
         torch = ctx.torch
         self.ctx, self.W, self.H, self.B = ctx, W, H, B
         self.is_float = src_kind == "f32"
@@ -266,7 +268,7 @@ class FusedBatch:
         self.cm = util.cam_matrix()
         self.black, self.white, self.wb = util.BLACK, util.WHITE, util.WB
         self.plan = ipa.FusedPlan(width=W, height=H, is_float=self.is_float, black0=util.BLACK, white0=util.WHITE, cfa=cfa, wb_coeffs=util.WB,
-                                  cam_to_xyz_normalized=self.cm, out_type=self.out_type, points=tuple(points), exposure=exposure, linear=linear)
+                                  cam_to_xyz_normalized=self.cm, out_type=self.out_type, points=tuple(points), exposure=exposure, linear=linear, schedule=schedule)
         self.points, self.exposure, self.linear = [tuple(p) for p in points], exposure, linear
         self.stream = torch.cuda.current_stream().cuda_stream
         self.in_b = 4.0 if self.is_float else 2.0
@@ -680,7 +682,7 @@ def main():
 
     # output_8bit forces linear = false, output_16bit linear = true (src/pipeline.rs:405, :452); Pipeline::run (f32) takes the setting
     linear = {"f32": args.linear, "u8": False, "u16": True}[args.out]
-    curve_kw = dict(points=CURVES[args.curve], exposure=args.exposure, linear=linear)
+    curve_kw = dict(points=CURVES[args.curve], exposure=args.exposure, linear=linear, schedule={"auto": 0, "split": 1}[args.schedule])
     wl = FusedBatch(ctx, ipa, util, W, H, B, cfa, args.src, args.out, args.data, util.SEED + 2, **curve_kw)
 
     # ---- correctness check against the CPU oracle (outside the timed region) ----
@@ -717,7 +719,7 @@ def main():
                                   "one frame per GPU per step" if weak else "%d frames per step, frame i on rank i mod N" % B),
                    "baseline_config": "BASELINE.json configs[%d]" % cidx,
                    "frame": [W, H], "src": args.src, "out": args.out, "frames_per_step": B, "prewarm_ms": args.prewarm_ms,
-                   "curve": args.curve, "curve_points": [list(p) for p in CURVES[args.curve]], "exposure": args.exposure, "linear": linear,
+                   "schedule": args.schedule, "curve": args.curve, "curve_points": [list(p) for p in CURVES[args.curve]], "exposure": args.exposure, "linear": linear,
                    "sharding": "independent frames, no data-path collective", "host_glibc": glibc_version(),
                    "host_cbrtf_matches_device": ipa.lib().ipk_host_libm_matches(None) == 1},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -801,6 +803,12 @@ def main():
             _, m2, md2 = timed(ctx, w2.step, max(5, args.steps // 2), 2, 120.0)     # generating the frame let the clock drop: its own short pre-warm
             other[kind] = {"kernel_ms": round(m2, 4), "kernel_ms_median": round(md2, 4), "frac": round(alg_bytes / (m2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del w2
+            if kind == "photo":
+                # the same frame under IPK_SCHED_SPLIT (a caller's choice for frames with blown regions; bit-identical results)
+                w3 = FusedBatch(ctx, ipa, util, W, H, world, cfa, args.src, args.out, kind, util.SEED + 2, schedule=1)
+                _, m3, md3 = timed(ctx, w3.step, max(5, args.steps // 2), 2, 120.0)
+                other[kind]["schedule_split"] = {"kernel_ms": round(m3, 4), "kernel_ms_median": round(md3, 4), "frac": round(alg_bytes / (m3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                del w3
         result["other_data"] = other
         # BASELINE.json configs[3]: 64 x 24 MP frames, frame i -> rank i mod N, compute-only and with the all-gather of the results
         del wl
@@ -948,7 +956,8 @@ def single_process_scale(torch, ipa, util, members, W, H, B, data, steps, warmup
     torch.cuda.empty_cache()
     members2 = ipa.init_devices([m.device for m in members])        # ... and comes back
     out["n1_batch_ms"] = round(t1, 3)
-    out["compute_only"] = {"ms": round(tN, 3), "speedup": round(t1 / tN, 2), "expected_ms": round(t1 / n, 3), "expected_speedup": float(n),
+    phys = len({m.device for m in members})                        # contexts that share a GPU share its time: the expectation counts physical devices
+    out["compute_only"] = {"ms": round(tN, 3), "speedup": round(t1 / tN, 2), "expected_ms": round(t1 / phys, 3), "expected_speedup": float(phys),
                            "MP_per_s": round(B * W * H / 1e6 / (tN * 1e-3), 1)}
     # host buffers in, host buffers out (what a Rust caller of output_8bit over a shoot sees)
     try:

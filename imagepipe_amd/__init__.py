@@ -685,9 +685,10 @@ class FusedPlan:
 
     def __init__(self, *, width, height, owidth=None, x=0, y=0, is_float=True, black0=0.0, white0=1.0,
                  cfa="RGGB", wb_coeffs=(1.0, 1.0, 1.0, float("nan")), cam_to_xyz_normalized=None, exposure=0.0,
-                 points=((0.5, 0.6),), linear=False, out_type=OUT_F32, band=None):
+                 points=((0.5, 0.6),), linear=False, out_type=OUT_F32, band=None, schedule=0):
         init()
         p = FusedParams()
+        p.schedule = int(schedule)                  # ipk_schedule: IPK_SCHED_AUTO / IPK_SCHED_SPLIT (results do not depend on it)
         p.src_type = SRC_F32 if is_float else SRC_U16
         p.owidth = owidth if owidth is not None else width
         p.x, p.y, p.width, p.height = x, y, width, height

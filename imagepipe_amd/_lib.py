@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("IPK_SO_OVERRIDE") or os.path.join(_HERE, "libimagepipe
 IPK_OK, IPK_NOOP = 0, 1
 SRC_U16, SRC_F32, SRC_RGB8, SRC_RGB16 = 0, 1, 2, 3
 OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
+SCHED_AUTO, SCHED_SPLIT = 0, 1
 OR_NORMAL, OR_HFLIP, OR_ROT180, OR_VFLIP, OR_TRANSPOSE, OR_ROT90, OR_TRANSVERSE, OR_ROT270, OR_UNKNOWN = range(9)
 ROT_NORMAL, ROT_90, ROT_180, ROT_270 = range(4)
 
@@ -42,6 +43,7 @@ class FusedParams(_SizedDesc):
         ("linear", C.c_int), ("out_type", C.c_int),
         ("band_src_row0", _sz), ("band_src_rows", _sz), ("band_out_row0", _sz), ("band_out_rows", _sz),
         ("cfa_width", C.c_int), ("cfa_height", C.c_int),           # later additions are appended, never inserted
+        ("schedule", C.c_int), ("reserved0", C.c_int),
     ]
 
 
@@ -59,6 +61,7 @@ class PipelineDesc(_SizedDesc):
         ("maxwidth", _sz), ("maxheight", _sz),
         ("linear", C.c_int), ("allow_fused", C.c_int), ("use_fastpath", C.c_int),
         ("cfa_width", C.c_int), ("cfa_height", C.c_int),
+        ("schedule", C.c_int), ("reserved0", C.c_int), ("reserved1", C.c_int), ("reserved2", C.c_int),
     ]
 
 

@@ -167,8 +167,8 @@ static int take_desc(const Desc *in, Desc &out) {
   if (have > sizeof(Desc)) return fail(IPK_ERR_INVALID, "descriptor.struct_size %zu is larger than this library's struct (%zu bytes): the caller was built against a newer header", have, sizeof(Desc));
   // Appended fields arrive in whole published layouts only: an object shorter than this library's struct is an object of the FIRST layout (its own
   // sizeof is `oldest` rounded up to the struct's alignment -- the bytes between are that compiler's tail padding, indeterminate, and must not land in
-  // cfa_width), so exactly the first layout's fields are copied.  A later layout adds its boundary to this list.
-  const size_t layouts[] = {oldest, sizeof(Desc)};
+  // cfa_width), so exactly the fields of the newest whole layout the object covers are copied.  A later layout adds its boundary to this list.
+  const size_t layouts[] = {oldest, offsetof(Desc, schedule), sizeof(Desc)};
   size_t take = oldest;
   for (size_t b : layouts) if (b <= have) take = b;
   std::memset(static_cast<void *>(&out), 0, sizeof(Desc));
@@ -608,6 +608,8 @@ size_t ipk_abi_sizeof(int which) {
     case 17: return offsetof(ipk_pipeline_desc, cfa_width);
     case 18: return offsetof(ipk_fused_params, band_src_row0);
     case 19: return offsetof(ipk_pipeline_desc, use_fastpath);
+    case 20: return offsetof(ipk_fused_params, schedule);
+    case 21: return offsetof(ipk_pipeline_desc, schedule);
     default: return 0;
   }
 }
@@ -1124,6 +1126,8 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.out_type = probe ? 4 : p->out_type;
   f.lab_table = cx().lut_plain[ipk::kLutXyzLab]; f.gam_table = cx().lut_plain[ipk::kLutGamma]; f.lab_pairs = cx().lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = cx().lut_pairs[ipk::kLutGamma];
   f.num_cus = cx().num_cus; f.queues = cx().queues;
+  if (p->schedule != IPK_SCHED_AUTO && p->schedule != IPK_SCHED_SPLIT) return fail(IPK_ERR_INVALID, "bad schedule");
+  f.schedule = p->schedule;
   { const int lrc = ipk::launch_fused_bayer(f, S(stream));
     if (lrc == -4) return fail(IPK_ERR_HIP, "kernel launch failed (nothing was enqueued; the stream's task queue is untouched)");
     if (lrc != 0) return fail(IPK_ERR_UNSUPPORTED, probe ? "the stream probe exists for Bayer frames of 256+ columns with validated levels" : "no rotated-space variant for these parameters"); }
@@ -1488,7 +1492,7 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
       std::memcpy(fp.wb_coeffs, d->wb_coeffs, sizeof(fp.wb_coeffs));
       std::memcpy(fp.cam_to_xyz_normalized, d->cam_to_xyz_normalized, sizeof(fp.cam_to_xyz_normalized));
       fp.exposure = d->exposure; fp.npoints = d->npoints; std::memcpy(fp.points, d->points, sizeof(fp.points));
-      fp.linear = linear; fp.out_type = out_type;
+      fp.linear = linear; fp.out_type = out_type; fp.schedule = d->schedule;
       tm.rest = "fused gofloat+demosaic+to_lab+basecurve+from_lab+gamma(+transform)";
       if (transform_noop) {
         rc = ipk_raw_to_srgb(&fp, src, dst, stream);
@@ -2073,7 +2077,7 @@ bool desc_is_one_fused_launch(const ipk_pipeline_desc *d, int out_type, ipk_fuse
   std::memcpy(fp.cam_to_xyz_normalized, d->cam_to_xyz_normalized, sizeof(fp.cam_to_xyz_normalized));
   fp.exposure = d->exposure; fp.npoints = d->npoints; std::memcpy(fp.points, d->points, sizeof(fp.points));
   fp.linear = out_type == IPK_OUT_U8 ? 0 : (out_type == IPK_OUT_U16 ? 1 : d->linear);   // pipeline.rs:405, :452
-  fp.out_type = out_type;
+  fp.out_type = out_type; fp.schedule = d->schedule;
   return true;
 }
 }  // namespace

@@ -2611,6 +2611,12 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
     // eight stores behind one wait for loads (gfx9 counts loads and stores in one vmcnt, so a wave otherwise has one row of stores in flight): 365.5 / 367.0
     // -> 364.4 / 364.1 us at 100 MP on one box, nothing; the same kernel measured 406 us on another box the same day -- these memory-bound kernels move
     // by 10 % from box to box, not with their row loop.)
+    // (Round 6, TWO raw rows in flight per wave -- the row loop unrolled by two with the rows' registers in alternating roles, no spills: the skeleton 0.3256 ->
+    // 0.3313 ms, the kernel 0.4559 / 0.3882 -> 0.4437 / 0.3864 ms noise / photo-like on one pass and 0.4510 / 0.3844 -> 0.4564 / 0.3828 on the next
+    // (gpurun_out ab_r06_pf2.txt): more loads in flight buy nothing, the walk is not waiting for latency.  hipcc also drains vmcnt to 0 at the first wait
+    // behind a loop's back edge whatever is younger, so half the intended overlap never happened.  What the walk costs the memory system was then measured
+    // without any arithmetic (tools/walk_probe.hip, profiles/README.md): 256-pixel strips 0.595 of the HBM peak, 512- or 1024-pixel strips 0.646, a flat
+    // launch of the same traffic 0.71; tasks walked as an advancing band of rows 0.50-0.56.)
     for (uint32_t r = r0, r1d = r1; r < r1d; ++r) {
       uint32_t e_now = r1;
       if (steal_on) {                                       // where this wave is, and where its task ends by now (asked for here, looked at behind the row)
@@ -2902,6 +2908,13 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   (void)task_counters_for(f.queues, s, a, queue_lock);
   unsigned blocks;
   fused_task_grid(a, f.num_cus, blocks);
+  // IPK_SCHED_SPLIT (include/imagepipe_amd.h): the one-task-per-wave schedule with every segment cut in two, walked statically -- wave i takes tasks i and
+  // i + n_waves, which lie half a frame apart, so a region that costs more (blown highlights: the cube-root path) is shared by twice as many waves, at one
+  // more priming per wave.  Round 5 measured it as a build flag (100 MP: photo-like 0.3812 -> 0.3683 / 0.3791 -> 0.3709 ms, noise 0.4600 -> 0.4648 /
+  // 0.464 -> 0.458, smooth 0.4298 -> 0.4515: which regions a wave pairs is the luck of the frame) -- hence a caller's choice, not a default.
+  if (f.schedule == 1 && a.n_strips * a.n_segs <= (uint32_t)(f.num_cus > 0 ? f.num_cus : 256) * 16u && (a.out_r1 - a.out_r0) / a.n_segs >= 40u) {
+    a.n_segs *= 2u; a.task_ctr = nullptr;
+  }
   if (f.out_type == 4) {                                  // ipk_stream_probe: the skeleton of the headline variants (Bayer phase, full strips, no guards)
     if (a.gen_cells || a.ori != 0 || a.W < 256u || a.exact_norm || std::fabs(a.min0) < 0x1p-70f || std::fabs(a.min0) > 0x1p70f) return -2;
     if (!f.src_is_u16) hipLaunchKernelGGL((k_fused_bayer<float, true, 4, true, false, false, true>), dim3(blocks), dim3(1024), 0, s, a);
@@ -2936,9 +2949,12 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
 // redo behind a wave-uniform branch, stops behind xyz_to_lab; only the Lab table lives in LDS (32 KB: several blocks per CU).
 // TOLAB_ONLY takes TWO pixels per lane (128-pixel chunks): with half the live values the compiler keeps the kernel to 64 vector registers, so that two
 // blocks (66 KB of LDS each) share a CU -- eight waves per SIMD instead of four cover the load latency this kernel otherwise sits in.
-template <bool TOLAB_ONLY>
+// NPV = pixel PAIRS per lane of the full chain: 2 (256-pixel chunks), or 1 for small frames -- a preview of 3 MP is three chunks per wave, and its time is the
+// launch, the table fill and the first and last round trips rather than the pixels: with six shorter chunks per wave the four waves of a SIMD fill and drain
+// their pipeline in half the time (config 5's 2160x1440: 21.0 -> 20.3 us; at 24 and 100 MP the long chunks win by 1-3 %, gpurun_out ab_r06_chainnp1.txt).
+template <bool TOLAB_ONLY, int NPV = 2>
 __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_t npix) {
-  constexpr int NP = TOLAB_ONLY ? 1 : 2, PPL = 2 * NP;                  // pixel pairs / pixels per lane
+  constexpr int NP = TOLAB_ONLY ? 1 : NPV, PPL = 2 * NP;                // pixel pairs / pixels per lane
   constexpr uint64_t CH = 64u * PPL;                                   // pixels per wave step
   __shared__ __attribute__((aligned(16))) LabTab s_lab[kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) GamTab s_gam[TOLAB_ONLY ? 4 : kLutPairs + 4];
@@ -2963,6 +2979,8 @@ __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_
   f3 *dst = reinterpret_cast<f3 *>(a.dst);
   // (round 5: the next chunk's pixels loaded during this one's arithmetic need 71 registers; held to the 64 that two resident blocks allow, the
   // spills double the kernel's time, 477 -> 882 us)
+  // (round 6: the NEXT chunk's loads issued behind this chunk's -- the full chain has the 16 registers to spare at one block per CU: 27.7 / 191.6 / 661 us
+  // at 3.1 / 24 / 100 MP against 27.7 / 190.9 / 651 without, gpurun_out ab_r06_chainpf.txt: the four waves of a SIMD already cover each other's loads)
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t base = chunk * CH + lane;
     float4 px[PPL];
@@ -3001,6 +3019,7 @@ __device__ __forceinline__ void pointwise_chain_body(const FusedArgs &a, uint64_
 }
 template <bool TOLAB_ONLY>
 __global__ __launch_bounds__(1024) void k_pointwise_chain(FusedArgs a, uint64_t npix) { pointwise_chain_body<TOLAB_ONLY>(a, npix); }
+__global__ __launch_bounds__(1024) void k_pointwise_chain_small(FusedArgs a, uint64_t npix) { pointwise_chain_body<false, 1>(a, npix); }
 // OpToLab alone: two resident blocks per CU (eight waves per SIMD) are the point of its two-pixel form, so the register budget is stated (64)
 template <>
 __global__ __launch_bounds__(1024, 8) void k_pointwise_chain<true>(FusedArgs a, uint64_t npix) { pointwise_chain_body<true>(a, npix); }
@@ -3020,6 +3039,12 @@ static FusedArgs chain_args(const FusedLaunch &f) {
 }
 int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s) {
   FusedArgs a = chain_args(f);
+  const unsigned cus = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
+  if (npix < (size_t)cus * 16u * 256u * 6u) {                              // fewer than six long chunks per wave (6.3 MP on 256 CUs): the two-pixel form
+    const size_t chunks = (npix + 127) / 128;
+    hipLaunchKernelGGL(k_pointwise_chain_small, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(cus, (chunks + 15) / 16))), dim3(1024), 0, s, a, (uint64_t)npix);
+    return 0;
+  }
   const size_t chunks = (npix + 255) / 256;
   const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);                      // (more blocks measured: 1 / 2 / 4 / 8 / 16 per CU 0.663 / 0.665 / 0.677 / 0.673 / 0.704 ms at 100 MP)
   const unsigned blocks = (unsigned)std::min<size_t>(cap, (chunks + 15) / 16);

@@ -82,6 +82,7 @@ struct FusedLaunch {
   int px_guard;                  // 0: u16 source whose levels and parameters the host found ordinary (kernel variant without per-pixel input guards)
   const float *gen_cells; int gen_pw, gen_ph, gen_check;   // generic-CFA mode (device cell records) or null: RGGB phase (xoff, yoff)
   int num_cus;
+  int schedule;                  // ipk_schedule (launch_fused_bayer, single frames on the static schedule only)
   TaskQueues *queues;            // the launching context's task queues (launch_fused_bayer only; may be null)
   int ori;                       // 0, or the ipk_orientation (Rotate90 / Rotate270) in whose rotated space the launch works: src is the permuted mosaic
   int roles[4];                  // ori != 0: demosaic role of the rotated-space pixel with parities (row & 1, col & 1), index 2 * row parity + col parity

@@ -72,8 +72,9 @@ IPK_API int ipk_init(int device);
 IPK_API void ipk_shutdown(void);
 IPK_API int ipk_is_initialized(void);
 /* sizeof / offsetof of the descriptor structs as this library was built, so that a binding can check its own layout before the first call:
- * which = 0 ipk_fused_params, 1 ipk_pipeline_desc, 2 ipk_band, 3 ipk_stage_time; 16 / 17 offsetof(cfa_width) in the first two (the appended
- * fields), 18 offsetof(ipk_fused_params, band_src_row0), 19 offsetof(ipk_pipeline_desc, use_fastpath); anything else 0.  No GPU needed. */
+ * which = 0 ipk_fused_params, 1 ipk_pipeline_desc, 2 ipk_band, 3 ipk_stage_time; 16 / 17 offsetof(cfa_width) in the first two (the end of the
+ * first published layout), 18 offsetof(ipk_fused_params, band_src_row0), 19 offsetof(ipk_pipeline_desc, use_fastpath), 20 / 21 offsetof(schedule) in
+ * the first two (the end of the second layout); anything else 0.  No GPU needed. */
 IPK_API size_t ipk_abi_sizeof(int which);
 /* Human-readable description of the last failure on this thread (never NULL). */
 IPK_API const char *ipk_last_error(void);
@@ -283,6 +284,15 @@ IPK_API int ipk_output16bit(const float *src, size_t n, uint16_t *dst, void *str
 /* Fused raw -> sRGB (gofloat + demosaic::full + tolab + basecurve + fromlab + gamma [+ quantise]) */
 /* ---------------------------------------------------------------------------------------- */
 
+/* How a fused launch deals a single frame's row segments to its waves.  The reference's Rayon loops balance themselves by work stealing
+ * (src/ops/demosaic.rs:93-116: one task per output row); a persistent GPU launch fixes each wave's rows up front, so a frame whose regions cost
+ * differently -- blown highlights take the cube-root path of XYZ_LAB_TRANSFORM.lookup, src/color_conversions.rs:102-104 -- finishes on its
+ * slowest waves.  IPK_SCHED_SPLIT gives every wave two pieces half a frame apart instead of one contiguous piece: a blown region is shared by
+ * twice as many waves (photo-like 100 MP frame: -2...-3.4 %), at one more three-row priming per wave (uniform frames: +1...+5 %).  A caller
+ * that knows its frames (a shoot with clipped skies) sets it; AUTO is the contiguous schedule.  Batches and frames above ~130 MP draw their
+ * tasks from a queue and ignore the field.  Results are bit-identical under every schedule. */
+typedef enum { IPK_SCHED_AUTO = 0, IPK_SCHED_SPLIT = 1 } ipk_schedule;
+
 /* Everything the ops between OpGoFloat and OpGamma read, for a CFA raw source at full scale with
  * a no-op rotatecrop (the default Pipeline::run on a RawImage). */
 typedef struct {
@@ -312,6 +322,9 @@ typedef struct {
    * compare whole layouts at start-up (tests/test_rust_binding.py checks the generated Rust layout the same way). */
   int cfa_width, cfa_height;       /* the tile's shape as the caller's CFA object has it (cfa.width / cfa.height, src/ops/demosaic.rs:33); 0, 0 = take
                                       it from the string (a "WxH:" prefix, or the letter count 4 / 36 / 144).  16 letters need one of the two. */
+  /* third layout */
+  int schedule;                    /* ipk_schedule: how the launch shares a frame's rows out among the waves (results do not depend on it) */
+  int reserved0;                   /* 0 */
 } ipk_fused_params;
 #define IPK_FUSED_PARAMS_INIT {(uint32_t)sizeof(ipk_fused_params)}      /* ipk_fused_params p = IPK_FUSED_PARAMS_INIT;  (everything else zero) */
 
@@ -379,6 +392,10 @@ typedef struct {
   int use_fastpath;                /* PipelineSettings.use_fastpath (pipeline.rs:117; the reference defaults it to true) */
   /* later additions are appended (see ipk_fused_params) */
   int cfa_width, cfa_height;       /* as in ipk_fused_params: the tile's shape from the caller's CFA object, 0, 0 = from the string */
+  /* third layout */
+  int schedule;                    /* ipk_schedule, handed to the fused launch when the run is one */
+  int reserved0;                   /* 0 */
+  int reserved1, reserved2;        /* 0 (the struct's end moves past the second layout's tail padding, so that a size tells the layouts apart) */
 } ipk_pipeline_desc;
 #define IPK_PIPELINE_DESC_INIT {(uint32_t)sizeof(ipk_pipeline_desc)}
 

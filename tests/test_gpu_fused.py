@@ -1287,3 +1287,29 @@ def test_fused_variants_quantised_outputs_24mp_vs_oracle(ipa, orc, is_float, vid
     assert np.array_equal(o8.cpu().numpy().reshape(h, w, 3), orc.pipeline_output_8bit(desc))
     w, h, o16 = pipe.output_16bit()
     assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(h, w, 3), orc.pipeline_output_16bit(desc))
+
+
+@pytest.mark.parametrize("h,w,src", [(6000, 8000, "u16"), (1200, 3000, "f32"), (97, 300, "u16")])
+def test_schedule_split_is_bit_identical(h, w, src):
+    """ipk_fused_params.schedule = IPK_SCHED_SPLIT deals every wave two pieces half a frame apart (48 MP: it applies; the small frames: it falls back to
+    the contiguous schedule); whatever the launch does with the field, every output sample equals the AUTO launch's, and a bad value is refused"""
+    import torch
+    import imagepipe_amd as ipa
+    ipa.init(0)
+    raw = util.noise_u16(util.SEED + 1234, h, w)
+    raw[h // 3: h // 3 + h // 8, w // 4: w // 2] = 16383                       # a blown patch: the region the split schedule exists for
+    src_t = torch.from_numpy(raw.astype(np.float32)).cuda().reshape(-1) if src == "f32" else torch.from_numpy(raw.view(np.int16)).cuda().reshape(-1)
+    kw = dict(width=w, height=h, is_float=src == "f32", black0=util.BLACK, white0=util.WHITE, cfa="RGGB", wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    a = ipa.FusedPlan(**kw)
+    b = ipa.FusedPlan(schedule=1, **kw)
+    oa, ob = a.new_output(), b.new_output()
+    a.run(src_t, oa); b.run(src_t, ob)
+    torch.cuda.synchronize()
+    assert torch.equal(oa.view(torch.int32), ob.view(torch.int32))
+    if h * w < 1000000:
+        import oracle
+        want = oracle.pipeline_run(oracle.make_pipeline(raw.astype(np.float32) if src == "f32" else raw, cfa="RGGB", source_kind=1 if src == "f32" else 0,
+                                                        blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix()))
+        util.assert_bits_equal(ob.cpu().numpy().reshape(h, w, 3), want, "split schedule vs oracle")
+    with pytest.raises(ipa.IpkError, match="schedule"):
+        ipa.FusedPlan(schedule=7, **kw).run(src_t, ob)

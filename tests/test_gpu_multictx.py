@@ -263,10 +263,18 @@ def test_fused_params_first_layout_object_is_accepted(L, orc):
     assert_bits_equal(out, want, "full-size descriptor")
     p.cfa_width = 7; p.cfa_height = 3                               # poison behind the first layout's end
     assert L.ipk_host_raw_to_srgb(C.byref(p), P(raw), P(out)) == -2
-    p.struct_size = C.sizeof(FusedParams) - 8
+    p.struct_size = (L.ipk_abi_sizeof(16) + 7) // 8 * 8             # sizeof of the first published layout
     out[:] = 0
     assert L.ipk_host_raw_to_srgb(C.byref(p), P(raw), P(out)) == 0, L.ipk_last_error()
     assert_bits_equal(out, want, "first-layout descriptor")
+    p.cfa_width = 0; p.cfa_height = 0; p.schedule = 99             # the second layout ends in front of `schedule`
+    p.struct_size = C.sizeof(FusedParams)
+    assert L.ipk_host_raw_to_srgb(C.byref(p), P(raw), P(out)) == -2 and b"schedule" in L.ipk_last_error()
+    p.struct_size = (L.ipk_abi_sizeof(20) + 7) // 8 * 8
+    out[:] = 0
+    assert L.ipk_host_raw_to_srgb(C.byref(p), P(raw), P(out)) == 0, L.ipk_last_error()
+    assert_bits_equal(out, want, "second-layout descriptor")
+    p.schedule = 0
     for bad in (0, 16, C.sizeof(FusedParams) + 8):
         p.struct_size = bad
         assert L.ipk_host_raw_to_srgb(C.byref(p), P(raw), P(out)) == -2, bad

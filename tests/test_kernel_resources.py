@@ -22,6 +22,7 @@ NO_SCRATCH = [
     (r"k_raw_scaled_demosaic_w8m<(float|unsigned short), \du, true>", 80),                  # four-colour filters: six
     (r"k_pointwise_chain<true>", 64),                                                       # two resident 1024-thread blocks
     (r"k_pointwise_chain<false>", 128),
+    (r"k_pointwise_chain_small", 128),                                                      # the two-pixel form of the full chain (small frames)
     (r"k_gamma|k_fromlab|k_basecurve|k_output8|k_output16", 128),
 ]
 

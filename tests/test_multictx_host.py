@@ -92,15 +92,19 @@ def test_new_descriptors_state_their_size(L):
     assert _lib.PipelineDesc.struct_size.offset == 0 and _lib.FusedParams.struct_size.offset == 0
 
 
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
 def test_a_caller_compiled_against_the_first_layout_is_accepted(L):
-    """an object 8 bytes short -- everything in front of cfa_width / cfa_height -- works, with shape-from-string semantics, and the library never
-    reads the 8 bytes behind it (they hold a shape that contradicts the string here: read, they would fail the call)"""
+    """an object that ends in front of cfa_width / cfa_height (the first published layout: 8 bytes short of the second) works, with shape-from-string
+    semantics, and the library never reads the bytes behind it (they hold a shape that contradicts the string here: read, they would change the call)"""
     full = _desc()
     rc, want = _sizes(L, full)
     assert rc == 0
-    old = _desc(cfa_width=7, cfa_height=3)                    # poison behind the caller's end
-    old.struct_size = C.sizeof(type(old)) - 8                 # sizeof of the first published layout (offsetof(cfa_width) = ipk_abi_sizeof(17), rounded up to 8)
-    assert L.ipk_abi_sizeof(17) <= old.struct_size < L.ipk_abi_sizeof(17) + 8
+    old = _desc(cfa_width=7, cfa_height=3, schedule=99)       # poison behind the caller's end
+    old.struct_size = _round8(L.ipk_abi_sizeof(17))           # sizeof of the first published layout: offsetof(cfa_width), rounded up to the struct's alignment
+    assert old.struct_size == _round8(L.ipk_abi_sizeof(21)) - 8 < C.sizeof(type(old))
     rc, got = _sizes(L, old)
     assert rc == 0, L.ipk_last_error()
     assert got == want
@@ -121,6 +125,21 @@ def test_a_caller_compiled_against_the_first_layout_is_accepted(L):
     assert L.ipk_pipeline_hashes(C.byref(o16), 0, 0, h_old) == 0 and L.ipk_pipeline_hashes(C.byref(f16), 0, 0, h_full) == 0 and h_old.raw == h_full.raw
 
 
+def test_a_caller_compiled_against_the_second_layout_is_accepted(L):
+    """the second layout ends in front of `schedule`: its callers' objects carry cfa_width / cfa_height (read) and tail padding where the third layout's
+    first field now lies (NOT read: a poisoned schedule there would be refused by the compute entry points, and is ignored here)"""
+    pat16 = b"RGBGRGBGBGRGBGRG"
+    second = _desc(cfa=pat16, cfa_width=8, cfa_height=2, schedule=99)
+    second.struct_size = _round8(L.ipk_abi_sizeof(21))
+    assert L.ipk_abi_sizeof(21) <= second.struct_size < C.sizeof(type(second))
+    assert _sizes(L, second)[0] == 0, L.ipk_last_error()      # the shape fields were read (16 letters need them) ...
+    third = _desc(cfa=pat16, cfa_width=8, cfa_height=2)
+    h2, h3 = C.create_string_buffer(256), C.create_string_buffer(256)
+    assert L.ipk_pipeline_hashes(C.byref(second), 0, 0, h2) == 0 and L.ipk_pipeline_hashes(C.byref(third), 0, 0, h3) == 0 and h2.raw == h3.raw
+    from imagepipe_amd import _lib
+    assert _lib.FusedParams.schedule.offset == L.ipk_abi_sizeof(20) and _lib.PipelineDesc.schedule.offset == L.ipk_abi_sizeof(21)
+
+
 @pytest.mark.parametrize("bad,word", [(0, b"struct_size is 0"), (8, b"smaller than the first published layout"), (None, b"newer header")])
 def test_impossible_sizes_are_refused(L, bad, word):
     d = _desc()
@@ -135,5 +154,8 @@ def test_fused_params_versioning_without_a_gpu(L):
     """ipk_fused_params goes through the same gate; without a GPU the size check cannot be reached through a compute call (NOT_INIT comes first), so
     the layout facts are checked here and the behaviour in tests/test_gpu_multictx.py"""
     from imagepipe_amd import _lib
-    assert L.ipk_abi_sizeof(16) == _lib.FusedParams.cfa_width.offset and C.sizeof(_lib.FusedParams) - 8 <= L.ipk_abi_sizeof(16) + 7
-    assert L.ipk_abi_sizeof(17) == _lib.PipelineDesc.cfa_width.offset and C.sizeof(_lib.PipelineDesc) - 8 <= L.ipk_abi_sizeof(17) + 7
+    assert L.ipk_abi_sizeof(16) == _lib.FusedParams.cfa_width.offset < L.ipk_abi_sizeof(20) == _lib.FusedParams.schedule.offset < C.sizeof(_lib.FusedParams)
+    assert L.ipk_abi_sizeof(17) == _lib.PipelineDesc.cfa_width.offset < L.ipk_abi_sizeof(21) == _lib.PipelineDesc.schedule.offset < C.sizeof(_lib.PipelineDesc)
+    # the end of every layout differs from the next one's by at least the struct's alignment, or a size could not tell them apart
+    for t, a, b in ((_lib.FusedParams, 16, 20), (_lib.PipelineDesc, 17, 21)):
+        assert _round8(L.ipk_abi_sizeof(a)) < _round8(L.ipk_abi_sizeof(b)) < C.sizeof(t)
