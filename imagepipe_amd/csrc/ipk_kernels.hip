@@ -1956,6 +1956,8 @@ template <typename SrcT, bool VEC>
 __device__ __forceinline__ void load_raw4(const SrcT *p, uint32_t nvalid, float &v0, float &v1, float &v2, float &v3);
 template <>
 __device__ __forceinline__ void load_raw4<float, true>(const float *p, uint32_t nvalid, float &v0, float &v1, float &v2, float &v3) {
+  // (round 6: these row loads nontemporal -- the skeleton 0.297 -> 0.315 ms at 100 MP, 0.0666 -> 0.081 at 24 MP, the kernel +0...4 %: the halo rows and a
+  // frame launched again are re-reads the caches serve; gpurun_out ab_r06_ntld.txt)
   if (nvalid == 4) { const f4u t = *reinterpret_cast<const f4u *>(p); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
   else { v0 = nvalid > 0 ? p[0] : 0.0f; v1 = nvalid > 1 ? p[1] : 0.0f; v2 = nvalid > 2 ? p[2] : 0.0f; v3 = 0.0f; }
 }

@@ -43,6 +43,8 @@ done
 # 4c. the stream probe (the fused kernel's memory skeleton) under the kernel trace, and the staged kernels of the 100 MP pipeline
 IPK_BENCH_NO_LIVE_PMC=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_probe -o s -- python bench.py --no-cpu-baseline --no-check --steps 20 > $OUT/bench_probe.log 2>&1
 ONLY=C3 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_staged -o s -- python tools/bench_configs.py > $OUT/bench_staged.log 2>&1
+# 4d. the single-process multi-device mode on the hardware there is: two contexts on the one GPU
+python bench.py --gpus 2 --single-process --devices 0,0 --no-cpu-baseline > $OUT/bench_sp.json 2> $OUT/bench_sp.err
 # 5. the plain default run, exactly as the driver issues it
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 tail -n 1 $OUT/bench_plain.json | cut -c1-400

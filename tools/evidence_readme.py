@@ -63,10 +63,31 @@ def glance():
             rows.append(("launch-to-launch spread, steady state (%d single launches)" % ls["launches"], t))
         if "other_data" in b:
             o = b["other_data"]
-            rows.append(("other data kinds", ", ".join("%s %.4f ms (%.3f)" % (k, o[k]["kernel_ms"], o[k]["frac"]) for k in sorted(o))))
+            t = ", ".join("%s %.4f ms (%.3f)" % (k, o[k]["kernel_ms"], o[k]["frac"]) for k in sorted(o))
+            if "schedule_split" in o.get("photo", {}):
+                t += "; photo under `IPK_SCHED_SPLIT` %.4f ms (%.3f)" % (o["photo"]["schedule_split"]["kernel_ms"], o["photo"]["schedule_split"]["frac"])
+            rows.append(("other data kinds", t))
+        cfg = b.get("config", {})
+        if "shader_clock_GHz" in cfg:
+            rows.append(("the box's state under the timed workload (`config.*`, `ipk_clock_probe` + hwmon)", "shader clock %.3f GHz (spans %.3f–%.3f)%s; **%.4f M shader cycles per launch** (`roofline.kernel_Mcycles` = kernel_ms × clock: the box-independent figure)" % (
+                cfg["shader_clock_GHz"], cfg["shader_clock_GHz_min_max"][0], cfg["shader_clock_GHz_min_max"][1],
+                ", socket power %.0f W (max %.0f)" % (cfg["socket_power_W"], cfg["socket_power_W_max"]) if "socket_power_W" in cfg else "", r.get("kernel_Mcycles", float("nan")))))
+        hb = b.get("host_boundary")
+        if hb and "to_u8" in hb:
+            rows.append(("host boundary: 24 MP u16 in HOST memory → sRGB in HOST memory (`host_boundary`, `ipk_host_pipeline_run(_batch)`, page-locked)", "; ".join(
+                "%s %.2f ms alone / **%.2f ms per frame batched** (PCIe floor %.2f: %.2f)" % (k.replace("to_", "→ "), hb[k]["ms_per_frame_single"], hb[k]["ms_per_frame_batched"],
+                                                                                           hb[k]["pcie_floor_ms"]["batched (directions overlap)"], hb[k]["frac_of_pcie_floor"]["batched"]) for k in ("to_u8", "to_f32") if k in hb)))
         if "cpu_baseline" in b:
             cb = b["cpu_baseline"]
             rows.append(("CPU baseline (`kind: %s`)" % cb["kind"], "%.1f %s on %d cores" % (cb["value"], cb["unit"], cb["cores"])))
+    sp1 = C.get("single_process_two_contexts_one_gpu", {}).get("scale")
+    if sp1 and "compute_only" in sp1:
+        t = "64 × 24 MP over two contexts on ONE GPU %.2f ms against %.2f ms on one context (%.2f×; expected %.0f× for %d physical device)" % (
+            sp1["compute_only"]["ms"], sp1["n1_batch_ms"], sp1["compute_only"]["speedup"], sp1["compute_only"]["expected_speedup"], sp1["distinct_devices"])
+        h2 = sp1.get("host_in_host_out_u8", {})
+        if "ms_per_frame" in h2:
+            t += "; host-to-host 8-bit %.2f ms per frame; same bytes as one context: %s" % (h2["ms_per_frame"], h2.get("same_bytes_as_one_context"))
+        rows.append(("single-process multi-device mode (`bench.py --gpus 2 --single-process --devices 0,0`; no second GPU exists here)", t))
     if "stream_probe" in C:
         sp = C["stream_probe"]
         rows.append(("stream probe under rocprofv3", "%d calls, average %.1f µs = %.3f of peak" % (sp["calls"], sp["average_us"], sp["frac_of_8TBps"])))

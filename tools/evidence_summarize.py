@@ -147,6 +147,10 @@ if f:
 bl = bench_line(os.path.join(src, "bench_plain.json"))
 if bl:
     out["bench_line"] = bl
+bl = bench_line(os.path.join(src, "bench_sp.json"))
+if bl:
+    out["single_process_two_contexts_one_gpu"] = {"command": "python bench.py --gpus 2 --single-process --devices 0,0 --no-cpu-baseline", "value": bl.get("value"),
+                                                  "ms_per_step": bl.get("ms_per_step"), "scale": bl.get("scale")}
 json.dump(out, open(os.path.join(dst, tag + "_counters.json"), "w"), indent=1, sort_keys=True)
 
 # ---- the VALU-issue account ---------------------------------------------------------------------------------------------------------------

@@ -29,8 +29,21 @@ __global__ __launch_bounds__(1024) void k_walk(Args a) {
       t = ((wv / 4u) * gridDim.x + blockIdx.x) * 4u + (wv % 4u) + k * n_waves;
     } else if (a.mode == 1) {                              // plain: wave g takes task g (a block = sixteen neighbouring strips of one segment)
       t = g + k * n_waves;
-    } else {                                               // 2: segment-major rounds: all waves work inside one advancing band of rows
+    } else if (a.mode == 2) {                              // segment-major rounds: all waves work inside one advancing band of rows
       t = g + k * n_waves;
+    } else if (a.mode == 3) {                              // spread 1: every wave of a block a whole round of blocks apart
+      t = wv * gridDim.x + blockIdx.x + k * n_waves;
+    } else if (a.mode == 4) {                              // spread 2
+      t = ((wv / 2u) * gridDim.x + blockIdx.x) * 2u + (wv % 2u) + k * n_waves;
+    } else if (a.mode == 5) {                              // spread 8
+      t = ((wv / 8u) * gridDim.x + blockIdx.x) * 8u + (wv % 8u) + k * n_waves;
+    } else if (a.mode == 6) {                              // the kernel's dealing over a STRIP-major numbering (neighbouring tasks = vertically adjacent segments)
+      const unsigned u = ((wv / 4u) * gridDim.x + blockIdx.x) * 4u + (wv % 4u) + k * n_waves;
+      t = u < a.n_tasks ? (u % a.n_segs) * a.n_strips + u / a.n_segs : u;
+    } else {                                               // 7: XCD-contiguous: block b runs on XCD b % 8; XCD x gets the x-th eighth of the tasks
+      const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (a.n_tasks + 7u) / 8u;
+      const unsigned u = (j * 16u + wv) + k * (n_waves / 8u);
+      t = u < per ? xcd * per + u : 0xFFFFFFFFu;
     }
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= a.n_tasks) break;
@@ -95,6 +108,13 @@ int main(int argc, char **argv) {
     run("512-px strips, one task per wave, the kernel's dealing", 2, 0, 0);
     run("512-px strips, one task per wave, wave g = task g", 2, 1, 0);
     run("1024-px strips, one task per wave, the kernel's dealing", 4, 0, 0);
+    run("256-px strips, spread 1", 1, 3, 0);
+    run("256-px strips, spread 2", 1, 4, 0);
+    run("256-px strips, spread 8", 1, 5, 0);
+    run("256-px strips, kernel's dealing over strip-major tasks", 1, 6, 0);
+    run("256-px strips, one eighth of the frame per XCD", 1, 7, 0);
+    run("512-px strips, spread 1", 2, 3, 0);
+    run("512-px strips, one eighth of the frame per XCD", 2, 7, 0);
     run("256-px strips, 32-row tasks walked in order (band)", 1, 2, 32);
     run("256-px strips, 8-row tasks walked in order (band)", 1, 2, 8);
     run("512-px strips, 16-row tasks walked in order (band)", 2, 2, 16);
