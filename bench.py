@@ -79,6 +79,8 @@ def parse():
                     help="additionally time ONE frame row-sharded over the N GPUs with the halo exchange (extra 'band_mode' object)")
     ap.add_argument("--schedule", choices=["auto", "split"], default="auto",
                     help="ipk_fused_params.schedule: split = every wave gets two pieces half a frame apart (frames with blown regions; results identical)")
+    ap.add_argument("--no-box-state", action="store_true", help="skip the shader-clock / socket-power leg (config.shader_clock_GHz ...): a second of extra launches, "
+                                                               "unwanted when a profiler averages over every launch of the run")
     ap.add_argument("--host-boundary", action="store_true", help="additionally run the host-buffers-in / host-buffers-out leg (`host_boundary`; part of the default run)")
     ap.add_argument("--single-process", action="store_true",
                     help="N GPUs from ONE process, the shape a drop-in behind the reference's Pipeline::run has (no torch.distributed, no RCCL): one ipk_ctx per "
@@ -739,7 +741,7 @@ def main():
                                  "in this run and beside expected_ms from the xGMI link arithmetic), not this number")
     if cold_ms is not None:
         result["config"]["cold_ms"] = round(cold_ms / wl.launches_per_step, 4)
-    if cold_ms is not None and not dev_small:
+    if cold_ms is not None and not dev_small and not args.no_box_state:
         # the box's state under this workload, straight behind the timed region (the clock is where the timed steps left it)
         try:
             result["config"].update(clock_power_leg(ctx, wl))

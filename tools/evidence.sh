@@ -27,7 +27,7 @@ pmc ubench "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRB
 # 4. configs[3] (the batch kernel), configs[1] (24 MP), configs[4] (scaled X-Trans): kernel-trace stats at the loaded clock + traffic
 for c in c4 c2 c5; do
   extra=""; [ $c = c4 ] && extra="--steps 5 --warmup 1"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o s -- python bench.py --config $c --no-cpu-baseline --no-check $extra > $OUT/bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o s -- python bench.py --config $c --no-cpu-baseline --no-check --no-box-state $extra > $OUT/bench_$c.log 2>&1
   pmc fetch_$c FETCH_SIZE python bench.py --config $c --no-cpu-baseline --no-check --steps 3 --warmup 1 --prewarm-ms 0
   pmc write_$c WRITE_SIZE python bench.py --config $c --no-cpu-baseline --no-check --steps 3 --warmup 1 --prewarm-ms 0
 done
