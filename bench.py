@@ -552,7 +552,10 @@ def host_boundary_leg(ctx, ipa, util, n=6, check=True):
     """The boundary a drop-in actually crosses (Rust Vecs in, Vecs out): BASELINE.json configs[1]'s 24 MP frame as u16 sensor data in HOST
     memory -> f32 / 8-bit sRGB in HOST memory through ipk_host_pipeline_run (one frame, synchronous: upload + kernel + download in turn) and
     ipk_host_pipeline_run_batch (three streams over two device slots: per-frame cost tends to the slowest of the three).  Page-locked buffers
-    (ipk_host_alloc).  pcie_floor_ms = the bytes of the busier direction / 63 GB/s (PCIe 5.0 x16, one direction); frac = floor / measured."""
+    (ipk_host_alloc).  pcie_floor_ms = the bytes of the busier direction / 63 GB/s (PCIe 5.0 x16, one direction, full duplex assumed); frac = floor / measured.
+    link_measured: the same two transfers as bare hipMemcpyAsync calls, alone and both at once -- on these boxes the directions do NOT add up (57 GB/s each way
+    alone, ~61-64 GB/s combined), so frac_of_measured_link (one upload + one download at once / the batch's time per frame) is the honest yardstick: ~1.1-1.2,
+    the deeper queue of the batch gets slightly more out of the link than one pair of copies does."""
     import numpy as np
     L = ipa.lib()
     W, H = 6000, 4000
@@ -570,6 +573,27 @@ def host_boundary_leg(ctx, ipa, util, n=6, check=True):
             raise RuntimeError("ipk_host_alloc failed")
         for i, q in enumerate(sp):
             ctypes.memmove(q, frames[i % 2].ctypes.data, in_bytes)
+        torch = ctx.torch
+        s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+        d_up = torch.empty(in_bytes, dtype=torch.uint8, device="cuda")
+
+        def link(ob, host_dst):
+            """what the link itself gives these two transfers (hipMemcpyAsync, page-locked): each alone, and both at once on two streams"""
+            d_dn = torch.empty(ob, dtype=torch.uint8, device="cuda")
+            up = lambda: L.ipk_memcpy_h2d(d_up.data_ptr(), sp[0], in_bytes, s_up.cuda_stream)
+            dn = lambda: L.ipk_memcpy_d2h(host_dst, d_dn.data_ptr(), ob, s_dn.cuda_stream)
+
+            def tm(fn, reps=4):
+                fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e3
+            a, b, c = tm(up), tm(dn), tm(lambda: (up(), dn()))
+            del d_dn
+            return {"up_alone_ms": round(a, 3), "down_alone_ms": round(b, 3), "both_at_once_ms": round(c, 3), "up_GBps": round(in_bytes / a / 1e6, 1), "down_GBps": round(ob / b / 1e6, 1),
+                    "combined_GBps_both_at_once": round((in_bytes + ob) / c / 1e6, 1)}
         for name, ot, esz in (("to_u8", ipa.OUT_U8, 1), ("to_f32", ipa.OUT_F32, 4)):
             ob = W * H * 3 * esz
             dp = [L.ipk_host_alloc(ob) for _ in range(n)]
@@ -601,6 +625,11 @@ def host_boundary_leg(ctx, ipa, util, n=6, check=True):
                  "pcie_floor_ms": {"single (up + down in turn)": round(floor_serial, 3), "batched (directions overlap)": round(floor_overlap, 3)},
                  "frac_of_pcie_floor": {"single": round(floor_serial / t_one, 4), "batched": round(floor_overlap / t_b, 4)},
                  "used_fused": bool(used.value)}
+            # the floor above assumes a full-duplex link; THIS box's link, measured now: the two directions share most of one direction's rate
+            lk = link(ob, dp[0])
+            e["link_measured"] = lk
+            e["moved_GBps_batched"] = round((in_bytes + ob) / t_b / 1e6, 1)
+            e["frac_of_measured_link"] = round(lk["both_at_once_ms"] / t_b, 4) if t_b > 0 else None
             if check and name == "to_u8":
                 import oracle
                 od = oracle.make_pipeline(frames[(n - 1) % 2], cfa="RGGB", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4, wb_coeffs=util.WB,

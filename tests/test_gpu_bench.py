@@ -143,6 +143,7 @@ def test_bench_reports_the_box_state_and_the_host_boundary():
     for k in ("to_u8", "to_f32"):
         e = hb[k]
         assert e["ms_per_frame_batched"] > 0 and e["ms_per_frame_single"] > 0 and 0 < e["frac_of_pcie_floor"]["batched"] <= 1.2 and e["used_fused"] is True, e
+    assert hb["to_u8"]["link_measured"]["up_GBps"] > 5 and hb["to_u8"]["link_measured"]["both_at_once_ms"] > 0 and hb["to_f32"]["frac_of_measured_link"] > 0.3
     assert "output_8bit" in hb["to_u8"]["parity_check"] and hb["to_f32"]["pcie_bytes_per_frame"]["down"] == 4 * hb["to_u8"]["pcie_bytes_per_frame"]["down"]
     assert d["failed_legs"] == []
 

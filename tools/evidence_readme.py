@@ -75,8 +75,11 @@ def glance():
         hb = b.get("host_boundary")
         if hb and "to_u8" in hb:
             rows.append(("host boundary: 24 MP u16 in HOST memory → sRGB in HOST memory (`host_boundary`, `ipk_host_pipeline_run(_batch)`, page-locked)", "; ".join(
-                "%s %.2f ms alone / **%.2f ms per frame batched** (PCIe floor %.2f: %.2f)" % (k.replace("to_", "→ "), hb[k]["ms_per_frame_single"], hb[k]["ms_per_frame_batched"],
-                                                                                           hb[k]["pcie_floor_ms"]["batched (directions overlap)"], hb[k]["frac_of_pcie_floor"]["batched"]) for k in ("to_u8", "to_f32") if k in hb)))
+                "%s %.2f ms alone / **%.2f ms per frame batched** (full-duplex PCIe floor %.2f: %.2f%s)" % (
+                    k.replace("to_", "→ "), hb[k]["ms_per_frame_single"], hb[k]["ms_per_frame_batched"], hb[k]["pcie_floor_ms"]["batched (directions overlap)"], hb[k]["frac_of_pcie_floor"]["batched"],
+                    "; the link measured in the same run: %.0f / %.0f GB/s up / down alone, %.0f combined when both run -- one upload + one download at once take %.2f ms" % (
+                        hb[k]["link_measured"]["up_GBps"], hb[k]["link_measured"]["down_GBps"], hb[k]["link_measured"]["combined_GBps_both_at_once"], hb[k]["link_measured"]["both_at_once_ms"])
+                    if "link_measured" in hb[k] else "") for k in ("to_u8", "to_f32") if k in hb)))
         if "cpu_baseline" in b:
             cb = b["cpu_baseline"]
             rows.append(("CPU baseline (`kind: %s`)" % cb["kind"], "%.1f %s on %d cores" % (cb["value"], cb["unit"], cb["cores"])))
