@@ -40,12 +40,25 @@ __global__ __launch_bounds__(1024) void k_walk(Args a) {
     } else if (a.mode == 6) {                              // the kernel's dealing over a STRIP-major numbering (neighbouring tasks = vertically adjacent segments)
       const unsigned u = ((wv / 4u) * gridDim.x + blockIdx.x) * 4u + (wv % 4u) + k * n_waves;
       t = u < a.n_tasks ? (u % a.n_segs) * a.n_strips + u / a.n_segs : u;
+    } else if (a.mode == 8 || a.mode == 9) {               // block-synchronous: the block's waves take 16 (8: 8 + 8 a round of blocks apart) neighbouring strips of one
+      const unsigned grp = a.mode == 8 ? 16u : 8u;         // segment and meet at a barrier every row: 48 (24) KB of every output row written together
+      const unsigned ngrp = (a.n_strips + grp - 1) / grp;  // strip groups per segment
+      const unsigned slot = (wv / grp) * gridDim.x + blockIdx.x + k * (gridDim.x * (16u / grp));      // which (segment, group)
+      const unsigned seg = slot / ngrp, gi = slot % ngrp;
+      const unsigned strip = min(gi * grp + (wv % grp), a.n_strips - 1);
+      t = seg < a.n_segs ? seg * a.n_strips + strip : 0xFFFFFFFFu;
     } else {                                               // 7: XCD-contiguous: block b runs on XCD b % 8; XCD x gets the x-th eighth of the tasks
       const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (a.n_tasks + 7u) / 8u;
       const unsigned u = (j * 16u + wv) + k * (n_waves / 8u);
       t = u < per ? xcd * per + u : 0xFFFFFFFFu;
     }
     t = __builtin_amdgcn_readfirstlane(t);
+    if (a.mode >= 8 && a.mode <= 9) {
+      // every wave of the block runs the same number of trips and rows (idle ones only meet the barriers)
+      const unsigned slots = a.n_segs * ((a.n_strips + (a.mode == 8 ? 16u : 8u) - 1) / (a.mode == 8 ? 16u : 8u));
+      if (blockIdx.x + k * (gridDim.x * (a.mode == 8 ? 1u : 2u)) >= slots) break;
+      if (t >= a.n_tasks) { for (unsigned r = 0; r < a.seg_rows; ++r) __builtin_amdgcn_s_barrier(); continue; }
+    } else
     if (t >= a.n_tasks) break;
     const unsigned strip = t % a.n_strips, seg = t / a.n_strips;
     const unsigned r0 = seg * a.seg_rows, r1 = min(a.H, r0 + a.seg_rows);
@@ -57,7 +70,8 @@ __global__ __launch_bounds__(1024) void k_walk(Args a) {
     for (int v = 0; v < V; ++v) { cur[v] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(sp + 256 * v)); }
     #pragma unroll
     for (int v = 0; v < V; ++v) { nxt[v] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(sp + (size_t)min(1u, r1 - r0 - 1) * a.W + 256 * v)); }
-    for (unsigned r = r0; r < r1; ++r) {
+    for (unsigned r = r0; r < r0 + (a.mode >= 8 && a.mode <= 9 ? a.seg_rows : r1 - r0); ++r) {
+      if (a.mode >= 8 && a.mode <= 9) { __builtin_amdgcn_s_barrier(); if (r >= r1) continue; }
       const unsigned ahead = min(r + 2u, r1 - 1u) - r0;
       #pragma unroll
       for (int v = 0; v < V; ++v) nn[v] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(sp + (size_t)ahead * a.W + 256 * v));
@@ -108,6 +122,9 @@ int main(int argc, char **argv) {
     run("512-px strips, one task per wave, the kernel's dealing", 2, 0, 0);
     run("512-px strips, one task per wave, wave g = task g", 2, 1, 0);
     run("1024-px strips, one task per wave, the kernel's dealing", 4, 0, 0);
+    run("256-px strips, 16 neighbours per block in lockstep (barrier per row)", 1, 8, 0);
+    run("256-px strips, 2 x 8 neighbours per block in lockstep", 1, 9, 0);
+    run("256-px strips, 16 neighbours in lockstep, 32-row tasks", 1, 8, 32);
     run("256-px strips, spread 1", 1, 3, 0);
     run("256-px strips, spread 2", 1, 4, 0);
     run("256-px strips, spread 8", 1, 5, 0);
