@@ -278,3 +278,24 @@ def test_fused_params_first_layout_object_is_accepted(L, orc):
     for bad in (0, 16, C.sizeof(FusedParams) + 8):
         p.struct_size = bad
         assert L.ipk_host_raw_to_srgb(C.byref(p), P(raw), P(out)) == -2, bad
+
+
+@pytest.mark.parametrize("devices,n,w,h", [(["0", "0"], 7, 512, 200), (["0"], 3, 300, 97), (["0", "0", "0"], 5, 1024, 64)])
+def test_multi_context_batch_from_a_plain_cpp_host(orc, devices, n, w, h):
+    """tests/cpp/multi_test.cpp: the Rust drop-in's shape as a compiled C++ program -- ipk_init_devices, the shoot developed through the single-context loop,
+    ipk_host_pipeline_run_batch_multi (f32 and 8-bit), the caller's own worker threads under ipk_ctx_make_current, and device-resident frames through
+    ipk_pipeline_run_batch_multi + ipk_devices_sync: all bit-identical inside the program; its frame 0 against the oracle here"""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "build", "multi_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp")])
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "f0.f32")
+        r = subprocess.run([exe, str(n), str(w), str(h), out] + devices, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "MULTI_OK %d members" % len(devices) in r.stdout, r.stdout + r.stderr
+        got = np.fromfile(out, np.float32).reshape(h, w, 3)
+        raw = np.fromfile(out + ".u16", np.uint16).reshape(h, w)
+    assert_bits_equal(got, _want(orc, raw), "multi_test frame 0 vs oracle")

@@ -159,3 +159,19 @@ def test_fused_params_versioning_without_a_gpu(L):
     # the end of every layout differs from the next one's by at least the struct's alignment, or a size could not tell them apart
     for t, a, b in ((_lib.FusedParams, 16, 20), (_lib.PipelineDesc, 17, 21)):
         assert _round8(L.ipk_abi_sizeof(a)) < _round8(L.ipk_abi_sizeof(b)) < C.sizeof(t)
+
+
+def test_cpp_multi_context_host_fails_loudly_without_a_gpu():
+    """tests/cpp/multi_test.cpp (the Rust drop-in's shape as a compiled host) builds against the header and, without a GPU, stops at ipk_init_devices with the
+    library's error text -- it never computes anything on the CPU"""
+    import os
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_multictx.py runs it")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "build", "multi_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp")])
+    r = subprocess.run([exe, "2", "64", "32", "/dev/null", "0", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and "MULTI_OK" not in r.stdout, r.stdout + r.stderr
