@@ -184,6 +184,7 @@ SIGNATURES = {
     "ipk_stream_probe": (C.c_int, [C.POINTER(FusedParams), _vp, _vp, _vp]),
     "ipk_selftest_spline3": (C.c_int, [C.c_float, _fp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_quant8": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "ipk_selftest_q8": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_cbrtf": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "ipk_selftest_task_queue": (C.c_int, [C.c_int]),
     "ipk_selftest_cache_put": (C.c_int, [_vp, C.c_char_p, _sz]),
@@ -237,6 +238,8 @@ def load():
             "or `make -C imagepipe_amd/csrc`. There is no CPU fallback." % SO_PATH)
     lib = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("IPK_SO_OVERRIDE") and not hasattr(lib, name):
+            continue                     # a development A/B against an OLDER build of the library (tools/*_ab.sh): what it lacks cannot be called
         fn = getattr(lib, name)          # AttributeError here = the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args

@@ -68,6 +68,7 @@ struct ipk_ctx {
   int num_cus = 0;
   void *lut_pairs[3] = {nullptr, nullptr, nullptr};      // device, 8192 x {v, dv}
   void *lut_plain[3] = {nullptr, nullptr, nullptr};      // device, 8193 floats
+  void *lut_q8 = nullptr;                                // device, 8192 x {k, threshold}: OpGamma + output8bit as one step lookup
   std::map<std::string, DevCfa> cfa_cache;
   std::map<std::string, float *> rot_cells;              // generic-CFA cell records laid out for a rotated space (pattern, orientation, frame phase)
   // stream-ordered scratch pool for the staged pipeline's intermediate OpBuffers
@@ -414,6 +415,10 @@ static int ctx_build(Context &c, int device) {
     HIPCHK(hipMalloc(&c.lut_plain[t], ipk::kLutLen * sizeof(float)));
     HIPCHK(hipMemcpy(c.lut_plain[t], g_host.lut_host[t].data(), ipk::kLutLen * sizeof(float), hipMemcpyHostToDevice));
   }
+  HIPCHK(hipMalloc(&c.lut_q8, 8192 * 8));
+  ipk::launch_build_q8(c.lut_pairs[ipk::kLutGamma], c.lut_q8, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
   // the row-walking kernels' task-queue heads, one block for all streams of this context (nothing is allocated at launch time, so launches can be captured)
   c.queues = ipk::create_task_queues();
   if (!c.queues) return fail(IPK_ERR_HIP, "task queue allocation failed");
@@ -454,6 +459,7 @@ static void ctx_release(Context &c) {
   // before destroying a context -- the device-wide wait below is the backstop, as it was for ipk_shutdown)
   (void)hipDeviceSynchronize();
   for (int t = 0; t < 3; ++t) { if (c.lut_pairs[t]) (void)hipFree(c.lut_pairs[t]); c.lut_pairs[t] = nullptr; if (c.lut_plain[t]) (void)hipFree(c.lut_plain[t]); c.lut_plain[t] = nullptr; }
+  if (c.lut_q8) { (void)hipFree(c.lut_q8); c.lut_q8 = nullptr; }
   {
     std::lock_guard<std::mutex> lk(c.mu);
     for (auto &kv : c.cfa_cache) { (void)hipFree(kv.second.lookups); (void)hipFree(kv.second.cfa48); if (kv.second.gen_cells) (void)hipFree(kv.second.gen_cells); }
@@ -1125,7 +1131,7 @@ static int fused_impl(const ipk_fused_params *p, const void *src, void *dst, voi
   f.linear = p->linear;
   f.out_type = probe ? 4 : p->out_type;
   f.lab_table = cx().lut_plain[ipk::kLutXyzLab]; f.gam_table = cx().lut_plain[ipk::kLutGamma]; f.lab_pairs = cx().lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = cx().lut_pairs[ipk::kLutGamma];
-  f.num_cus = cx().num_cus; f.queues = cx().queues;
+  f.num_cus = cx().num_cus; f.queues = cx().queues; f.gam_q8 = cx().lut_q8;
   if (p->schedule != IPK_SCHED_AUTO && p->schedule != IPK_SCHED_SPLIT) return fail(IPK_ERR_INVALID, "bad schedule");
   f.schedule = p->schedule;
   { const int lrc = ipk::launch_fused_bayer(f, S(stream));
@@ -1288,6 +1294,13 @@ int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint6
   void *dev; rc = selftest_alloc(&dev); if (rc) return rc;
   if (ipk::launch_selftest_spline3(sp, dev, nullptr) != 0) { (void)hipFree(dev); return fail(IPK_ERR_UNSUPPORTED, "the kernels keep the select form for this curve"); }
   HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
+int ipk_selftest_q8(uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  if (!n_bad) return fail(IPK_ERR_INVALID, "bad selftest arguments");
+  void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;
+  ipk::launch_selftest_q8(cx().lut_pairs[ipk::kLutGamma], cx().lut_q8, dev, nullptr); HIPCHK(hipGetLastError());
   return selftest_collect(dev, n_bad, first_bad_bits);
 }
 int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_bad_bits) {

@@ -211,6 +211,17 @@ __device__ __forceinline__ float gamma_sample(const LutPair *__restrict__ gam, f
   return lut_interp(gam, rs_min(rs_max(v, 0.0f), 1.0f));
 }
 
+// OpGamma's step FOLLOWED BY output8bit (src/ops/gamma.rs:22, src/color_conversions.rs:323-326), as one lookup.  Inside one segment of the 13-bit gamma table
+// the interpolated value rises by at most 12.92 / 8191 = 0.0016, i.e. by 0.40 of an 8-bit step: the quantised result of every clamped sample c of
+// segment i is therefore k_i or k_i + 1, and -- every f32 operation on the way being monotone in c -- it is k_i + (c >= t_i) for ONE threshold t_i
+// (+inf where the segment holds no step).  The table is built ON THE DEVICE from the pair table by bisection with the literal expression
+// (k_build_q8), and the identity is then checked for every f32 bit pattern (ipk_selftest_q8): 3 instructions + one 8-byte read per sample instead of 7 + one.
+struct __attribute__((aligned(8))) Q8Entry { uint32_t k; float t; };
+__device__ __forceinline__ uint32_t q8_sample(const Q8Entry *__restrict__ tab, float c /* already clamped to [0, 1] */) {
+  const Q8Entry e = tab[f32_as_u32_sat(c * kLutMaxF)];
+  return e.k + (c >= e.t ? 1u : 0u);
+}
+
 // output8bit / output16bit (src/color_conversions.rs:323-330)
 __device__ __forceinline__ uint8_t output8bit_literal(float v) {
   return (uint8_t)f32_as_u32_sat(rs_min(rs_max(v * 256.0f, 0.0f), 255.0f));

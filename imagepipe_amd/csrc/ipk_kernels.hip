@@ -107,6 +107,10 @@ __device__ __forceinline__ void stage_table_direct(LutPair *s_tab, const float *
   if (blockDim.x == 1024) stage_lds_direct(s_tab, pairs, kLutPairs * 8u);
   else fill_lds_table_any(s_tab, plain);
 }
+__device__ __forceinline__ void stage_q8_direct(Q8Entry *s_tab, const Q8Entry *q8) {
+  if (blockDim.x == 1024) stage_lds_direct(s_tab, q8, kLutPairs * 8u);
+  else for (int i = threadIdx.x; i < kLutPairs; i += blockDim.x) s_tab[i] = q8[i];
+}
 __device__ __forceinline__ void stage_table_direct(float *s_tab, const float *plain, const LutPair *) {
   if (blockDim.x != 1024) { fill_lds_table_any(s_tab, plain); return; }
   stage_lds_direct(s_tab, plain, kLutPairs * 4u);
@@ -1474,6 +1478,7 @@ struct FusedArgs {
   const float *lab_table;
   const float *gam_table;     // SRGB_GAMMA_TRANSFORM, 8193 plain floats
   const LutPair *lab_pairs, *gam_pairs;   // the two tables as 8192 {v, dv} pairs (the LDS image of the pair form)
+  const Q8Entry *gam_q8;      // gamma + output8bit as 8192 {k, threshold} steps (ipk_device.hpp Q8Entry): the 8-bit-output variants' LDS image
   const float *gen_cells;     // generic-CFA mode: gen_pw*gen_ph cells of 36 floats (ipk_host.hpp Cfa::gen_cells), else null
   uint32_t gen_pw, gen_ph;    // pattern width / height (both divide 48)
   int gen_check;              // generic-CFA mode, u16 sources: 1 when the host could not show that every normalised sample is ordinary
@@ -1909,6 +1914,27 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
     bb[g] = X * S2(pm[6]) + Y * S2(pm[7]) + Z * S2(pm[8]);
   }
   if (TOLAB_ONLY) return bad;
+  constexpr bool Q8 = std::is_same<GT, Q8Entry>::value;        // the 8-bit-output variants: gamma + output8bit as one step lookup, results as integers in float BITS
+  if constexpr (Q8) {
+    #pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const float x6[6] = {rr[g].x, rr[g].y, gg[g].x, gg[g].y, bb[g].x, bb[g].y};
+      uint32_t q[6];
+      if (!linear) {
+        float c[6]; Q8Entry e[6];
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = __builtin_amdgcn_fmed3f(x6[k], 0.0f, 1.0f);
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) e[k] = reinterpret_cast<const Q8Entry *>(s_gam)[f32_as_u32_sat(c[k] * kLutMaxF)];
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = e[k].k + (c[k] >= e[k].t ? 1u : 0u);
+      } else {
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(x6[k] * 256.0f), 0u, 0u);   // == output8bit (ipk_selftest_quant8 variant 1)
+      }
+      rr[g] = F2(__uint_as_float(q[0]), __uint_as_float(q[1])); gg[g] = F2(__uint_as_float(q[2]), __uint_as_float(q[3])); bb[g] = F2(__uint_as_float(q[4]), __uint_as_float(q[5]));
+    }
+  } else {
   if (!linear) {
     float pos[6 * NP]; LutPair e[6 * NP];
     #pragma unroll
@@ -1931,6 +1957,7 @@ __device__ __forceinline__ bool pointwise4_fast(const FusedArgs &a, const float 
       bb[g] = F2(p[4].x, p[5].x) + F2(w[4], w[5]) * F2(p[4].y, p[5].y);
     }
   }
+  }
   #pragma unroll
   for (int g = 0; g < NP; ++g) {
     o[2 * g].r = rr[g].x; o[2 * g].g = gg[g].x; o[2 * g].b = bb[g].x;
@@ -1948,7 +1975,14 @@ __device__ __forceinline__ PixOut pointwise_exact(const FusedArgs &a, const LT *
   if (a.has_curve) l = spline_interpolate_lds(s_knots, a.spline.npoints, a.spline.nseg, l);
   PixOut o;
   lab_to_rgb(a.rgbm, l, ca, cb, o.r, o.g, o.b);
-  if (!a.linear) { o.r = gamma_sample_plain(s_gam, o.r); o.g = gamma_sample_plain(s_gam, o.g); o.b = gamma_sample_plain(s_gam, o.b); }
+  if (!a.linear) {
+    if constexpr (std::is_same<GT, Q8Entry>::value) {      // the LDS holds the 8-bit step table: this rare path reads the pair table where it lives
+      o.r = gamma_sample_plain(a.gam_pairs, o.r); o.g = gamma_sample_plain(a.gam_pairs, o.g); o.b = gamma_sample_plain(a.gam_pairs, o.b);
+    } else { o.r = gamma_sample_plain(s_gam, o.r); o.g = gamma_sample_plain(s_gam, o.g); o.b = gamma_sample_plain(s_gam, o.b); }
+  }
+  if constexpr (std::is_same<GT, Q8Entry>::value) {        // ... and hands back what the fast form does: the quantised samples in float bits
+    o.r = __uint_as_float((uint32_t)output8bit(o.r)); o.g = __uint_as_float((uint32_t)output8bit(o.g)); o.b = __uint_as_float((uint32_t)output8bit(o.b));
+  }
   return o;
 }
 
@@ -2059,6 +2093,14 @@ template <> struct OutStage<0> {   // f32: 12 dwords per lane, 3 x dwordx4 store
   }
 };
 template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
+  // the samples arrive already quantised (integers 0..255 in the floats' bits: pointwise4_fast / pointwise_exact with the Q8Entry table)
+  static __device__ __forceinline__ void stage_bits(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
+    auto B = [](float f) { return __float_as_uint(f); };
+    uint32_t *p = stg + 3 * lane;
+    p[0] = (B(o[0].r) | (B(o[0].g) << 8)) | ((B(o[0].b) | (B(o[1].r) << 8)) << 16);
+    p[1] = (B(o[1].g) | (B(o[1].b) << 8)) | ((B(o[2].r) | (B(o[2].g) << 8)) << 16);
+    p[2] = (B(o[2].b) | (B(o[3].r) << 8)) | ((B(o[3].g) | (B(o[3].b) << 8)) << 16);
+  }
   static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
     uint32_t *p = stg + 3 * lane;
     p[0] = output8bit_x4(o[0].r, o[0].g, o[0].b, o[1].r);
@@ -2152,12 +2194,16 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
   // buffer per wave (3 KB for f32) that turns the lane-blocked output (12 values per lane) into lane-interleaved 16-byte stores.
   // (the generic-CFA variants also hold their cell records in LDS and keep both tables plain)
   typedef typename std::conditional<GEN, float, LabTab>::type LabT;
-  typedef typename std::conditional<GEN || OUTS == 0, float, GamTab>::type GamT;   // f32 output: 48 KB of staging, no room for two pair tables
+  constexpr bool Q8 = OUTS == 1 && FULL && !GEN && !DEMO && !SKEL;     // 8-bit output (full strips): OpGamma + output8bit as one step lookup (Q8Entry, ipk_device.hpp)
+  typedef typename std::conditional<Q8, Q8Entry, typename std::conditional<GEN || OUTS == 0, float, GamTab>::type>::type GamT;   // f32 output: 48 KB of staging, no room for two pair tables
   __shared__ __attribute__((aligned(16))) LabT s_lab[DEMO ? 4 : kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) GamT s_gam[DEMO ? 4 : kLutPairs + 4];
   // the two tables go straight into LDS (no registers, see stage_lds_direct) and are in flight from here to the block's one barrier, which every wave
   // reaches in front of its first row's table reads (arrive() below)
-  if (!DEMO) { stage_table_direct(s_lab, a.lab_table, a.lab_pairs); stage_table_direct(s_gam, a.gam_table, a.gam_pairs); }
+  if (!DEMO) {
+    stage_table_direct(s_lab, a.lab_table, a.lab_pairs);
+    if constexpr (Q8) stage_q8_direct(s_gam, a.gam_q8); else stage_table_direct(s_gam, a.gam_table, a.gam_pairs);
+  }
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];   // base-curve knots + the 3-knot form's segment records
   __shared__ float s_par[32];                            // mul[0..3], cm[4..15], rgbm[16..24]
   __shared__ __attribute__((aligned(16))) float s_cells[GEN ? kGenMaxCells * kGenCellFloats : 4];   // generic-CFA cell records
@@ -2597,7 +2643,7 @@ __device__ __forceinline__ void fused_bayer_body(const FusedArgs &a, const Batch
         // The compiler reasons about one lane: a lane never reads back what it staged, so without these wave-scope
         // fences it treats the staging writes as dead stores / reorders them past the reads.  Wavefront-scope fences
         // and the wave barrier emit no instructions (the hardware already runs one wave's LDS operations in order).
-        OutStage<OUTS>::stage(stg, lane, o);
+        if constexpr (Q8) OutStage<1>::stage_bits(stg, lane, o); else OutStage<OUTS>::stage(stg, lane, o);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         OutStage<OUTS>::flush(stg, lane, frame_dst, (size_t)(r - a.out_r0) * a.W + pc0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2864,6 +2910,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   a.lab_table = reinterpret_cast<const float *>(f.lab_table);
   a.gam_table = reinterpret_cast<const float *>(f.gam_table);
   a.lab_pairs = reinterpret_cast<const LutPair *>(f.lab_pairs); a.gam_pairs = reinterpret_cast<const LutPair *>(f.gam_pairs);
+  a.gam_q8 = reinterpret_cast<const Q8Entry *>(f.gam_q8);
   a.gen_cells = f.gen_cells; a.gen_pw = (uint32_t)f.gen_pw; a.gen_ph = (uint32_t)f.gen_ph; a.gen_check = f.gen_check; a.px_guard = f.px_guard;
   a.ori = f.ori;
   for (int i = 0; i < 4; ++i) a.roles[i] = f.roles[i];
@@ -3287,6 +3334,49 @@ __global__ void k_selftest_quant8(SelftestOut *out, int variant) {
     if (a != b) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
   }
   if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
+// The 8-bit step table (Q8Entry): one thread per gamma-table segment bisects, over f32 BIT PATTERNS (all operations are monotone in c >= 0), for the first
+// sample of the segment, the first of the next one, and the first sample inside whose literal result -- OpGamma's step, then output8bit -- is one above
+// the segment's first.  ipk_selftest_q8 then compares the step form with the literal one on every f32.
+__device__ __forceinline__ uint32_t q8_literal(const LutPair *__restrict__ pairs, float c) { return (uint32_t)output8bit(lut_interp(pairs, c)); }
+__global__ void k_build_q8(const LutPair *__restrict__ pairs, Q8Entry *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint32_t)kLutPairs) return;
+  auto first_with_key = [&](uint32_t key) {                 // smallest bit pattern b in [0, bits(1.0)] with u32(c * 8191) >= key; bits(1.0) + 1 when there is none
+    uint32_t lo = 0u, hi = 0x3F800001u;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2u; if (f32_as_u32_sat(__uint_as_float(mid) * kLutMaxF) >= key) hi = mid; else lo = mid + 1u; }
+    return lo;
+  };
+  const uint32_t b0 = first_with_key(i), b1 = first_with_key(i + 1u);       // the segment's samples: bit patterns [b0, b1)
+  Q8Entry e; e.k = 0u; e.t = __builtin_inff();
+  if (b0 < b1) {
+    e.k = q8_literal(pairs, __uint_as_float(b0));
+    if (q8_literal(pairs, __uint_as_float(b1 - 1u)) != e.k) {
+      uint32_t lo = b0, hi = b1 - 1u;                       // the first pattern whose literal result is above k
+      while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2u; if (q8_literal(pairs, __uint_as_float(mid)) > e.k) hi = mid; else lo = mid + 1u; }
+      e.t = __uint_as_float(lo);
+    }
+  }
+  out[i] = e;
+}
+void launch_build_q8(const void *gam_pairs, void *q8_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_q8, dim3(kLutPairs / 256), dim3(256), 0, s, reinterpret_cast<const LutPair *>(gam_pairs), reinterpret_cast<Q8Entry *>(q8_out));
+}
+// every f32 x: OpGamma's step on x followed by output8bit (the literal device forms) against clamp + step lookup (what the 8-bit kernels run)
+__global__ void k_selftest_q8(const LutPair *__restrict__ pairs, const Q8Entry *__restrict__ q8, SelftestOut *out) {
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float x = __uint_as_float((unsigned)i);
+    const uint32_t a = (uint32_t)output8bit_literal(gamma_sample(pairs, x));
+    const uint32_t b = q8_sample(q8, __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f));
+    if (a != b) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
+int launch_selftest_q8(const void *gam_pairs, const void *q8, void *out_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_selftest_q8, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<const LutPair *>(gam_pairs), reinterpret_cast<const Q8Entry *>(q8), reinterpret_cast<SelftestOut *>(out_dev));
+  return 0;
 }
 // device cbrt variants on an array (the host compares with libm): 0 literal glibc port, 1 select form, 2 fast form for (1,2)
 __global__ void k_selftest_cbrt(const float *__restrict__ in, float *__restrict__ out, size_t n, int variant) {

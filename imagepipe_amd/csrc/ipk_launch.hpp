@@ -79,6 +79,7 @@ struct FusedLaunch {
   int out_type;                  // 0 f32, 1 u8, 2 u16
   const void *lab_table, *gam_table;   // plain 8193-float tables (XYZ_LAB_TRANSFORM, SRGB gamma)
   const void *lab_pairs, *gam_pairs;   // the same two as 8192 x {v[i], v[i+1] - v[i]} (built at ipk_init): the LDS image of the pair form, copied without registers
+  const void *gam_q8;                  // 8192 x {k, threshold}: OpGamma + output8bit as one step lookup (launch_build_q8), the 8-bit variants' LDS image
   int px_guard;                  // 0: u16 source whose levels and parameters the host found ordinary (kernel variant without per-pixel input guards)
   const float *gen_cells; int gen_pw, gen_ph, gen_check;   // generic-CFA mode (device cell records) or null: RGGB phase (xoff, yoff)
   int num_cus;
@@ -110,6 +111,8 @@ int launch_selftest_spline3(const SplineHost &h, void *out_dev, hipStream_t s);
 int launch_selftest_fract(void *out_dev, hipStream_t s);
 int launch_selftest_clamp(void *out_dev, hipStream_t s);
 int launch_selftest_quant8(void *out_dev, int variant, hipStream_t s);
+void launch_build_q8(const void *gam_pairs, void *q8_out, hipStream_t s);        // q8_out: 8192 x 8 bytes of device memory
+int launch_selftest_q8(const void *gam_pairs, const void *q8, void *out_dev, hipStream_t s);
 int launch_selftest_cbrt(const float *in, float *out, size_t n, int variant, hipStream_t s);
 
 }  // namespace ipk

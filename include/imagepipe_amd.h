@@ -616,6 +616,10 @@ IPK_API int ipk_selftest_spline3(float exposure, const float *points, int npoint
 /* output8bit (src/color_conversions.rs:323-326) on every f32 against a cheaper form: variant 0 v_cvt_pk_u8_f32(v*256), 1 the same of
  * floor(v*256), 2 min(saturating v_cvt_u32_f32(v*256), 255) -- the form the kernels use must report 0 mismatches */
 IPK_API int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_bad_bits);
+/* OpGamma's step followed by output8bit (src/ops/gamma.rs:22, src/color_conversions.rs:323-326) on every f32, against the ONE-lookup form the 8-bit
+ * output kernels run: clamp, then k_i + (c >= t_i) from a table of 8192 {k, threshold} steps built on the device from the gamma table (inside one of its
+ * segments the quantised value changes at most once, and every operation on the way is monotone). */
+IPK_API int ipk_selftest_q8(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* the device cbrtf routines (variant 0 literal glibc port, 1 select form, 2 form for 1<x<2) on a device array;
  * callers compare with the host libm's cbrtf (src/color_conversions.rs:123 -> f32::cbrt) */
 IPK_API int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream);

@@ -165,6 +165,15 @@ def test_output8bit_packed_form_is_exact_on_every_f32(L):
         assert (n.value == 0) == expect_zero, (variant, n.value, hex(first.value))
 
 
+def test_gamma_plus_output8bit_as_one_step_lookup_is_exact_on_every_f32(L):
+    """the 8-bit-output kernels replace OpGamma's table step + output8bit (src/ops/gamma.rs:22, src/color_conversions.rs:323-326) by ONE lookup in a table of
+    8192 {k, threshold} steps built on the device from the gamma table (inside one table segment the 8-bit value changes at most once): the literal
+    composition against clamp + step lookup on all 2^32 inputs -- negative, above 1, NaN, inf, denormal included"""
+    n = C.c_uint64(123); first = C.c_uint32()
+    assert L.ipk_selftest_q8(C.byref(n), C.byref(first)) == 0, L.ipk_last_error()
+    assert n.value == 0, (n.value, hex(first.value))
+
+
 def test_init_time_libm_check_agrees_with_the_exhaustive_one(L):
     """ipk_init compares the host's cbrtf with the device routine on 65 536 arguments and reports it (ipk_host_libm_matches); on this
     host (glibc 2.35, the routine the device ports) they agree -- the exhaustive tests above say the same for every argument"""
