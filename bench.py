@@ -776,7 +776,7 @@ def main():
             result["config"].update(clock_power_leg(ctx, wl))
             if "shader_clock_GHz" in result["config"]:
                 # the box-independent figure: shader cycles one launch takes.  The kernel is clock / power bound, so kernel_ms moves with the clock the
-                # box's firmware grants under the 1400 W cap (2.13-2.24 GHz on three boxes of one day) and this product does not (1.019-1.023 M)
+                # box's firmware grants under the 1400 W cap (2.13-2.25 GHz on the boxes of one day) and this product far less (0.99-1.02 M; the clock is probed behind the timed region, not inside it)
                 result["roofline"]["kernel_Mcycles"] = round(kernel_ms * result["config"]["shader_clock_GHz"], 4)
         except Exception as e:
             ctx.fail("clock_power", repr(e))
