@@ -415,10 +415,23 @@ static int ctx_build(Context &c, int device) {
     HIPCHK(hipMalloc(&c.lut_plain[t], ipk::kLutLen * sizeof(float)));
     HIPCHK(hipMemcpy(c.lut_plain[t], g_host.lut_host[t].data(), ipk::kLutLen * sizeof(float), hipMemcpyHostToDevice));
   }
+  // OpGamma + output8bit as one step lookup (ipk_device.hpp Q8Entry): built on the device from THIS host's gamma table, and checked against the literal
+  // composition on every f32 before the context goes live (a few milliseconds) -- the 8-bit kernels have no other form to fall back to, so a table that
+  // failed the check (it cannot, by the slope argument; a broken powf could) stops ipk_init loudly instead of producing wrong bytes
   HIPCHK(hipMalloc(&c.lut_q8, 8192 * 8));
   ipk::launch_build_q8(c.lut_pairs[ipk::kLutGamma], c.lut_q8, nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
+  {
+    struct { unsigned long long bad; unsigned int first; unsigned int pad; } h = {0, 0xFFFFFFFFu, 0};
+    void *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, sizeof(h)));
+    HIPCHK(hipMemcpy(dev, &h, sizeof(h), hipMemcpyHostToDevice));
+    ipk::launch_selftest_q8(c.lut_pairs[ipk::kLutGamma], c.lut_q8, dev, nullptr);
+    const hipError_t e = hipMemcpy(&h, dev, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(IPK_ERR_HIP, "the 8-bit step table could not be verified: %s", hipGetErrorString(e));
+    if (h.bad != 0) return fail(IPK_ERR_UNSUPPORTED, "the 8-bit step table disagrees with OpGamma + output8bit on %llu inputs (first 0x%08x): this host's gamma table is not monotone?", h.bad, h.first);
+  }
   // the row-walking kernels' task-queue heads, one block for all streams of this context (nothing is allocated at launch time, so launches can be captured)
   c.queues = ipk::create_task_queues();
   if (!c.queues) return fail(IPK_ERR_HIP, "task queue allocation failed");
