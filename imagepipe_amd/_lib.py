@@ -190,6 +190,7 @@ SIGNATURES = {
     "ipk_selftest_cache_put": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ipk_selftest_sha256": (C.c_int, [C.c_char_p, _sz, C.c_char_p]),
     "ipk_pointwise_chain": (C.c_int, [_vp, _sz, _sz, C.c_int, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, _vp, _vp]),
+    "ipk_pointwise_chain_out": (C.c_int, [_vp, _sz, _sz, C.c_int, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ipk_raster_to_srgb": (C.c_int, [_vp, C.c_int, _sz, _sz, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ipk_pipeline_takes_fastpath": (C.c_int, [C.POINTER(PipelineDesc), C.c_int]),
     "ipk_pipeline_hashes": (C.c_int, [C.POINTER(PipelineDesc), C.c_int, C.c_uint64, C.c_char_p]),

@@ -1210,7 +1210,7 @@ struct PointwisePrep {
     f.spline = &sp;
     f.linear = linear;
     f.lab_table = cx().lut_plain[ipk::kLutXyzLab]; f.gam_table = cx().lut_plain[ipk::kLutGamma]; f.lab_pairs = cx().lut_pairs[ipk::kLutXyzLab]; f.gam_pairs = cx().lut_pairs[ipk::kLutGamma];
-    f.num_cus = cx().num_cus;
+    f.num_cus = cx().num_cus; f.gam_q8 = cx().lut_q8;
     return IPK_OK;
   }
 };
@@ -1224,6 +1224,23 @@ int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int mono
   int rc = pp.prepare(monochrome, wb_coeffs, cam_to_xyz_normalized, exposure, points, npoints, linear); if (rc) return rc;
   pp.f.src = src4; pp.f.dst = dst3;
   ipk::launch_pointwise_chain(pp.f, width * height, S(stream));
+  HIPCHK(hipGetLastError());
+  return IPK_OK;
+}
+
+// the same followed by output8bit / output16bit (src/pipeline.rs:408-414, :455-461) in one pass: what output_8bit / output_16bit compute behind a staged
+// demosaic (a preview under a size limit, an X-Trans or four-colour frame) without the f32 image in between
+int ipk_pointwise_chain_out(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs, const float *cam_to_xyz_normalized,
+                            float exposure, const float *points, int npoints, int linear, int out_type, void *dst, void *stream) {
+  REQUIRE_INIT();
+  if (!src4 || !dst || !wb_coeffs || !cam_to_xyz_normalized || !dims_ok(width, height)) return fail(IPK_ERR_INVALID, "bad pointwise_chain_out arguments");
+  if (out_type == IPK_OUT_F32) return ipk_pointwise_chain(src4, width, height, monochrome, wb_coeffs, cam_to_xyz_normalized, exposure, points, npoints, linear, static_cast<float *>(dst), stream);
+  if (out_type != IPK_OUT_U8 && out_type != IPK_OUT_U16) return fail(IPK_ERR_INVALID, "bad out_type");
+  if (width * height < 256) return fail(IPK_ERR_UNSUPPORTED, "pointwise_chain_out needs at least 256 pixels (use ipk_pointwise_chain + ipk_output8bit / 16bit)");
+  PointwisePrep pp;
+  int rc = pp.prepare(monochrome, wb_coeffs, cam_to_xyz_normalized, exposure, points, npoints, linear); if (rc) return rc;
+  pp.f.src = src4; pp.f.dst = dst; pp.f.out_type = out_type;
+  if (ipk::launch_chain_quantised(pp.f, width * height, S(stream)) != 0) return fail(IPK_ERR_UNSUPPORTED, "pointwise_chain_out: frame too small");
   HIPCHK(hipGetLastError());
   return IPK_OK;
 }
@@ -1665,6 +1682,16 @@ int ipk_pipeline_run(const ipk_pipeline_desc *d, const void *src, void *dst, int
   const size_t n3 = w * h * 3 * sizeof(float);
   const bool f32_out0 = out_type == IPK_OUT_F32;
   bool chained = false;
+  if (d->allow_fused && colors == 4 && !f32_out0 && transform_noop && w * h >= 256) {
+    // ... and with output8bit / output16bit in the same pass when the caller wants 8 or 16 bits and nothing follows: the f32 image never exists
+    if (w != fw || h != fh) return fail(IPK_ERR_INVALID, "internal: produced %zux%zu, negotiated %zux%zu", w, h, fw, fh);
+    rc = ipk_pointwise_chain_out(static_cast<const float *>(buf), w, h, monochrome, d->wb_coeffs, d->cam_to_xyz_normalized, d->exposure, d->points, d->npoints,
+                                 linear, out_type, dst, stream);
+    if (rc < 0) return rc;
+    tm.rest = nullptr;
+    tm.mark("to_lab+basecurve+from_lab+gamma+quantise");
+    return IPK_OK;
+  }
   if (d->allow_fused && colors == 4) {
     // tolab + basecurve + fromlab + gamma in one pass (no cache wants the three intermediates)
     void *o = nullptr;

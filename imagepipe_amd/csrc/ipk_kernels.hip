@@ -3123,16 +3123,22 @@ int launch_tolab_fast(const FusedLaunch &f, size_t npix, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(1))) rgb8x4 { uint32_t w[3]; };
 struct __attribute__((packed, aligned(2))) rgb16x4 { uint32_t w[6]; };
+struct Rgbe32 { float4 v; };            // SrcT tag: the source is a 4-channel f32 OpBuffer (demosaic's / gofloat's RGBE pixels), not raster bytes -- the staged
+                                        // pipeline's tolab..gamma + quantisation in one pass when the caller wants 8 or 16 bits (ipk_pointwise_chain_out)
 template <typename SrcT, int OUT>
 __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npix, const LutPair *__restrict__ gamma_reverse) {
-  __shared__ LabTab s_lab[kLutPairs + 4];
-  __shared__ typename std::conditional<OUT == 0, float, GamTab>::type s_gam[kLutPairs + 4];
+  constexpr bool RGBE = std::is_same<SrcT, Rgbe32>::value;
+  constexpr bool Q8 = OUT == 1;                                         // OpGamma + output8bit as one step lookup (ipk_device.hpp Q8Entry)
+  __shared__ __attribute__((aligned(16))) LabTab s_lab[kLutPairs + 4];
+  __shared__ __attribute__((aligned(16))) typename std::conditional<Q8, Q8Entry, typename std::conditional<OUT == 0, float, GamTab>::type>::type s_gam[kLutPairs + 4];
   __shared__ __attribute__((aligned(16))) float s_knots[kKnotFloats];
   __shared__ float s_par[32];
   __shared__ float s_expand[sizeof(SrcT) == 1 ? 256 : 4];              // expand_srgb_gamma(input8bit(i)), the 256 possible RGB8 samples
   constexpr int STG = OUT == 0 ? 768 : (OUT == 1 ? 192 : 384);
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[16 * STG];
-  fill_lds_tables(s_lab, a.lab_table, s_gam, a.gam_table);
+  // the tables straight into LDS (stage_lds_direct: no registers), in flight behind the rest of the prologue
+  stage_table_direct(s_lab, a.lab_table, a.lab_pairs);
+  if constexpr (Q8) stage_q8_direct(s_gam, a.gam_q8); else stage_table_direct(s_gam, a.gam_table, a.gam_pairs);
   if (sizeof(SrcT) == 1) for (int i = threadIdx.x; i < 256; i += blockDim.x) s_expand[i] = lut_interp(gamma_reverse, input8bit((uint8_t)i));
   if (threadIdx.x < 4) s_par[threadIdx.x] = a.tolab.mul[threadIdx.x];
   else if (threadIdx.x < 16) s_par[threadIdx.x] = a.tolab.cm[threadIdx.x - 4];
@@ -3140,7 +3146,7 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
   if (threadIdx.x < kSplineMaxKnots) fill_knots(s_knots, a.spline, (int)threadIdx.x);
   __shared__ __attribute__((aligned(16))) float s_grid[kGridFloats];
   if (a.spline.grid_ok) fill_grid(s_grid, a.spline, (int)threadIdx.x);
-  __syncthreads();
+  sync_after_lds_direct();
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -3150,6 +3156,11 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
   for (uint64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
     const uint64_t base = min(chunk * 256, npix - 256);                // the last chunk ends at the last pixel
     float4 px[4];
+    if constexpr (RGBE) {
+      const float *p4 = reinterpret_cast<const float *>(a.src) + (base + 4u * lane) * 4;
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) px[j] = ld_stream4(p4 + 4 * j);
+    } else
     if (sizeof(SrcT) == 1) {
       const rgb8x4 t = *reinterpret_cast<const rgb8x4 *>(src + (base + 4u * lane) * 3);
       float e[12];
@@ -3167,6 +3178,12 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
     }
     PixOut o[4];
     bool bad = a.fast_ok == 0;
+    if (RGBE) {                                                        // the fast form drops the E term: legal while the fourth channel is +0.0 (pointwise_chain_body)
+      uint32_t wbits = 0u;
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) wbits |= __float_as_uint(px[j].w);
+      bad |= wbits != 0u;
+    }
     if (a.fast_ok) bad |= pointwise4_fast<true>(a, s_par, s_lab, s_gam, s_knots, px, o, a.has_curve != 0, a.linear != 0, 0, nullptr, s_grid);
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
       #pragma unroll
@@ -3175,7 +3192,7 @@ __global__ __launch_bounds__(1024) void k_raster_chain(FusedArgs a, uint64_t npi
         if (bad) o[j] = e;
       }
     }
-    OutStage<OUT>::stage(stg, lane, o);
+    if constexpr (Q8) OutStage<1>::stage_bits(stg, lane, o); else OutStage<OUT>::stage(stg, lane, o);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     OutStage<OUT>::flush(stg, lane, a.dst, (size_t)base);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -3188,9 +3205,22 @@ static void launch_raster_t(const FusedArgs &a, size_t npix, int out_type, const
   else if (out_type == 1) hipLaunchKernelGGL((k_raster_chain<SrcT, 1>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, gr);
   else hipLaunchKernelGGL((k_raster_chain<SrcT, 2>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, gr);
 }
+// OpToLab..OpGamma + output8bit / output16bit over a 4-channel f32 OpBuffer in one pass (f.out_type 1 or 2; npix >= 256)
+int launch_chain_quantised(const FusedLaunch &f, size_t npix, hipStream_t s) {
+  if (npix < 256 || (f.out_type != 1 && f.out_type != 2)) return -1;
+  FusedArgs a = chain_args(f);
+  a.gam_q8 = reinterpret_cast<const Q8Entry *>(f.gam_q8);
+  const size_t chunks = (npix + 255) / 256;
+  const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
+  const unsigned blocks = std::max(1u, (unsigned)std::min<size_t>(cap, (chunks + 15) / 16));
+  if (f.out_type == 1) hipLaunchKernelGGL((k_raster_chain<Rgbe32, 1>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, (const LutPair *)nullptr);
+  else hipLaunchKernelGGL((k_raster_chain<Rgbe32, 2>), dim3(blocks), dim3(1024), 0, s, a, (uint64_t)npix, (const LutPair *)nullptr);
+  return 0;
+}
 int launch_raster_chain(const FusedLaunch &f, size_t npix, int src_is_u16, const void *gamma_reverse_pairs, hipStream_t s) {
   if (npix < 256) return -1;
   FusedArgs a = chain_args(f);
+  a.gam_q8 = reinterpret_cast<const Q8Entry *>(f.gam_q8);
   const size_t chunks = (npix + 255) / 256;
   const unsigned cap = (unsigned)(f.num_cus > 0 ? f.num_cus : 256);
   const unsigned blocks = std::max(1u, (unsigned)std::min<size_t>(cap, (chunks + 15) / 16));

@@ -99,6 +99,8 @@ void launch_rotate1(const T *src, size_t owidth, size_t oheight, int64_t base_of
 // OpToLab..OpGamma in one pass over a 4-channel f32 buffer (src/dst, mul4, cm12, rgbm9, curve, linear, tables, fast_ok are read)
 int launch_pointwise_chain(const FusedLaunch &f, size_t npix, hipStream_t s);
 int launch_tolab_fast(const FusedLaunch &f, size_t npix, hipStream_t s);   // OpToLab alone on the chain's fast form
+// OpToLab..OpGamma + output8bit / output16bit in one pass over a 4-channel f32 buffer (f.out_type 1 / 2, f.gam_q8 set; npix >= 256): -1 otherwise
+int launch_chain_quantised(const FusedLaunch &f, size_t npix, hipStream_t s);
 // run_other + OpToLab..OpGamma + quantisation in one pass over an RGB8 / RGB16 raster (npix >= 256; f.out_type selects the output)
 int launch_raster_chain(const FusedLaunch &f, size_t npix, int src_is_u16, const void *gamma_reverse_pairs, hipStream_t s);
 

@@ -356,6 +356,13 @@ IPK_API int ipk_raw_to_srgb_oriented(const ipk_fused_params *p, const void *src,
 IPK_API int ipk_pointwise_chain(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs,
                                 const float *cam_to_xyz_normalized, float exposure, const float *points, int npoints, int linear,
                                 float *dst3, void *stream);
+/* The same followed by the quantise loop of output_8bit / output_16bit (src/pipeline.rs:408-414, :455-461) in ONE pass: dst receives width*height*3 samples
+ * of out_type (IPK_OUT_U8 / IPK_OUT_U16; IPK_OUT_F32 = ipk_pointwise_chain).  What ipk_pipeline_run uses behind a staged demosaic when the caller wants
+ * 8 or 16 bits and OpTransform is a no-op (a preview under a size limit, X-Trans, four-colour filters): bit-identical to ipk_pointwise_chain followed by
+ * ipk_output8bit / ipk_output16bit.  At least 256 pixels (IPK_ERR_UNSUPPORTED below). */
+IPK_API int ipk_pointwise_chain_out(const float *src4, size_t width, size_t height, int monochrome, const float *wb_coeffs,
+                                    const float *cam_to_xyz_normalized, float exposure, const float *points, int npoints, int linear,
+                                    int out_type, void *dst, void *stream);
 /* The raster-source counterpart of ipk_raw_to_srgb: OpGoFloat::run_other (src/ops/gofloat.rs:171-201; RGB8 through
  * expand_srgb_gamma(input8bit(v)), RGB16 through input16bit(v)) + OpToLab + OpBaseCurve + OpFromLab + OpGamma (+ output8bit /
  * output16bit, src/pipeline.rs:408-414,455-461) in one pass from the width*height*3 source samples to width*height*3 outputs of

@@ -395,6 +395,34 @@ def test_pointwise_chain_equals_the_four_ops(ipa, orc, mono, npix):
 
 
 @pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("npix", [256, 257, 64 * 96, 100003])
+def test_pointwise_chain_out_equals_the_four_ops_and_the_quantise_loop(ipa, orc, mono, npix):
+    """ipk_pointwise_chain_out = OpToLab -> OpBaseCurve -> OpFromLab -> OpGamma -> output8bit / output16bit (src/pipeline.rs:408-414, :455-461) in one
+    kernel: equal to the oracle's stages followed by its quantise loops, specials and a nonzero / NaN E channel included, with and without curve and
+    gamma (the 8-bit form runs OpGamma + output8bit as one step lookup); below 256 pixels it says so and writes nothing"""
+    import ctypes as C
+    import torch
+    buf = np.ascontiguousarray(_rgbe_inputs(max(npix, 3 * util.SPECIALS.size), util.SEED + 25)[:npix]).reshape(1, npix, 4)
+    src = torch.from_numpy(buf.ravel()).cuda()
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    L = ipa.lib()
+    for exposure, points, linear in [(0.0, [(0.5, 0.6)], False), (0.3, [(0.2, 0.1), (0.7, 0.9)], False), (0.0, [], True), (0.2, [(0.1, 0.07), (0.3, 0.27), (0.5, 0.6), (0.7, 0.82), (0.9, 0.95)], False)]:
+        pts = [c for p in points for c in p] or [0.0, 0.0]
+        want = orc.gamma(orc.fromlab(orc.basecurve(orc.tolab(buf, util.WB, util.cam_matrix(), monochrome=mono), exposure, points)), linear)
+        for out_type, dt, quant in ((1, torch.uint8, orc.output8bit), (2, torch.int16, orc.output16bit)):
+            dst = torch.zeros(npix * 3, dtype=dt, device="cuda")
+            rc = L.ipk_pointwise_chain_out(src.data_ptr(), npix, 1, int(mono), fa(util.WB), fa(util.cam_matrix().ravel()), exposure, fa(pts), len(points),
+                                           int(linear), out_type, dst.data_ptr(), None)
+            assert rc == 0, L.ipk_last_error()
+            got = dst.cpu().numpy() if out_type == 1 else dst.cpu().numpy().view(np.uint16)
+            w = quant(want).ravel()
+            assert np.array_equal(got, w), (mono, npix, exposure, linear, out_type, int((got != w).sum()), np.flatnonzero(got != w)[:4])
+    small = torch.zeros(255 * 3, dtype=torch.uint8, device="cuda")
+    assert L.ipk_pointwise_chain_out(src.data_ptr(), 255, 1, 0, fa(util.WB), fa(util.cam_matrix().ravel()), 0.0, fa([0.5, 0.6]), 1, 0, 1, small.data_ptr(), None) == -5
+    assert int(small.sum()) == 0
+
+
+@pytest.mark.parametrize("mono", [False, True])
 def test_tolab_vs_oracle(ipa, orc, mono):
     h, w = 64, 96
     buf = _rgbe_inputs(h * w, util.SEED + 20).reshape(h, w, 4)
