@@ -555,6 +555,9 @@ def test_config5_full_size_vs_oracle(ipa, orc):
     assert_bits_equal(got.numpy(), want, "config 5 full size")
     w, h, o8 = pipe.output_8bit()
     assert np.array_equal(o8.cpu().numpy().reshape(h, w, 3), orc.pipeline_output_8bit(_oracle_desc(orc, raw, xt, maxwidth=2160)))
+    # (both quantised previews leave through ipk_pointwise_chain_out: tolab..gamma + the quantise loop in one pass, the 8-bit one on the step table)
+    w, h, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(h, w, 3), orc.pipeline_output_16bit(_oracle_desc(orc, raw, xt, maxwidth=2160)))
 
 
 @pytest.mark.parametrize("H,W,cfa,th,tw", [(4000, 6000, "RGGB", 50, 40), (10000, 10000, "RGGB", 50, 40),
