@@ -58,6 +58,27 @@ def test_fused_f32_vs_oracle_with_specials(ipa, orc, shape):
     assert_bits_equal(got.numpy(), orc.pipeline_run(_oracle_desc(orc, raw, "GRBG")), "fused f32 specials")
 
 
+@pytest.mark.parametrize("shape", [(65, 259), (100, 1000), (40, 300)])
+@pytest.mark.parametrize("points", [[(0.5, 0.6)], [(0.1, 0.07), (0.3, 0.27), (0.5, 0.6), (0.7, 0.82), (0.9, 0.95)], []])
+def test_fused_f32_with_specials_quantised_outputs(ipa, orc, shape, points):
+    """the 8-bit variants run OpGamma + output8bit as one step lookup, and the lanes the fast form flags (NaN, inf, denormal, huge samples in the mosaic)
+    go through the literal form, which reads the gamma table where it lives and quantises itself: both against output_8bit / output_16bit of the oracle,
+    full strips (width >= 256: the step-table variants) and a narrow frame (the plain ones), 3-knot / grid / no curve"""
+    h, w = shape
+    raw = util.noise_u16(util.SEED + 35, h, w).astype(np.float32) + util.uniform_f32(util.SEED + 36, h * w).reshape(h, w)
+    raw.ravel()[11: 11 + util.SPECIALS.size] = util.SPECIALS * np.float32(16383.0)
+    raw[h // 2, :] = 16383.0 * 3.0                                                     # a blown row: every Lab ratio out of the table
+    pipe = ipa.Pipeline.new_from_source(_raw(ipa, raw, "GRBG", is_float=True))
+    pipe.ops.basecurve.points = points
+    desc = lambda: _oracle_desc(orc, raw, "GRBG", points=points)
+    ww, hh, o8 = pipe.output_8bit()
+    assert pipe.last_used_fused and (ww, hh) == (w, h)
+    got, want = o8.cpu().numpy().reshape(h, w, 3), orc.pipeline_output_8bit(desc())
+    assert np.array_equal(got, want), (int((got != want).sum()), np.argwhere(got != want)[:4])
+    ww, hh, o16 = pipe.output_16bit()
+    assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(h, w, 3), orc.pipeline_output_16bit(desc()))
+
+
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
 def test_fused_256x256_config0(ipa, orc, kind):
     """BASELINE.json configs[0]: 256x256 synthetic RGGB -> sRGB; the reference-shaped CPU path is the oracle."""
