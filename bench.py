@@ -1051,7 +1051,9 @@ def sp_child(args):
 def sp_children(ctx, args):
     """rank 0 starts sp_child over the job's devices; every rank waits for it at the barrier that follows"""
     import subprocess
+    import datetime
     res = None
+    ctx.barrier()                                   # every rank's GPU is idle before the child measures on all of them
     if ctx.rank == 0:
         try:
             devs = ",".join(str(i) for i in range(ctx.world)) if not ctx.share else ",".join("0" for _ in range(ctx.world))
@@ -1067,8 +1069,23 @@ def sp_children(ctx, args):
             res = {"ok": False, "error": repr(e)}
         if res.get("ok") is False:
             ctx.fail("scale.single_process", res["error"])
+    # The other ranks wait on the HOST (the job's key-value store), not in a collective: an RCCL barrier would sit on their GPUs as a spinning kernel for
+    # as long as the child measures on those very GPUs.  Whatever happens to the store, every rank then meets at the ordinary barrier.
+    try:
+        store = ctx.dist.distributed_c10d._get_default_store()
+        key = "ipk_sp_done_%d" % sp_children.calls
+        sp_children.calls += 1
+        if ctx.rank == 0:
+            store.set(key, "1")
+        else:
+            store.wait([key], datetime.timedelta(seconds=900))
+    except Exception as e:
+        sys.stderr.write("bench.py: rank %d: host-side wait unavailable (%r); waiting in the barrier\n" % (ctx.rank, e))
     ctx.barrier()
     return res
+
+
+sp_children.calls = 0
 
 
 def main_single_process(args):
