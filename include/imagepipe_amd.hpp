@@ -373,4 +373,39 @@ class Pipeline {
   }
 };
 
+// ---- several devices from ONE process (imagepipe_amd.h, "Several devices from ONE process") --------------------------------------------------
+// The reference is one process whose callers loop Pipeline::run over the frames of a shoot (src/lib.rs:21-26, src/pipeline.rs:246-249).
+// CurrentContext: scope guard -- inside it every call of this header (and of the C ABI) on THIS thread runs on the given context / device.
+class CurrentContext {
+ public:
+  explicit CurrentContext(ipk_ctx *c) : prev_(ipk_ctx_current()) { check(ipk_ctx_make_current(c), "ipk_ctx_make_current"); }
+  CurrentContext(const CurrentContext &) = delete;
+  CurrentContext &operator=(const CurrentContext &) = delete;
+  ~CurrentContext() { (void)ipk_ctx_make_current(prev_); }
+ private:
+  ipk_ctx *prev_;
+};
+// DeviceSet: one context per listed device ordinal (none listed: every visible device); frame i of a batch goes to member i % size().
+class DeviceSet {
+ public:
+  explicit DeviceSet(const std::vector<int> &devices = {}) { check(ipk_init_devices(devices.empty() ? nullptr : devices.data(), (int)devices.size()), "ipk_init_devices"); }
+  size_t size() const { return (size_t)ipk_device_set_size(); }
+  ipk_ctx *member(size_t i) const { return ipk_device_ctx((int)i); }
+  // a caller looping output_8bit / run over a shoot of same-shaped frames in HOST memory (page-locked: ipk_host_alloc); synchronous
+  static void develop_host(const Pipeline &p, const std::vector<const void *> &raws, const std::vector<void *> &outs, int out_type);
+  // frames resident on their member's device (frame i on member i % size()); enqueues on every device, sync() waits for all
+  static void develop_device(const Pipeline &p, const std::vector<const void *> &raws, const std::vector<void *> &outs, int out_type);
+  static void sync() { check(ipk_devices_sync(), "ipk_devices_sync"); }
+};
+inline void DeviceSet::develop_host(const Pipeline &p, const std::vector<const void *> &raws, const std::vector<void *> &outs, int out_type) {
+  if (raws.size() != outs.size()) throw Error("develop_host: as many outputs as frames");
+  ipk_pipeline_desc d = p.desc();
+  check(ipk_host_pipeline_run_batch_multi(&d, raws.data(), outs.data(), raws.size(), out_type, nullptr), "ipk_host_pipeline_run_batch_multi");
+}
+inline void DeviceSet::develop_device(const Pipeline &p, const std::vector<const void *> &raws, const std::vector<void *> &outs, int out_type) {
+  if (raws.size() != outs.size()) throw Error("develop_device: as many outputs as frames");
+  ipk_pipeline_desc d = p.desc();
+  check(ipk_pipeline_run_batch_multi(&d, raws.data(), outs.data(), raws.size(), out_type, nullptr), "ipk_pipeline_run_batch_multi");
+}
+
 }  // namespace imagepipe

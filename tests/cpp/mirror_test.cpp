@@ -52,6 +52,24 @@ int main(int argc, char **argv) {
       pipe.allow_fused = true; pipe.ops.transform.fliph = !pipe.ops.transform.fliph;
       if (edited == 0 || !same(c3->to_host(), ref->to_host())) { std::fprintf(stderr, "cached run after edit disagrees (%x)\n", edited); return 7; }
     }
+    {  // the same frame as a "shoot" of three, dealt over a device set of two contexts (both on device 0 here), host buffers in and out;
+       // and one run under the second member as the current context -- all equal to the single-context results above
+      imagepipe::DeviceSet set({0, 0});
+      if (set.size() != 2) { std::fprintf(stderr, "device set size %zu\n", set.size()); return 8; }
+      std::vector<const void *> ins; std::vector<void *> outs;
+      for (int i = 0; i < 3; ++i) {
+        void *in = ipk_host_alloc(raw.size() * 2), *out = ipk_host_alloc(o8.data.size());
+        if (!in || !out) { std::fprintf(stderr, "ipk_host_alloc\n"); return 8; }
+        std::memcpy(in, raw.data(), raw.size() * 2); ins.push_back(in); outs.push_back(out);
+      }
+      imagepipe::DeviceSet::develop_host(pipe, ins, outs, IPK_OUT_U8);
+      for (int i = 0; i < 3; ++i) if (std::memcmp(outs[i], o8.data.data(), o8.data.size()) != 0) { std::fprintf(stderr, "device-set frame %d differs\n", i); return 8; }
+      for (int i = 0; i < 3; ++i) { ipk_host_free(const_cast<void *>(ins[i])); ipk_host_free(outs[i]); }
+      { imagepipe::CurrentContext cur(set.member(1));
+        auto a2 = pipe.run();
+        if (!same(a2->to_host(), va)) { std::fprintf(stderr, "run under the second context differs\n"); return 8; } }
+      if (ipk_ctx_current() == set.member(1)) { std::fprintf(stderr, "the scope guard did not restore the context\n"); return 8; }
+    }
     std::printf("%zu %zu %d %zu\n", a->width, a->height, fused_flag ? 1 : 0, o8.data.size());
     FILE *o = std::fopen(argv[7], "wb");
     std::fwrite(va.data(), 4, va.size(), o); std::fclose(o);
