@@ -185,6 +185,7 @@ SIGNATURES = {
     "ipk_selftest_spline3": (C.c_int, [C.c_float, _fp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_quant8": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_q8": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "ipk_selftest_quant16": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ipk_selftest_cbrtf": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "ipk_selftest_task_queue": (C.c_int, [C.c_int]),
     "ipk_selftest_cache_put": (C.c_int, [_vp, C.c_char_p, _sz]),

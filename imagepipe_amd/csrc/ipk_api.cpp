@@ -1326,6 +1326,13 @@ int ipk_selftest_spline3(float exposure, const float *points, int npoints, uint6
   HIPCHK(hipGetLastError());
   return selftest_collect(dev, n_bad, first_bad_bits);
 }
+int ipk_selftest_quant16(uint64_t *n_bad, uint32_t *first_bad_bits) {
+  REQUIRE_INIT();
+  if (!n_bad) return fail(IPK_ERR_INVALID, "bad selftest arguments");
+  void *dev; int rc = selftest_alloc(&dev); if (rc) return rc;
+  ipk::launch_selftest_quant16(dev, nullptr); HIPCHK(hipGetLastError());
+  return selftest_collect(dev, n_bad, first_bad_bits);
+}
 int ipk_selftest_q8(uint64_t *n_bad, uint32_t *first_bad_bits) {
   REQUIRE_INIT();
   if (!n_bad) return fail(IPK_ERR_INVALID, "bad selftest arguments");

@@ -235,9 +235,19 @@ __device__ __forceinline__ uint32_t output8bit_x4(float a, float b, float c, flo
   w = __builtin_amdgcn_cvt_pk_u8_f32(floorf(c * 256.0f), 2u, w);
   return __builtin_amdgcn_cvt_pk_u8_f32(floorf(d * 256.0f), 3u, w);
 }
-__device__ __forceinline__ uint16_t output16bit(float v) {
+__device__ __forceinline__ uint16_t output16bit_literal(float v) {
   return (uint16_t)f32_as_u32_sat(rs_min(rs_max(roundf(v * 65535.0f), 0.0f), 65535.0f));
 }
+// Two samples into one dword.  Rust's f32::round rounds halves away from zero, which for p = v * 65535 >= 0 is floor(p + 0.5) -- the sum is exact wherever
+// it matters (p < 2^17 carries at most seven fraction bits) -- and everything the clamp does is done by the conversions: v_cvt_u32_f32 sends negatives and
+// NaN to 0 and saturates, v_cvt_pk_u16_u32 saturates at 65535.  mul, add, floor, cvt + half a pack per sample instead of roundf's six and two clamps;
+// equal to the literal form on every f32 (exhaustive: ipk_selftest_quant16).  (v_cvt_pknorm_u16_f32 rounds halves to even: 32 768 inputs differ.)
+__device__ __forceinline__ uint32_t output16bit_x2(float a, float b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 p = __builtin_amdgcn_cvt_pk_u16(f32_as_u32_sat(floorf(a * 65535.0f + 0.5f)), f32_as_u32_sat(floorf(b * 65535.0f + 0.5f)));
+  return (uint32_t)p.x | ((uint32_t)p.y << 16);
+}
+__device__ __forceinline__ uint16_t output16bit(float v) { return (uint16_t)(output16bit_x2(v, 0.0f) & 0xFFFFu); }
 // input8bit / input16bit (src/color_conversions.rs:313-320)
 __device__ __forceinline__ float input8bit(uint8_t v) { return (float)v / 255.0f; }
 __device__ __forceinline__ float input16bit(uint16_t v) { return (float)v / 65535.0f; }

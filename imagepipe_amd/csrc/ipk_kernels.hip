@@ -1176,8 +1176,8 @@ __global__ void k_output16(const float *__restrict__ src, size_t n, uint16_t *__
   const size_t n4 = ((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 7)) == 0 ? n / 4 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 v = ld_stream4(src + 4 * i);
-    st_stream_u(reinterpret_cast<uint32_t *>(dst) + 2 * i, (uint32_t)output16bit(v.x) | ((uint32_t)output16bit(v.y) << 16));
-    st_stream_u(reinterpret_cast<uint32_t *>(dst) + 2 * i + 1, (uint32_t)output16bit(v.z) | ((uint32_t)output16bit(v.w) << 16));
+    st_stream_u(reinterpret_cast<uint32_t *>(dst) + 2 * i, output16bit_x2(v.x, v.y));
+    st_stream_u(reinterpret_cast<uint32_t *>(dst) + 2 * i + 1, output16bit_x2(v.z, v.w));
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = output16bit(src[i]);
 }
@@ -2118,13 +2118,10 @@ template <> struct OutStage<1> {   // u8: 3 dwords per lane, 3 x dword stores
 };
 template <> struct OutStage<2> {   // u16: 6 dwords per lane, 3 x dwordx2 stores
   static __device__ __forceinline__ void stage(uint32_t *stg, uint32_t lane, const PixOut o[4]) {
-    uint32_t q[12];
-    #pragma unroll
-    for (int j = 0; j < 4; ++j) { q[3 * j] = output16bit(o[j].r); q[3 * j + 1] = output16bit(o[j].g); q[3 * j + 2] = output16bit(o[j].b); }
     uint2 *p = reinterpret_cast<uint2 *>(stg + 6 * lane);
-    p[0] = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
-    p[1] = make_uint2(q[4] | (q[5] << 16), q[6] | (q[7] << 16));
-    p[2] = make_uint2(q[8] | (q[9] << 16), q[10] | (q[11] << 16));
+    p[0] = make_uint2(output16bit_x2(o[0].r, o[0].g), output16bit_x2(o[0].b, o[1].r));
+    p[1] = make_uint2(output16bit_x2(o[1].g, o[1].b), output16bit_x2(o[2].r, o[2].g));
+    p[2] = make_uint2(output16bit_x2(o[2].b, o[3].r), output16bit_x2(o[3].g, o[3].b));
   }
   static __device__ __forceinline__ void flush(const uint32_t *stg, uint32_t lane, void *dst, size_t pix) {
     u64u *g = reinterpret_cast<u64u *>(reinterpret_cast<uint16_t *>(dst) + pix * 3);      // 2-byte-aligned 8-byte stores
@@ -3404,6 +3401,19 @@ __global__ void k_selftest_q8(const LutPair *__restrict__ pairs, const Q8Entry *
   }
   if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
 }
+// output16bit: the literal (v * 65535).round().max(0).min(65535) as u16 against the packed conversion form (output16bit_x2), every bit pattern, both halves
+__global__ void k_selftest_quant16(SelftestOut *out) {
+  unsigned long long bad = 0; unsigned first = 0xFFFFFFFFu;
+  const unsigned long long total = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float v = __uint_as_float((unsigned)i);
+    const uint32_t a = output16bit_literal(v);
+    const uint32_t w = output16bit_x2(v, -v), w2 = output16bit_x2(0.25f, v);
+    if ((w & 0xFFFFu) != a || (w2 >> 16) != a || (w2 & 0xFFFFu) != 16384u) { ++bad; if ((unsigned)i < first) first = (unsigned)i; }
+  }
+  if (bad) { atomicAdd(&out->bad, bad); atomicMin(&out->first_bad, first); }
+}
+int launch_selftest_quant16(void *out_dev, hipStream_t s) { hipLaunchKernelGGL(k_selftest_quant16, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<SelftestOut *>(out_dev)); return 0; }
 int launch_selftest_q8(const void *gam_pairs, const void *q8, void *out_dev, hipStream_t s) {
   hipLaunchKernelGGL(k_selftest_q8, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<const LutPair *>(gam_pairs), reinterpret_cast<const Q8Entry *>(q8), reinterpret_cast<SelftestOut *>(out_dev));
   return 0;

@@ -113,6 +113,7 @@ int launch_selftest_spline3(const SplineHost &h, void *out_dev, hipStream_t s);
 int launch_selftest_fract(void *out_dev, hipStream_t s);
 int launch_selftest_clamp(void *out_dev, hipStream_t s);
 int launch_selftest_quant8(void *out_dev, int variant, hipStream_t s);
+int launch_selftest_quant16(void *out_dev, hipStream_t s);
 void launch_build_q8(const void *gam_pairs, void *q8_out, hipStream_t s);        // q8_out: 8192 x 8 bytes of device memory
 int launch_selftest_q8(const void *gam_pairs, const void *q8, void *out_dev, hipStream_t s);
 int launch_selftest_cbrt(const float *in, float *out, size_t n, int variant, hipStream_t s);

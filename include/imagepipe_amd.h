@@ -627,6 +627,9 @@ IPK_API int ipk_selftest_quant8(int variant, uint64_t *n_bad, uint32_t *first_ba
  * output kernels run: clamp, then k_i + (c >= t_i) from a table of 8192 {k, threshold} steps built on the device from the gamma table (inside one of its
  * segments the quantised value changes at most once, and every operation on the way is monotone). */
 IPK_API int ipk_selftest_q8(uint64_t *n_bad, uint32_t *first_bad_bits);
+/* output16bit = (v*65535.0).round().max(0.0).min(65535.0) as u16 (src/color_conversions.rs:327-330; f32::round rounds halves away from zero) against the
+ * form the kernels pack their 16-bit output with -- floor(v*65535 + 0.5) through the saturating v_cvt_u32_f32 and v_cvt_pk_u16_u32 -- on every f32. */
+IPK_API int ipk_selftest_quant16(uint64_t *n_bad, uint32_t *first_bad_bits);
 /* the device cbrtf routines (variant 0 literal glibc port, 1 select form, 2 form for 1<x<2) on a device array;
  * callers compare with the host libm's cbrtf (src/color_conversions.rs:123 -> f32::cbrt) */
 IPK_API int ipk_selftest_cbrtf(const float *in, float *out, size_t n, int variant, void *stream);

@@ -165,6 +165,14 @@ def test_output8bit_packed_form_is_exact_on_every_f32(L):
         assert (n.value == 0) == expect_zero, (variant, n.value, hex(first.value))
 
 
+def test_output16bit_packed_form_is_exact_on_every_f32(L):
+    """output16bit = (v*65535).round().max(0).min(65535) as u16 (color_conversions.rs:327-330; round = halves away from zero) against
+    floor(v*65535 + 0.5) through the saturating v_cvt_u32_f32 / v_cvt_pk_u16_u32, both halves of the packed dword: all 2^32 inputs"""
+    n = C.c_uint64(123); first = C.c_uint32()
+    assert L.ipk_selftest_quant16(C.byref(n), C.byref(first)) == 0, L.ipk_last_error()
+    assert n.value == 0, (n.value, hex(first.value))
+
+
 def test_gamma_plus_output8bit_as_one_step_lookup_is_exact_on_every_f32(L):
     """the 8-bit-output kernels replace OpGamma's table step + output8bit (src/ops/gamma.rs:22, src/color_conversions.rs:323-326) by ONE lookup in a table of
     8192 {k, threshold} steps built on the device from the gamma table (inside one table segment the 8-bit value changes at most once): the literal
