@@ -560,6 +560,7 @@ class Pipeline:
         self.last_used_fused = None
         self.last_ops_run = None              # bit i set when op i executed in the last run (0 = served from the cache)
         self.source_id = 0                    # extension of the hash chain: identifies the frame inside a shared PipelineCache
+        self.schedule = 0                     # ipk_pipeline_desc.schedule (IPK_SCHED_AUTO / IPK_SCHED_SPLIT): how a fused launch shares the rows out
 
     @staticmethod
     def new_from_source(img):
@@ -621,6 +622,7 @@ class Pipeline:
         d.linear = int(st.linear)
         d.allow_fused = int(self.allow_fused)
         d.use_fastpath = int(st.use_fastpath)
+        d.schedule = int(self.schedule)
         return d
 
     def sizes(self):

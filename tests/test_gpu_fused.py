@@ -1337,3 +1337,12 @@ def test_schedule_split_is_bit_identical(h, w, src):
         util.assert_bits_equal(ob.cpu().numpy().reshape(h, w, 3), want, "split schedule vs oracle")
     with pytest.raises(ipa.IpkError, match="schedule"):
         ipa.FusedPlan(schedule=7, **kw).run(src_t, ob)
+    # ... and through the pipeline driver: ipk_pipeline_desc.schedule reaches the fused launch, the hash chain does not see it (same results, same keys)
+    img = ipa.RawImage(width=w, height=h, data=src_t, cfa="RGGB", is_float=src == "f32", blacklevels=[util.BLACK] * 4, whitelevels=[util.WHITE] * 4,
+                       wb_coeffs=util.WB, cam_to_xyz_normalized=util.cam_matrix())
+    pipe = ipa.Pipeline.new_from_source(img)
+    keys = pipe.hashes()
+    pipe.schedule = 1
+    got = pipe.run().data
+    assert pipe.last_used_fused and pipe.hashes() == keys
+    assert torch.equal(got.view(torch.int32), oa.view(torch.int32))
