@@ -294,6 +294,7 @@ class Pipeline {
  public:
   PipelineGlobals globals; PipelineOps ops;
   bool allow_fused = true, last_used_fused = false;
+  int schedule = IPK_SCHED_AUTO;                        // ipk_pipeline_desc.schedule: how a fused launch shares a frame's rows out (results unaffected)
   int last_ops_run = 0xFF;                 // bit i: op i executed in the last run (0 = served from the cache)
   uint64_t source_id = 0;                  // identifies the frame inside a shared PipelineCache (extension, see the C header)
   static PipelineCache new_cache(size_t size) { return PipelineCache(size); }
@@ -358,6 +359,7 @@ class Pipeline {
     for (size_t i = 0; i < ops.basecurve.points.size() && i < 64; ++i) { d.points[2 * i] = ops.basecurve.points[i].first; d.points[2 * i + 1] = ops.basecurve.points[i].second; }
     d.rotation = ops.transform.rotation; d.fliph = ops.transform.fliph; d.flipv = ops.transform.flipv;
     d.maxwidth = globals.settings.maxwidth; d.maxheight = globals.settings.maxheight; d.linear = globals.settings.linear; d.allow_fused = allow_fused; d.use_fastpath = globals.settings.use_fastpath;
+    d.schedule = schedule;
     return d;
   }
  private:
