@@ -1011,13 +1011,15 @@ def single_process_scale(torch, ipa, util, members, W, H, B, data, steps, warmup
         srcs = (ctypes.c_void_p * nb)(*[sp[k % len(sp)] for k in range(nb)]); dsts = (ctypes.c_void_p * nb)(*dp)
 
         def run(fn):
-            for rep in range(3):                                    # the first call builds the lanes
+            ts = []
+            for rep in range(5):                                    # the first call builds the lanes; the median of the other four is reported
                 t0 = time.perf_counter()
                 rc = fn(ctypes.byref(d), srcs, dsts, nb, ipa.OUT_U8, None)
                 if rc < 0:
                     raise RuntimeError(L.ipk_last_error().decode())
-                t = (time.perf_counter() - t0) * 1e3
-            return t
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ts = sorted(ts[1:])
+            return 0.5 * (ts[1] + ts[2])
         tNh = run(L.ipk_host_pipeline_run_batch_multi)
         first = np.frombuffer((ctypes.c_char * out_b).from_address(dp[0]), dtype=np.uint8).copy()
         with members2[0]:
