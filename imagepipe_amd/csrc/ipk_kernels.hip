@@ -26,6 +26,9 @@ using namespace ipkd;
 #define IPK_RARE(x) __builtin_expect(!!(x), 0)
 constexpr uint32_t kSpread = 4;        // static schedule: a block's waves start on groups of kSpread neighbouring tasks a round of blocks apart (fused_bayer_body)
 constexpr uint32_t kMinTaskRows = 4;   // one task per wave: at least this many rows each (fused_task_grid)
+#ifndef IPK_SPLIT_MIN_ROWS
+#define IPK_SPLIT_MIN_ROWS 16u   // IPK_SCHED_SPLIT applies when a wave's contiguous piece has at least this many rows (24 MP, 23 rows: photo-like 0.0958 -> 0.0917 ms, noise 0.1154 -> 0.1196)
+#endif
 constexpr uint32_t kStealMin = 4;      // a takeover needs at least this many rows left behind the owner's current one
 
 namespace ipk {
@@ -2958,7 +2961,7 @@ int launch_fused_bayer(const FusedLaunch &f, hipStream_t s) {
   // i + n_waves, which lie half a frame apart, so a region that costs more (blown highlights: the cube-root path) is shared by twice as many waves, at one
   // more priming per wave.  Round 5 measured it as a build flag (100 MP: photo-like 0.3812 -> 0.3683 / 0.3791 -> 0.3709 ms, noise 0.4600 -> 0.4648 /
   // 0.464 -> 0.458, smooth 0.4298 -> 0.4515: which regions a wave pairs is the luck of the frame) -- hence a caller's choice, not a default.
-  if (f.schedule == 1 && a.n_strips * a.n_segs <= (uint32_t)(f.num_cus > 0 ? f.num_cus : 256) * 16u && (a.out_r1 - a.out_r0) / a.n_segs >= 40u) {
+  if (f.schedule == 1 && a.n_strips * a.n_segs <= (uint32_t)(f.num_cus > 0 ? f.num_cus : 256) * 16u && (a.out_r1 - a.out_r0) / a.n_segs >= IPK_SPLIT_MIN_ROWS) {
     a.n_segs *= 2u; a.task_ctr = nullptr;
   }
   if (f.out_type == 4) {                                  // ipk_stream_probe: the skeleton of the headline variants (Bayer phase, full strips, no guards)

@@ -1313,7 +1313,7 @@ def test_fused_variants_quantised_outputs_24mp_vs_oracle(ipa, orc, is_float, vid
     assert np.array_equal(o16.cpu().numpy().view(np.uint16).reshape(h, w, 3), orc.pipeline_output_16bit(desc))
 
 
-@pytest.mark.parametrize("h,w,src", [(6000, 8000, "u16"), (1200, 3000, "f32"), (97, 300, "u16")])
+@pytest.mark.parametrize("h,w,src", [(6000, 8000, "u16"), (4000, 6000, "f32"), (1200, 3000, "f32"), (97, 300, "u16")])
 def test_schedule_split_is_bit_identical(h, w, src):
     """ipk_fused_params.schedule = IPK_SCHED_SPLIT deals every wave two pieces half a frame apart (48 MP: it applies; the small frames: it falls back to
     the contiguous schedule); whatever the launch does with the field, every output sample equals the AUTO launch's, and a bad value is refused"""
